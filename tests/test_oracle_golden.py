@@ -1,0 +1,212 @@
+"""Pin the CPU oracle (oracle/sbagan_oracle.py) against golden vectors that
+tools/make_golden.py produced by running the reference's own modules
+(AttnGAN2/code/{model,model_bert,GlobalAttention}.py, miscc/losses.py).
+CPU only; a few seconds."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (SMOOTH, TINY, FULL, check, check_param, d_shapes, g_shapes, load_golden,
+                     make_inputs)
+from oracle import fill
+from oracle import sbagan_oracle as O
+
+B, L = 3, 6
+
+
+@pytest.fixture(scope='module')
+def G(golden_dir):
+    return load_golden(golden_dir, 'units_tiny.npz')
+
+
+@pytest.fixture(scope='module')
+def x():
+    return make_inputs(TINY, B, L, tag=100)
+
+
+def test_word_attention_and_mask_quirk(G, x):
+    d = TINY
+    P = fill.fill_state_dict({'conv_context.weight': (d['ngf'], d['nef'], 1, 1)})
+    w = P['conv_context.weight'].requires_grad_(True)
+    h = fill.unit((B, d['ngf'], 8, 8), 201).requires_grad_(True)
+    assert np.array_equal(G['attn/mask'], x['mask'].numpy())
+    ctx, a = O.word_attention(h, x['words'], w, x['mask'])
+    # integer / bool part: exactly the same entries are masked to zero
+    assert np.array_equal((a.detach() == 0).numpy(), G['attn/att_is_zero'])
+    rows = O.word_attention_mask_rows(B, 64, x['mask'])
+    exp_zero = x['mask'].numpy()[rows]                      # [B, Q, L]
+    assert np.array_equal(np.transpose(exp_zero, (0, 2, 1)).reshape(B, -1, 8, 8),
+                          G['attn/att_is_zero'])
+    check(G, 'attn/ctx', ctx); check(G, 'attn/att', a)
+    gh, gw = torch.autograd.grad((ctx * fill.unit(tuple(ctx.shape), 202)).sum(), [h, w])
+    check(G, 'attn/gh', gh); check(G, 'attn/gw', gw)
+
+
+def test_func_attention_words_sent_kl(G, x):
+    d = TINY
+    assert np.array_equal(G['cap_lens'], x['cap_lens'].numpy())
+    assert np.array_equal(G['captions'], x['captions'].numpy())
+    feat = fill.unit((B, d['nef'], 17, 17), 211).requires_grad_(True)
+    words = x['words'].clone().requires_grad_(True)
+    wc, at = O.func_attention(words, feat, 4.0)
+    check(G, 'funcattn/wctx', wc); check(G, 'funcattn/att', at)
+    labels = torch.arange(B)
+    for cname, cids in (('', np.arange(B)), ('_sameclass', np.array([0, 1, 0]))):
+        w0, w1 = O.words_loss(feat, words, labels, x['cap_lens'], cids, B, 4.0, 5.0, 10.0)
+        assert abs(float(w0) - float(G['words_loss%s/w0' % cname])) < 1e-4 * max(1, abs(float(w0)))
+        assert abs(float(w1) - float(G['words_loss%s/w1' % cname])) < 1e-4 * max(1, abs(float(w1)))
+        gf, gq = torch.autograd.grad(w0 + w1, [feat, words])
+        check(G, 'words_loss%s/gfeat' % cname, gf, rtol=1e-3, atol=1e-5)
+        check(G, 'words_loss%s/gwords' % cname, gq, rtol=1e-3, atol=1e-5)
+        code = fill.unit((B, d['nef']), 212).requires_grad_(True)
+        sent = x['sent'].clone().requires_grad_(True)
+        s0, s1 = O.sent_loss(code, sent, labels, cids, B, 10.0)
+        assert abs(float(s0) - float(G['sent_loss%s/s0' % cname])) < 1e-4 * max(1, abs(float(s0)))
+        assert abs(float(s1) - float(G['sent_loss%s/s1' % cname])) < 1e-4 * max(1, abs(float(s1)))
+        gc, gs = torch.autograd.grad(s0 + s1, [code, sent])
+        check(G, 'sent_loss%s/gcode' % cname, gc, rtol=1e-3); check(G, 'sent_loss%s/gsent' % cname, gs, rtol=1e-3)
+    mu, lv = fill.unit((B, d['ncf']), 221), 0.3 * fill.unit((B, d['ncf']), 222)
+    assert abs(float(O.kl_loss(mu, lv)) - float(G['kl'])) < 1e-6
+
+
+def test_class_mask_bit_exact():
+    m = O.class_mask(np.array([0, 1, 0, 2, 1]), 5).numpy()
+    exp = np.zeros((5, 5), bool)
+    exp[0, 2] = exp[2, 0] = exp[1, 4] = exp[4, 1] = True
+    assert np.array_equal(m, exp)
+    assert O.class_mask(None, 3) is None
+
+
+@pytest.mark.parametrize('variant', ['model', 'bert', 'mix'])
+def test_generator_variants(G, x, variant):
+    d = TINY
+    v = 'model' if variant == 'model' else 'bert'
+    shapes = g_shapes(d, 3, v)
+    # the fixture holds one grad-norm per reference parameter: same key set
+    ref_params = sorted(k[len('g_%s/gradnorm/' % variant):] for k in G.files
+                        if k.startswith('g_%s/gradnorm/' % variant))
+    mine = sorted(k for k in shapes if k.endswith(('.weight', '.bias')))
+    assert ref_params == mine
+    P = fill.fill_state_dict(shapes)
+    for k in mine:
+        P[k].requires_grad_(True)
+    eps = torch.from_numpy(G['g_%s/eps' % variant])
+    z = x['z2'] if variant == 'mix' else x['z']
+    imgs, atts, mu, logvar = O.g_net(P, z, x['sent'], x['words'], x['mask'], eps, 3, variant)
+    for i, im in enumerate(imgs):
+        check(G, 'g_%s/img%d' % (variant, i), im, rtol=1e-3, atol=2e-5)
+    for i, a in enumerate(atts):
+        check(G, 'g_%s/att%d' % (variant, i), a, rtol=1e-3, atol=2e-5)
+    check(G, 'g_%s/mu' % variant, mu); check(G, 'g_%s/logvar' % variant, logvar)
+    loss = sum((im * fill.unit(tuple(im.shape), 230 + i)).sum() for i, im in enumerate(imgs)) \
+        + O.kl_loss(mu, logvar)
+    grads = torch.autograd.grad(loss, [P[k] for k in mine], allow_unused=True)
+    for k, g in zip(mine, grads):
+        ref = float(G['g_%s/gradnorm/%s' % (variant, k)])
+        got = 0.0 if g is None else float(g.double().norm())
+        assert abs(got - ref) <= 2e-3 * abs(ref) + 1e-5, (k, got, ref)
+    for k in shapes:
+        if k.endswith(('running_mean', 'running_var')):
+            ref = float(G['g_%s/buf/%s' % (variant, k)])
+            assert abs(float(P[k].double().sum()) - ref) <= 1e-4 * abs(ref) + 1e-4, k
+
+
+@pytest.mark.parametrize('which', [0, 1, 2])
+def test_discriminators(G, x, which):
+    d = TINY
+    shapes = d_shapes(d, which)
+    ref_params = sorted(k[len('d%d/gradnorm/' % which):] for k in G.files
+                        if k.startswith('d%d/gradnorm/' % which))
+    mine = sorted(k for k in shapes if k.endswith(('.weight', '.bias')))
+    assert ref_params == mine
+    P = fill.fill_state_dict(shapes, salt=which)
+    feat = O.d_net(P, x['imgs'][which])
+    check(G, 'd%d/feat_real' % which, feat, rtol=1e-3)
+    check(G, 'd%d/cond_logits' % which, O.d_get_logits(P, 'COND_DNET', feat, x['sent']), rtol=1e-3)
+    check(G, 'd%d/uncond_logits' % which, O.d_get_logits(P, 'UNCOND_DNET', feat), rtol=1e-3)
+    P = fill.fill_state_dict(shapes, salt=which)
+    for k in mine:
+        P[k].requires_grad_(True)
+    fake = fill.uniform((B, 3, 64 * 2 ** which, 64 * 2 ** which), 300 + which)
+    errD = O.discriminator_loss(P, x['imgs'][which], fake, x['sent'], torch.ones(B), torch.zeros(B))
+    assert abs(float(errD) - float(G['d%d/errD' % which])) < 1e-4
+    grads = torch.autograd.grad(errD, [P[k] for k in mine])
+    for k, g in zip(mine, grads):
+        ref = float(G['d%d/gradnorm/%s' % (which, k)])
+        assert abs(float(g.double().norm()) - ref) <= 2e-3 * abs(ref) + 1e-6, k
+    for k in shapes:
+        if k.endswith(('running_mean', 'running_var')):
+            ref = float(G['d%d/buf/%s' % (which, k)])
+            assert abs(float(P[k].double().sum()) - ref) <= 1e-4 * abs(ref) + 1e-4, k
+    with torch.no_grad():
+        for k in mine:
+            P[k].requires_grad_(False)
+    fk = fake.clone().requires_grad_(True)
+    f = O.d_net(P, fk)
+    l = (O.d_get_logits(P, 'COND_DNET', f, x['sent']) + O.d_get_logits(P, 'UNCOND_DNET', f)).sum()
+    check(G, 'd%d/gimg' % which, torch.autograd.grad(l, fk)[0], rtol=2e-3, atol=1e-7)
+
+
+def _run_oracle_steps(Gs, d, Bs, variant, nsteps=2, tag=500):
+    x = make_inputs(d, Bs, 18, lmax=18, tag=tag)
+    v = 'model' if variant == 'model' else 'bert'
+    PG = fill.fill_state_dict(g_shapes(d, 3, v))
+    PDs = [fill.fill_state_dict(d_shapes(d, i), salt=i) for i in range(3)]
+    st = O.OracleState(PG, PDs)
+    enc = fill.StandInImageEncoder(d['nef'])
+    outs = []
+    for step in range(nsteps):
+        noise = fill.unit((2, Bs, d['nz']) if variant == 'mix' else (Bs, d['nz']), tag + 50 + step)
+        eps = torch.from_numpy(Gs['step%d/eps' % step])
+        outs.append(O.train_step(st, x['imgs'], x['sent'], x['words'], x['mask'], x['cap_lens'],
+                                 x['class_ids'], noise, eps, enc, SMOOTH, variant=variant))
+    return st, outs
+
+
+def _check_steps(Gs, st, outs, rtol):
+    for step, o in enumerate(outs):
+        for k in ('errD0', 'errD1', 'errD2', 'errG_total', 'kl_loss',
+                  'gnormD0', 'gnormD1', 'gnormD2', 'gnormG'):
+            ref = float(Gs['step%d/%s' % (step, k)])
+            # step >= 1 follows an Adam update, whose first step is sign-like
+            # (p -= lr * g / (|g| + eps)): rounding-level differences in tiny
+            # gradients move parameters by O(lr), so later steps get 10x slack.
+            tol = rtol * (10 if step else 1)
+            assert abs(o[k] - ref) <= tol * abs(ref) + 1e-6, (step, k, o[k], ref)
+        for i, f in enumerate(o['fake']):
+            check(Gs, 'step%d/fake%d' % (step, i), f, rtol=10 * rtol, atol=1e-4, l2tol=(5e-3 if step else None))
+    nsteps = len(outs)
+    for n, p in st.PG.items():
+        if n.endswith('num_batches_tracked'):
+            assert int(p) == int(Gs['final/G/%s/sum' % n]), n
+        elif n.endswith(('running_mean', 'running_var')):
+            check(Gs, 'final/G/%s' % n, p, l2tol=1e-2)
+        else:
+            check_param(Gs, 'final/G/%s' % n, p, 2e-4 * nsteps)
+    for i, PD in enumerate(st.PDs):
+        for n, p in PD.items():
+            if n.endswith('num_batches_tracked'):
+                assert int(p) == int(Gs['final/D%d/%s/sum' % (i, n)]), n
+            elif n.endswith(('running_mean', 'running_var')):
+                check(Gs, 'final/D%d/%s' % (i, n), p, l2tol=1e-2)
+            else:
+                check_param(Gs, 'final/D%d/%s' % (i, n), p, 2e-4 * nsteps)
+    avg_sum = sum(float(a.double().sum()) for a in st.avgG.values())
+    assert abs(avg_sum - float(Gs['final/avgG_sum'])) <= 1e-3 * abs(float(Gs['final/avgG_sum'])) + 2e-2
+
+
+@pytest.mark.parametrize('variant', ['model', 'bert', 'mix'])
+def test_two_training_steps_tiny(golden_dir, variant):
+    """Full G+D step x2 (ordering, Adam, EMA, BN buffers) vs the reference
+    modules driven in trainer.py:261-299 order."""
+    Gs = load_golden(golden_dir, 'step_tiny_%s.npz' % variant)
+    st, outs = _run_oracle_steps(Gs, TINY, 3, variant)
+    _check_steps(Gs, st, outs, rtol=2e-4)
+
+
+def test_two_training_steps_full_dims(golden_dir):
+    """bird_style.yml dims (ngf 32, ndf 64, nef 256), 3 stages, B=4, 2 steps."""
+    torch.set_num_threads(8)
+    Gs = load_golden(golden_dir, 'step_full_model_b4.npz')
+    st, outs = _run_oracle_steps(Gs, FULL, 4, 'model')
+    _check_steps(Gs, st, outs, rtol=5e-4)
