@@ -1,0 +1,243 @@
+/*
+ * sbagan_hip.h -- C ABI of libsbagan_hip.so: the MI355X (gfx950) kernels behind
+ * the SBA-GAN adversarial training hot path.
+ *
+ * Conventions
+ *  - every entry point is extern "C", takes raw DEVICE pointers, sizes and a
+ *    hipStream_t (passed as void*), returns int: 0 = ok, <0 = SBA_E_* below.
+ *    Nothing is allocated, freed or synchronised inside; no global state; the
+ *    library is thread-safe per stream and graph-capturable.
+ *  - activations are NHWC ("channels last").  `dtype` selects the storage and
+ *    MFMA input type of activations / packed weights: SBA_F32 (exact f32 MFMA,
+ *    v_mfma_f32_32x32x2_f32) or SBA_BF16 (v_mfma_f32_32x32x16_bf16, f32
+ *    accumulate).  Statistics, losses, master weights, gradients of weights and
+ *    optimizer state are always f32.
+ *  - "reference" citations are relative to zhengfei0908/SBA-GAN AttnGAN2/code.
+ *    The reference has no FFI of its own: each function below
+ *    replaces the torch.nn call sequence cited next to it.
+ */
+#ifndef SBAGAN_HIP_H
+#define SBAGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBA_F32 0
+#define SBA_BF16 1
+
+#define SBA_OK 0
+#define SBA_E_ARG (-1)      /* shape / alignment / enum argument the kernels do not support */
+#define SBA_E_LAUNCH (-2)   /* hipGetLastError() != hipSuccess after the launch */
+
+#define SBA_ACT_NONE 0
+#define SBA_ACT_GLU 1       /* model.py:15-23 */
+#define SBA_ACT_LRELU 2     /* LeakyReLU(0.2), model.py:544 */
+
+#define SBA_MAX_TAPS 16
+
+/* Geometry of one implicit-GEMM convolution launch.  Output pixel (oy, ox) of
+ * the OHs x OWs sub-grid reads input pixel (oy*sy + ty[t], ox*sx + tx[t]) for
+ * tap t (zero outside the logical input), and is stored at output pixel
+ * (oy*osy + ooy, ox*osx + oox) of the OH x OW output.  ups != 0: the logical
+ * input is the nearest-neighbour x2 upsampling of the physical IH x IW tensor
+ * (reference nn.Upsample(scale_factor=2), model.py:41), read as (iy>>1, ix>>1).
+ * Packed weights for the launch are [Cout][ntaps][Cin]. */
+typedef struct sba_conv_geom {
+    int32_t N, IH, IW, Cin;
+    int32_t OH, OW, Cout;
+    int32_t OHs, OWs;
+    int32_t sy, sx;
+    int32_t osy, osx, ooy, oox;
+    int32_t ups;
+    int32_t ntaps;
+    int8_t ty[SBA_MAX_TAPS];
+    int8_t tx[SBA_MAX_TAPS];
+} sba_conv_geom;
+
+const char* sba_version(void);
+
+/* ---- convolutions (replace nn.Conv2d fwd / autograd bwd; model.py:32-35,552,563-574) ---- */
+/* y[pixel][co] = sum_t sum_ci x[gather(pixel,t)][ci] * w[co][t][ci]  (+ addend[pixel][co]).
+ * stats != NULL: also accumulates per-channel sum(y), sum(y^2) of the f32 accumulators into
+ * stats[0..Cout) and stats[Cout..2Cout) (caller zeroes it) -- the BatchNorm batch statistics. */
+int sba_conv_igemm(int dtype, const void* x, const void* w, void* y, const void* addend,
+                   float* stats, const sba_conv_geom* g, void* stream);
+/* dw[co][t][ci] += sum_pixel dy[pixel][co] * x[gather(pixel,t)][ci]   (f32 accumulate/output).
+ * ksplit > 1 splits the pixel range over that many workgroups (atomic accumulation). */
+int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* dw, const sba_conv_geom* g,
+                   int ksplit, void* stream);
+/* weight packing: master f32 [Cout][KH][KW][Cin] (= torch channels_last storage of an OIHW
+ * parameter) -> packed `dtype` weights.  mode 0: same order (cast).  mode 1: data-gradient
+ * weights of a stride-1 'same' conv: out[ci][KH-1-kh][KW-1-kw][co].  mode 2: data-gradient of
+ * the 4x4 stride-2 pad-1 conv, four parity classes: out[(py*2+px)][ci][j*2+i][co] with
+ * kh = (1-py) + 2j, kw = (1-px) + 2i. */
+int sba_pack_weight(int dtype, const float* w, void* out, int Cout, int KH, int KW, int Cin,
+                    int mode, void* stream);
+/* sum each 2x2 block: dx[n][y][x][c] = sum dup[n][2y+a][2x+b][c] (bwd of nearest x2). */
+int sba_pool2x2_sum(int dtype, const void* dup, void* dx, int N, int H, int W, int C, void* stream);
+
+/* ---- BatchNorm(train) + activation (model.py:43-44,62-65,543-544,553-554) ---- */
+/* stats (sum, sumsq over `count` rows) -> scale/shift for the normalise pass, saved mean/rstd,
+ * running stats update (momentum 0.1, unbiased var), num_batches_tracked += 1. */
+int sba_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
+                    float* mean, float* rstd, int C, int64_t count, float eps, float momentum,
+                    void* stream);
+/* out = act(y*scale+shift) (+ residual).  GLU halves the channel count.  out may have a larger
+ * channel stride (out_cstride) and offset (out_coff) so that it can be written into a concat. */
+int sba_bn_act_fwd(int dtype, const void* y, const float* scale, const float* shift,
+                   const void* residual, void* out, int64_t rows, int C, int act,
+                   int out_cstride, int out_coff, void* stream);
+/* pass 1 of the backward: red[0..C) += sum dz, red[C..2C) += sum dz*xhat, where dz is the
+ * gradient w.r.t. the BN output (activation backward applied to dout on the fly). */
+int sba_bn_act_bwd_reduce(int dtype, const void* y, const void* dout, const float* scale,
+                          const float* shift, const float* mean, const float* rstd, float* red,
+                          int64_t rows, int C, int act, int dout_cstride, int dout_coff,
+                          void* stream);
+/* pass 2: dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); also dgamma += red[C+c], dbeta += red[c]. */
+int sba_bn_act_bwd_apply(int dtype, const void* y, const void* dout, const float* scale,
+                         const float* shift, const float* mean, const float* rstd,
+                         const float* gamma, const float* red, void* dy, float* dgamma,
+                         float* dbeta, int64_t rows, int C, int act, int dout_cstride,
+                         int dout_coff, void* stream);
+/* Linear(no bias)+BatchNorm1d(train)+GLU on [B][F] f32, output permuted to NHWC [B][4*4][F/2/16]
+ * (INIT_STAGE_G.fc + view, model.py:353-356,372-373). */
+int sba_bn1d_glu_fwd(int dtype, const float* y, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, int64_t* nbt, float* mean,
+                     float* rstd, void* out, int B, int F, float eps, float momentum, void* stream);
+int sba_bn1d_glu_bwd(int dtype, const float* y, const void* dout, const float* gamma,
+                     const float* beta, const float* mean, const float* rstd, float* dy,
+                     float* dgamma, float* dbeta, int B, int F, void* stream);
+
+/* ---- small dense layers, f32 (CA_NET, MAPPING_NET, INIT fc, AdaIN style; model.py:278,306-313,330,354) ---- */
+int sba_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N,
+                   void* stream);
+/* dx = dy*W (may be NULL); dw += dy^T x; dbias += sum dy (may be NULL). */
+int sba_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw,
+                   float* dbias, int B, int K, int N, void* stream);
+/* CA_NET tail (model.py:281-294): h[B][4c] -> GLU -> mu|logvar; c = eps*exp(.5*logvar)+mu. */
+int sba_ca_fwd(const float* h, const float* eps, float* c, float* mu, float* logvar, int B, int C,
+               void* stream);
+int sba_ca_bwd(const float* h, const float* eps, const float* dc, const float* dmu,
+               const float* dlogvar, float* dh, int B, int C, void* stream);
+
+/* attention key projection conv_context (GlobalAttention.py:75,95-97): src[b][i][l] = sum_c W[i][c] words[b][c][l].
+ * bwd: dW += ..., dwords = ... (may be NULL). */
+int sba_ctx_proj_fwd(const float* words, const float* W, float* src, int B, int idf, int cdf, int L,
+                     void* stream);
+int sba_ctx_proj_bwd(const float* words, const float* W, const float* dsrc, float* dW, float* dwords,
+                     int B, int idf, int cdf, int L, void* stream);
+
+/* ---- AdaIN (model.py:324-339) ---- */
+/* per (n,c) sum/sumsq of h over HW -> mean/rstd (biased var, eps). */
+int sba_instnorm_stats(int dtype, const void* h, float* mean, float* rstd, int N, int HW, int C,
+                       float eps, void* stream);
+/* out[..., coff + c] = (style[n][c]+1)*xhat + style[n][C+c]. */
+int sba_adain_fwd(int dtype, const void* h, const float* mean, const float* rstd, const float* style,
+                  void* out, int N, int HW, int C, int out_cstride, int out_coff, void* stream);
+/* red[n][c][0..2) += (sum dout*xhat, sum dout)  -> dstyle; */
+int sba_adain_bwd_reduce(int dtype, const void* h, const void* dout, const float* mean,
+                         const float* rstd, float* red, int N, int HW, int C, int dout_cstride,
+                         int dout_coff, void* stream);
+/* dh (+)= (style+1)*rstd*(dout - mean(dout) - xhat*mean(dout*xhat)); dstyle[n][c] = red sumxhat,
+ * dstyle[n][C+c] = red sum.  accumulate != 0 adds into dh. */
+int sba_adain_bwd_apply(int dtype, const void* h, const void* dout, const float* mean,
+                        const float* rstd, const float* style, const float* red, void* dh,
+                        float* dstyle, int N, int HW, int C, int dout_cstride, int dout_coff,
+                        int accumulate, void* stream);
+
+/* ---- word attention (GlobalAttention.py:82-121) ---- */
+/* src[B][idf][L] f32 is conv_context applied to the words (use sba_linear_fwd).
+ * mask[B][L] uint8 or NULL.  mask_mode 0 = the reference's row order
+ * (row r = b*Q+q of the score matrix takes mask[r % B]), 1 = per-sample mask[b].
+ * ctx written at channel offset out_coff of a tensor with out_cstride channels.
+ * att (f32 [B][L][Q]) may be NULL. */
+int sba_word_attn_fwd(int dtype, const void* h, const float* src, const uint8_t* mask, void* ctx,
+                      float* att, int B, int Q, int idf, int L, int mask_mode, int out_cstride,
+                      int out_coff, void* stream);
+/* dh = d/dh, dsrc[B][idf][L] += d/dsrc (f32, caller zeroes).  accumulate != 0: dh += . */
+int sba_word_attn_bwd(int dtype, const void* h, const float* src, const uint8_t* mask,
+                      const void* dctx, void* dh, float* dsrc, int B, int Q, int idf, int L,
+                      int mask_mode, int dctx_cstride, int dctx_coff, int accumulate, void* stream);
+
+/* ---- image head: conv3x3(ngf->3)+tanh, NHWC in, NCHW f32 out (model.py:426-437) ---- */
+int sba_img_head_fwd(int dtype, const void* h, const float* w, float* img, int N, int H, int W,
+                     int C, void* stream);
+/* dh (+)= ..., dw[3][3][3][C] += ...  (w and dw in channels_last [co][kh][kw][ci]). */
+int sba_img_head_bwd(int dtype, const void* h, const float* w, const float* img, const float* dimg,
+                     void* dh, float* dw, int N, int H, int W, int C, int accumulate, void* stream);
+
+/* ---- discriminator stem: conv4x4 s2 p1 (3->ndf) + LeakyReLU(0.2), NCHW f32 in, NHWC out
+ *      (model.py:563-564) ---- */
+int sba_d_stem_fwd(int dtype, const float* img, const float* w, void* out, int N, int S, int C,
+                   void* stream);
+/* dw[C][4][4][3] += ; dimg (NCHW f32, may be NULL) = . `out` is the saved forward output. */
+int sba_d_stem_bwd(int dtype, const float* img, const float* w, const void* out, const void* dout,
+                   float* dimg, float* dw, int N, int S, int C, void* stream);
+
+/* ---- logits head: conv4x4 s4 (8ndf->1, bias) + sigmoid on a 4x4 map (model.py:590-592,606-607) ---- */
+int sba_logits_fwd(int dtype, const void* h, const float* w, const float* bias, float* prob, int B,
+                   int K, void* stream);
+int sba_logits_bwd(int dtype, const void* h, const float* w, const float* prob, const float* dprob,
+                   void* dh, float* dw, float* dbias, int B, int K, int accumulate, void* stream);
+/* cat(h[B][16][C], sent[B][E] tiled 4x4) -> out[B][16][C+E]  (model.py:597-600) */
+int sba_cond_cat_fwd(int dtype, const void* h, const float* sent, void* out, int B, int C, int E,
+                     void* stream);
+int sba_cond_cat_bwd(int dtype, const void* dout, void* dh, float* dsent, int B, int C, int E,
+                     int accumulate, void* stream);
+
+/* ---- losses ---- */
+/* loss[0] = sum_s weight[s] * mean BCE(prob_s, target[s]) over nseg segments given by
+ * offsets[s]..offsets[s+1] into the concatenated prob array (nn.BCELoss, losses.py:144-158,175-178).
+ * dprob = d loss / d prob (scaled later by the upstream gradient). */
+int sba_bce_multi(const float* prob, const int32_t* offsets, const float* target, const float* weight,
+                  int nseg, float* loss, float* dprob, void* stream);
+/* KL_loss (losses.py:210-214): loss, dmu, dlogvar. */
+int sba_kl_loss(const float* mu, const float* logvar, float* loss, float* dmu, float* dlogvar,
+                int n, void* stream);
+/* DAMSM word loss (losses.py:62-132 with func_attention GlobalAttention.py:31-69).
+ * feat[B][nef][R] f32 (R = 17*17), words[B][nef][L] f32, cap_lens int64[B].
+ * sim[j][i] (image j, caption i) = log sum_t exp(g2 * cos(word_t, attended context)).
+ * Saves attn[B*B][Lmax][R] and attn1 (first softmax) for the backward. */
+int sba_damsm_words_fwd(const float* feat, const float* words, const int64_t* cap_lens, float* sim,
+                        float* attn, float* attn1, float* wctx, int B, int nef, int R, int L,
+                        float gamma1, float gamma2, void* stream);
+int sba_damsm_words_bwd(const float* feat, const float* words, const int64_t* cap_lens,
+                        const float* sim, const float* attn, const float* attn1, const float* wctx,
+                        const float* dsim, float* dfeat, float* dwords, int B, int nef, int R, int L,
+                        float gamma1, float gamma2, void* stream);
+/* sentence similarity matrix (losses.py:41-47): s[j][i] = cos(cnn[j], rnn[i]) * g3. */
+int sba_damsm_sent_fwd(const float* cnn, const float* rnn, float* s, int B, int nef, float gamma3,
+                       float eps, void* stream);
+int sba_damsm_sent_bwd(const float* cnn, const float* rnn, const float* ds, float* dcnn, float* drnn,
+                       int B, int nef, float gamma3, float eps, void* stream);
+/* two cross entropies over a B x B score matrix and its transpose with labels = arange(B) and the
+ * same-class mask (uint8[B][B], may be NULL) filled with -inf (losses.py:51-56,123-129):
+ * loss[0] = CE(rows), loss[1] = CE(cols); dscore0/dscore1 = their gradients. `scale` multiplies
+ * the scores first (gamma3 for the word loss). */
+int sba_ce_pair(const float* score, const uint8_t* mask, float scale, float* loss, float* dscore0,
+                float* dscore1, int B, void* stream);
+
+/* out[k] = ga[0]*a[k] + gb[0]*b[k]: combines the two CE gradients with their upstream (device) scalars. */
+int sba_combine2(float* out, const float* a, const float* ga, const float* b, const float* gb, int n,
+                 void* stream);
+
+/* ---- optimizer (trainer.py:136-143,275,297-299) ---- */
+/* state = {int32 step; float step_size; float inv_sqrt_bc2}: step += 1 and the Adam bias
+ * corrections for (lr, beta1, beta2), computed on device so the step is graph-replayable. */
+int sba_adam_prepare(void* state, float lr, float beta1, float beta2, void* stream);
+/* Adam update of n contiguous f32 parameters; avg != NULL: EMA avg = .999*avg + .001*p;
+ * shadow != NULL: bf16 copy of the updated parameters (the packed forward weights). */
+int sba_adam_step(float* p, const float* g, float* m, float* v, float* avg, void* shadow,
+                  const void* state, int64_t n, float beta1, float beta2, float eps, float grad_scale,
+                  void* stream);
+/* y = cast(x) between f32 and dtype, n elements. */
+int sba_cast(int dtype_dst, void* dst, int dtype_src, const void* src, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBAGAN_HIP_H */

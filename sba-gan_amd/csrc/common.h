@@ -1,0 +1,94 @@
+// Shared device helpers for the SBA-GAN gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sbagan_hip.h"
+
+typedef uint16_t bf16_t;   // storage type of bf16 activations / packed weights
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;    // MFMA A/B fragment (8 bf16)
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;   // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN) on gfx950
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+
+// VEC<T>: 16-byte vector of T (4 floats / 8 bf16) for coalesced elementwise kernels
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    float4 v;
+    __device__ __forceinline__ float get(int i) const { return ((const float*)&v)[i]; }
+    __device__ __forceinline__ void set(int i, float f) { ((float*)&v)[i] = f; }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    uint4 v;
+    __device__ __forceinline__ float get(int i) const { return bf2f(((const bf16_t*)&v)[i]); }
+    __device__ __forceinline__ void set(int i, float f) { ((bf16_t*)&v)[i] = f2bf(f); }
+};
+template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
+    Vec16<T> r;
+    r.v = *reinterpret_cast<const decltype(r.v)*>(p);
+    return r;
+}
+template <typename T> __device__ __forceinline__ void st16(T* p, const Vec16<T>& r) {
+    *reinterpret_cast<decltype(r.v)*>(p) = r.v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum for blockDim.x <= 1024 threads; `sh` holds >= 16 floats; result in all threads
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sh[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += sh[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) sh[wid] = v;
+    __syncthreads();
+    float r = -INFINITY;
+    for (int i = 0; i < nw; ++i) r = fmaxf(r, sh[i]);
+    return r;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+#define SBA_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? SBA_OK : SBA_E_LAUNCH)
+#define SBA_DISPATCH(dtype, CALL)                       \
+    do {                                                \
+        if ((dtype) == SBA_F32) { using T = float; CALL; }        \
+        else if ((dtype) == SBA_BF16) { using T = bf16_t; CALL; } \
+        else return SBA_E_ARG;                          \
+    } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

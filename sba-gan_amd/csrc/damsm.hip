@@ -1,0 +1,413 @@
+// DAMSM word / sentence matching loss (miscc/losses.py:11-132 with func_attention,
+// GlobalAttention.py:31-69) for gfx950, f32 throughout.
+//
+// The reference loops over captions in Python and runs ~25 tiny kernels per caption;
+// here one workgroup handles one (caption i, image j) pair end to end: region-word
+// scores (289 x T), softmax over words, x gamma1, softmax over regions, attended
+// context (nef x T), per-word cosine, log-sum-exp.  cap_lens is read on the device
+// (no .tolist() sync).  Work is ~5 MFLOP per pair: latency/launch bound, so the
+// win is the fusion; the 289 x T x 256 contractions run on the VALU from LDS.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 320;       // threads per pair: >= R (289), 5 waves
+constexpr int CCH = 32;       // feature channels staged per LDS chunk
+constexpr int TMAX = 32;
+
+struct Lds {
+    float* q;     // [nef][Lw]   words of caption i (zero beyond T)
+    float* z;     // [Lw][R]     attention (scratch / A)
+    float* w;     // [nef][Lw]   weighted context (fwd) / dwctx (bwd)
+    float* f;     // [CCH][R]    staged feature chunk
+    float* t;     // [4*TMAX]    per-word scalars
+};
+__device__ __forceinline__ Lds carve(float* sm, int nef, int Lw, int R) {
+    Lds l;
+    l.q = sm;
+    l.z = l.q + nef * Lw;
+    l.w = l.z + Lw * R;
+    l.f = l.w + nef * Lw;
+    l.t = l.f + CCH * R;
+    return l;
+}
+inline size_t lds_bytes(int nef, int Lw, int R) {
+    return sizeof(float) * ((size_t)2 * nef * Lw + (size_t)Lw * R + (size_t)CCH * R + 4 * TMAX);
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
+    const float* __restrict__ feat, const float* __restrict__ words, const int64_t* __restrict__ cap_lens,
+    float* __restrict__ sim, float* __restrict__ attn, float* __restrict__ attn1, float* __restrict__ wctx_o,
+    int B, int nef, int R, int Lw, float gamma1, float gamma2) {
+    extern __shared__ float sm[];
+    Lds L = carve(sm, nef, Lw, R);
+    const int i = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6, nw = NT / 64;
+    int T = (int)cap_lens[i];
+    T = T < 1 ? 1 : (T > Lw ? Lw : T);
+    const int64_t pair = (int64_t)j * B + i;
+    const float* fj = feat + (int64_t)j * nef * R;
+
+    for (int k = tid; k < nef * Lw; k += NT) {
+        const int t = k % Lw;
+        L.q[k] = t < T ? words[(int64_t)i * nef * Lw + k] : 0.f;
+    }
+    __syncthreads();
+
+    // phase 1: S[r][t] = sum_c f[c][r] q[c][t]; softmax over t; x gamma1
+    float s[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) s[t] = 0.f;
+    if (tid < R) {
+        for (int c = 0; c < nef; ++c) {
+            const float fv = fj[(int64_t)c * R + tid];
+            const float* qr = &L.q[c * Lw];
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (t < Lw) s[t] += fv * qr[t];
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+            if (t < T) mx = fmaxf(mx, s[t]);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            s[t] = t < T ? expf(s[t] - mx) : 0.f;
+            sum += s[t];
+        }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+            if (t < T) {
+                const float a1 = s[t] * inv;
+                attn1[(pair * Lw + t) * R + tid] = a1;
+                L.z[t * R + tid] = a1 * gamma1;
+            }
+    }
+    __syncthreads();
+    // phase 2: softmax over regions for each word (one wave per word)
+    for (int t = wid; t < T; t += nw) {
+        float mx = -INFINITY;
+        for (int r = lane; r < R; r += 64) mx = fmaxf(mx, L.z[t * R + r]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int r = lane; r < R; r += 64) {
+            const float e = expf(L.z[t * R + r] - mx);
+            L.z[t * R + r] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int r = lane; r < R; r += 64) {
+            const float a = L.z[t * R + r] * inv;
+            L.z[t * R + r] = a;
+            attn[(pair * Lw + t) * R + r] = a;
+        }
+    }
+    __syncthreads();
+    // phase 3: wctx[c][t] = sum_r f[c][r] A[t][r], feature staged CCH channels at a time
+    for (int c0 = 0; c0 < nef; c0 += CCH) {
+        for (int k = tid; k < CCH * R; k += NT) L.f[k] = fj[(int64_t)c0 * R + k];
+        __syncthreads();
+        for (int o = tid; o < CCH * T; o += NT) {
+            const int cl = o / T, t = o - cl * T;
+            float acc = 0.f;
+            for (int r = 0; r < R; ++r) acc += L.f[cl * R + r] * L.z[t * R + r];
+            L.w[(c0 + cl) * Lw + t] = acc;
+            wctx_o[(pair * Lw + t) * nef + c0 + cl] = acc;
+        }
+        __syncthreads();
+    }
+    // phase 4: cosine per word, then log-sum-exp
+    for (int t = wid; t < T; t += nw) {
+        float w12 = 0.f, n1 = 0.f, n2 = 0.f;
+        for (int c = lane; c < nef; c += 64) {
+            const float qv = L.q[c * Lw + t], wv = L.w[c * Lw + t];
+            w12 += qv * wv; n1 += qv * qv; n2 += wv * wv;
+        }
+        w12 = wave_sum(w12); n1 = wave_sum(n1); n2 = wave_sum(n2);
+        if (lane == 0) L.t[t] = w12 / fmaxf(sqrtf(n1) * sqrtf(n2), 1e-8f);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float z = 0.f;
+        for (int t = 0; t < T; ++t) z += expf(gamma2 * L.t[t]);
+        sim[pair] = logf(z);
+    }
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
+    const float* __restrict__ feat, const float* __restrict__ words, const int64_t* __restrict__ cap_lens,
+    const float* __restrict__ sim, const float* __restrict__ attn, const float* __restrict__ attn1,
+    const float* __restrict__ wctx_i, const float* __restrict__ dsim, float* __restrict__ dfeat,
+    float* __restrict__ dwords, int B, int nef, int R, int Lw, float gamma1, float gamma2) {
+    extern __shared__ float sm[];
+    Lds L = carve(sm, nef, Lw, R);
+    const int i = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6, nw = NT / 64;
+    int T = (int)cap_lens[i];
+    T = T < 1 ? 1 : (T > Lw ? Lw : T);
+    const int64_t pair = (int64_t)j * B + i;
+    const float* fj = feat + (int64_t)j * nef * R;
+    const float g = dsim[pair];
+    const float zsum = expf(sim[pair]);
+
+    for (int k = tid; k < nef * Lw; k += NT) {
+        const int t = k % Lw, c = k / Lw;
+        L.q[k] = t < T ? words[(int64_t)i * nef * Lw + k] : 0.f;
+        L.w[k] = t < T ? wctx_i[(pair * Lw + t) * nef + c] : 0.f;
+    }
+    __syncthreads();
+    // per word: cos, norms -> dcos; scalars kept in L.t: [t]=dcos/(n1 n2), [TMAX+t]=dcos*cos/n2^2,
+    // [2TMAX+t]=dcos*cos/n1^2 (for the direct word gradient), [3TMAX+t]=clamped flag
+    for (int t = wid; t < T; t += nw) {
+        float w12 = 0.f, n1 = 0.f, n2 = 0.f;
+        for (int c = lane; c < nef; c += 64) {
+            const float qv = L.q[c * Lw + t], wv = L.w[c * Lw + t];
+            w12 += qv * wv; n1 += qv * qv; n2 += wv * wv;
+        }
+        w12 = wave_sum(w12); n1 = wave_sum(n1); n2 = wave_sum(n2);
+        if (lane == 0) {
+            const float den = sqrtf(n1) * sqrtf(n2);
+            const bool clamped = den < 1e-8f;
+            const float cosv = w12 / fmaxf(den, 1e-8f);
+            const float dcos = g * gamma2 * expf(gamma2 * cosv) / zsum;
+            L.t[t] = dcos / fmaxf(den, 1e-8f);
+            L.t[TMAX + t] = clamped ? 0.f : dcos * cosv / n2;
+            L.t[2 * TMAX + t] = clamped ? 0.f : dcos * cosv / n1;
+        }
+    }
+    __syncthreads();
+    // dq_direct[c][t] (kept in registers of the owning thread is not possible: write to dwords now),
+    // then overwrite L.w with dwctx[c][t] = a*q - b*wctx
+    for (int k = tid; k < nef * Lw; k += NT) {
+        const int t = k % Lw, c = k / Lw;
+        if (t < T) {
+            const float qv = L.q[k], wv = L.w[k];
+            if (dwords)
+                atomicAdd(&dwords[((int64_t)i * nef + c) * Lw + t], L.t[t] * wv - L.t[2 * TMAX + t] * qv);
+            L.w[k] = L.t[t] * qv - L.t[TMAX + t] * wv;
+        } else {
+            L.w[k] = 0.f;
+        }
+    }
+    __syncthreads();
+    // pass A over the features: dA[t][r] = sum_c dwctx[c][t] f[c][r]
+    float dA[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) dA[t] = 0.f;
+    if (tid < R) {
+        for (int c = 0; c < nef; ++c) {
+            const float fv = fj[(int64_t)c * R + tid];
+            const float* wr = &L.w[c * Lw];
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (t < Lw) dA[t] += fv * wr[t];
+        }
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+            if (t < T) L.z[t * R + tid] = dA[t] * attn[(pair * Lw + t) * R + tid];    // A*dA
+    }
+    __syncthreads();
+    // per word: dot_t = sum_r A dA
+    for (int t = wid; t < T; t += nw) {
+        float d = 0.f;
+        for (int r = lane; r < R; r += 64) d += L.z[t * R + r];
+        d = wave_sum(d);
+        if (lane == 0) L.t[3 * TMAX + t] = d;
+    }
+    __syncthreads();
+    // per region: dz = A (dA - dot), da1 = gamma1 dz, dS = a1 (da1 - sum_t a1 da1); keep A and dS in registers
+    float av[TMAX], ds[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) { av[t] = 0.f; ds[t] = 0.f; }
+    if (tid < R) {
+        float dot1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+            if (t < T) {
+                const float a = attn[(pair * Lw + t) * R + tid];
+                const float a1 = attn1[(pair * Lw + t) * R + tid];
+                const float da1 = gamma1 * a * (dA[t] - L.t[3 * TMAX + t]);
+                av[t] = a;
+                ds[t] = da1;          // temporarily da1
+                dA[t] = a1;           // reuse dA[] for a1
+                dot1 += a1 * da1;
+            }
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t)
+            if (t < T) {
+                ds[t] = dA[t] * (ds[t] - dot1);
+                L.z[t * R + tid] = ds[t];
+            }
+        // pass B: dfeat[c][r] += sum_t dwctx[c][t] A[t][r] + dS[r][t] q[c][t]
+        for (int c = 0; c < nef; ++c) {
+            const float* wr = &L.w[c * Lw];
+            const float* qr = &L.q[c * Lw];
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (t < Lw) acc += wr[t] * av[t] + ds[t] * qr[t];
+            atomicAdd(&dfeat[((int64_t)j * nef + c) * R + tid], acc);
+        }
+    }
+    if (dwords) {
+        __syncthreads();
+        // dq[c][t] += sum_r f[c][r] dS[r][t], features staged through LDS
+        for (int c0 = 0; c0 < nef; c0 += CCH) {
+            for (int k = tid; k < CCH * R; k += NT) L.f[k] = fj[(int64_t)c0 * R + k];
+            __syncthreads();
+            for (int o = tid; o < CCH * T; o += NT) {
+                const int cl = o / T, t = o - cl * T;
+                float acc = 0.f;
+                for (int r = 0; r < R; ++r) acc += L.f[cl * R + r] * L.z[t * R + r];
+                atomicAdd(&dwords[((int64_t)i * nef + c0 + cl) * Lw + t], acc);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// sentence scores: s[j][i] = gamma3 * <cnn_j, rnn_i> / max(|cnn_j| |rnn_i|, eps)
+__global__ void damsm_sent_fwd_kernel(const float* __restrict__ cnn, const float* __restrict__ rnn,
+                                      float* __restrict__ s, int B, int nef, float gamma3, float eps) {
+    const int i = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+    float w12 = 0.f, n0 = 0.f, n1 = 0.f;
+    for (int c = lane; c < nef; c += 64) {
+        const float a = cnn[j * nef + c], b = rnn[i * nef + c];
+        w12 += a * b; n0 += a * a; n1 += b * b;
+    }
+    w12 = wave_sum(w12); n0 = wave_sum(n0); n1 = wave_sum(n1);
+    if (lane == 0) s[j * B + i] = w12 / fmaxf(sqrtf(n0) * sqrtf(n1), eps) * gamma3;
+}
+
+__global__ void damsm_sent_bwd_kernel(const float* __restrict__ cnn, const float* __restrict__ rnn,
+                                      const float* __restrict__ ds, float* __restrict__ dcnn,
+                                      float* __restrict__ drnn, int B, int nef, float gamma3, float eps) {
+    const int i = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+    float w12 = 0.f, n0 = 0.f, n1 = 0.f;
+    for (int c = lane; c < nef; c += 64) {
+        const float a = cnn[j * nef + c], b = rnn[i * nef + c];
+        w12 += a * b; n0 += a * a; n1 += b * b;
+    }
+    w12 = wave_sum(w12); n0 = wave_sum(n0); n1 = wave_sum(n1);
+    const float den = sqrtf(n0) * sqrtf(n1);
+    const bool clamped = den < eps;
+    const float g = ds[j * B + i] * gamma3;
+    const float k0 = g / fmaxf(den, eps);
+    const float ka = clamped ? 0.f : g * (w12 / den) / n0;
+    const float kb = clamped ? 0.f : g * (w12 / den) / n1;
+    for (int c = lane; c < nef; c += 64) {
+        const float a = cnn[j * nef + c], b = rnn[i * nef + c];
+        if (dcnn) atomicAdd(&dcnn[j * nef + c], k0 * b - ka * a);
+        if (drnn) atomicAdd(&drnn[i * nef + c], k0 * a - kb * b);
+    }
+}
+
+// two cross entropies (rows / columns) over a B x B score matrix with labels arange(B)
+__global__ void ce_pair_kernel(const float* __restrict__ score, const uint8_t* __restrict__ mask, float scale,
+                               float* __restrict__ loss, float* __restrict__ d0, float* __restrict__ d1, int B) {
+    extern __shared__ float s[];      // [B*B] scaled masked scores, then [2*B] row/col lse
+    float* lse = s + B * B;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < B * B; k += blockDim.x)
+        s[k] = (mask && mask[k]) ? -INFINITY : score[k] * scale;
+    __syncthreads();
+    for (int k = tid; k < 2 * B; k += blockDim.x) {
+        const bool col = k >= B;
+        const int a = col ? k - B : k;
+        float mx = -INFINITY;
+        for (int b = 0; b < B; ++b) mx = fmaxf(mx, col ? s[b * B + a] : s[a * B + b]);
+        float sum = 0.f;
+        for (int b = 0; b < B; ++b) sum += expf((col ? s[b * B + a] : s[a * B + b]) - mx);
+        lse[k] = mx + logf(sum);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float l0 = 0.f, l1 = 0.f;
+        for (int a = 0; a < B; ++a) { l0 += lse[a] - s[a * B + a]; l1 += lse[B + a] - s[a * B + a]; }
+        loss[0] = l0 / B;
+        loss[1] = l1 / B;
+    }
+    const float invB = 1.f / B;
+    for (int k = tid; k < B * B; k += blockDim.x) {
+        const int j = k / B, i = k - j * B;
+        const float dl = j == i ? 1.f : 0.f;
+        // d loss / d (unscaled score): softmax - onehot, times scale / B
+        d0[k] = (expf(s[k] - lse[j]) - dl) * invB * scale;
+        d1[k] = (expf(s[k] - lse[B + i]) - dl) * invB * scale;
+    }
+}
+
+__global__ void combine2_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ ga,
+                                const float* __restrict__ b, const float* __restrict__ gb, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = ga[0] * a[i] + gb[0] * b[i];
+}
+
+}  // namespace
+
+extern "C" int sba_damsm_words_fwd(const float* feat, const float* words, const int64_t* cap_lens, float* sim,
+                                   float* attn, float* attn1, float* wctx, int B, int nef, int R, int L,
+                                   float gamma1, float gamma2, void* stream) {
+    if (!feat || !words || !cap_lens || !sim || !attn || !attn1 || !wctx) return SBA_E_ARG;
+    if (B <= 0 || B > 1024 || nef <= 0 || nef % CCH || R <= 0 || R > NT || L <= 0 || L > TMAX) return SBA_E_ARG;
+    const size_t sh = lds_bytes(nef, L, R);
+    if (sh > 160 * 1024) return SBA_E_ARG;
+    (void)hipFuncSetAttribute((const void*)damsm_words_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)sh);
+    hipLaunchKernelGGL(damsm_words_fwd_kernel, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words, cap_lens,
+                       sim, attn, attn1, wctx, B, nef, R, L, gamma1, gamma2);
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_damsm_words_bwd(const float* feat, const float* words, const int64_t* cap_lens, const float* sim,
+                                   const float* attn, const float* attn1, const float* wctx, const float* dsim,
+                                   float* dfeat, float* dwords, int B, int nef, int R, int L, float gamma1,
+                                   float gamma2, void* stream) {
+    if (!feat || !words || !cap_lens || !sim || !attn || !attn1 || !wctx || !dsim || !dfeat) return SBA_E_ARG;
+    if (B <= 0 || B > 1024 || nef <= 0 || nef % CCH || R <= 0 || R > NT || L <= 0 || L > TMAX) return SBA_E_ARG;
+    const size_t sh = lds_bytes(nef, L, R);
+    if (sh > 160 * 1024) return SBA_E_ARG;
+    (void)hipFuncSetAttribute((const void*)damsm_words_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)sh);
+    hipLaunchKernelGGL(damsm_words_bwd_kernel, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words, cap_lens,
+                       sim, attn, attn1, wctx, dsim, dfeat, dwords, B, nef, R, L, gamma1, gamma2);
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_damsm_sent_fwd(const float* cnn, const float* rnn, float* s, int B, int nef, float gamma3,
+                                  float eps, void* stream) {
+    if (!cnn || !rnn || !s || B <= 0 || B > 1024 || nef <= 0) return SBA_E_ARG;
+    hipLaunchKernelGGL(damsm_sent_fwd_kernel, dim3(B, B), dim3(64), 0, (hipStream_t)stream, cnn, rnn, s, B, nef,
+                       gamma3, eps);
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_damsm_sent_bwd(const float* cnn, const float* rnn, const float* ds, float* dcnn, float* drnn,
+                                  int B, int nef, float gamma3, float eps, void* stream) {
+    if (!cnn || !rnn || !ds || B <= 0 || B > 1024 || nef <= 0) return SBA_E_ARG;
+    hipLaunchKernelGGL(damsm_sent_bwd_kernel, dim3(B, B), dim3(64), 0, (hipStream_t)stream, cnn, rnn, ds, dcnn, drnn,
+                       B, nef, gamma3, eps);
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_ce_pair(const float* score, const uint8_t* mask, float scale, float* loss, float* dscore0,
+                           float* dscore1, int B, void* stream) {
+    if (!score || !loss || !dscore0 || !dscore1 || B <= 0 || B > 96) return SBA_E_ARG;
+    const size_t sh = sizeof(float) * ((size_t)B * B + 2 * B);
+    hipLaunchKernelGGL(ce_pair_kernel, dim3(1), dim3(256), sh, (hipStream_t)stream, score, mask, scale, loss,
+                       dscore0, dscore1, B);
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_combine2(float* out, const float* a, const float* ga, const float* b, const float* gb, int n,
+                            void* stream) {
+    if (!out || !a || !ga || !b || !gb || n <= 0) return SBA_E_ARG;
+    hipLaunchKernelGGL(combine2_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out, a, ga, b, gb, n);
+    return SBA_CHECK_LAUNCH();
+}

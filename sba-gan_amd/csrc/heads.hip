@@ -1,0 +1,509 @@
+// Narrow-channel layers at the two ends of the networks (gfx950).  These are
+// HBM / issue-bound, not MFMA-shaped (3 image channels on one side):
+//   - generator image head  conv3x3(ngf->3)+tanh      (GET_IMAGE_G, model.py:426-437)
+//   - discriminator stem    conv4x4 s2 (3->ndf)+LReLU (encode_image_by_16times, model.py:563-564)
+//   - logits head           conv4x4 s4 (8ndf->1)+sigmoid on the 4x4 map (D_GET_LOGITS, model.py:590-607)
+//   - conditioning concat   (model.py:597-600)
+// Images stay in the reference's NCHW f32 layout at the boundary; features are NHWC.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ image head
+template <typename T, int C>
+__global__ __launch_bounds__(256) void img_head_fwd_kernel(const T* __restrict__ h, const float* __restrict__ w,
+                                                           float* __restrict__ img, int N, int H, int W) {
+    constexpr int V = Vec16<T>::N;
+    __shared__ float s_w[27 * C];            // [co][kh][kw][ci]
+    for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) s_w[i] = w[i];
+    __syncthreads();
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p >= (int64_t)N * H * W) return;
+    const int x = (int)(p % W), y = (int)((p / W) % H), n = (int)(p / ((int64_t)W * H));
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int iy = y + kh - 1;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ix = x + kw - 1;
+            if (ix < 0 || ix >= W) continue;
+            const T* hp = h + (((int64_t)n * H + iy) * W + ix) * C;
+#pragma unroll
+            for (int cv = 0; cv < C / V; ++cv) {
+                Vec16<T> v = ld16(hp + cv * V);
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const float hv = v.get(k);
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) acc[co] += hv * s_w[((co * 3 + kh) * 3 + kw) * C + cv * V + k];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < 3; ++co) img[(((int64_t)n * 3 + co) * H + y) * W + x] = tanhf(acc[co]);
+}
+
+// one thread per INPUT pixel p: d[27] = dpre of the 9 output pixels that read p (x 3 channels);
+// dh[p][ci] = sum d[co,kh,kw] w[co][kh][kw][ci];  dw[co][kh][kw][ci] += sum_p d[p][co,kh,kw] h[p][ci]
+template <typename T, int C>
+__global__ __launch_bounds__(256) void img_head_bwd_kernel(const T* __restrict__ h, const float* __restrict__ w,
+                                                           const float* __restrict__ img,
+                                                           const float* __restrict__ dimg, T* __restrict__ dh,
+                                                           float* __restrict__ dw, int N, int H, int W,
+                                                           int accumulate) {
+    constexpr int V = Vec16<T>::N;
+    constexpr int HS = C + 1, DS = 28;
+    extern __shared__ float sm[];
+    float* s_w = sm;                 // [27][C]
+    float* s_h = s_w + 27 * C;       // [256][HS]
+    float* s_d = s_h + 256 * HS;     // [256][DS]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 27 * C; i += 256) s_w[i] = w[i];
+    const int64_t total = (int64_t)N * H * W;
+    const int64_t p = blockIdx.x * (int64_t)256 + tid;
+    const bool live = p < total;
+    float d[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) d[i] = 0.f;
+    int x = 0, y = 0, n = 0;
+    if (live) {
+        x = (int)(p % W); y = (int)((p / W) % H); n = (int)(p / ((int64_t)W * H));
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int oy = y - kh + 1;
+            if (oy < 0 || oy >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ox = x - kw + 1;
+                if (ox < 0 || ox >= W) continue;
+#pragma unroll
+                for (int co = 0; co < 3; ++co) {
+                    const int64_t o = (((int64_t)n * 3 + co) * H + oy) * W + ox;
+                    const float t = img[o];
+                    d[(co * 3 + kh) * 3 + kw] = dimg[o] * (1.f - t * t);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 27; ++i) s_d[tid * DS + i] = d[i];
+    __syncthreads();     // s_w ready
+    const T* hp = h + p * C;
+    T* op = dh + p * C;
+#pragma unroll
+    for (int cv = 0; cv < C / V; ++cv) {
+        Vec16<T> hv, o, prev;
+        if (live) hv = ld16(hp + cv * V);
+        if (live && accumulate) prev = ld16(op + cv * V);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            s_h[tid * HS + cv * V + k] = live ? hv.get(k) : 0.f;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 27; ++i) acc += d[i] * s_w[i * C + cv * V + k];
+            if (live && accumulate) acc += prev.get(k);
+            o.set(k, acc);
+        }
+        if (live) st16(op + cv * V, o);
+    }
+    __syncthreads();
+    for (int o = tid; o < 27 * C; o += 256) {
+        const int i = o / C, ci = o - i * C;
+        float acc = 0.f;
+        for (int t = 0; t < 256; ++t) acc += s_d[t * DS + i] * s_h[t * HS + ci];
+        atomicAdd(&dw[o], acc);
+    }
+}
+
+// ------------------------------------------------------------------ discriminator stem
+// thread = (output pixel, V-channel vector); weights transposed in LDS as [48][C]
+template <typename T>
+__global__ __launch_bounds__(256) void d_stem_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                         T* __restrict__ out, int N, int S, int C) {
+    constexpr int V = Vec16<T>::N;
+    extern __shared__ float s_w[];       // [48][C]: k = (kh*4+kw)*3+ci
+    for (int i = threadIdx.x; i < 48 * C; i += blockDim.x) {
+        const int co = i / 48, k = i - co * 48;
+        s_w[k * C + co] = w[i];
+    }
+    __syncthreads();
+    const int O = S / 2, cv = C / V;
+    const int64_t total = (int64_t)N * O * O * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V;
+        int64_t p = i / cv;
+        const int ox = (int)(p % O), oy = (int)((p / O) % O), n = (int)(p / ((int64_t)O * O));
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+            const int iy = 2 * oy + kh - 1;
+            if (iy < 0 || iy >= S) continue;
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const int ix = 2 * ox + kw - 1;
+                if (ix < 0 || ix >= S) continue;
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float v = img[(((int64_t)n * 3 + ci) * S + iy) * S + ix];
+                    const float* wr = &s_w[((kh * 4 + kw) * 3 + ci) * C + c];
+#pragma unroll
+                    for (int k = 0; k < V; ++k) acc[k] += v * wr[k];
+                }
+            }
+        }
+        Vec16<T> o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) o.set(k, acc[k] > 0.f ? acc[k] : 0.2f * acc[k]);
+        st16(out + p * C + c, o);
+    }
+}
+
+// dw[co][k] += sum_pix dpre[pix][co] * patch[pix][k]; block = TILES x 64 output pixels,
+// thread owns a 4(co) x 3(k) register block
+template <typename T>
+__global__ __launch_bounds__(256) void d_stem_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ out,
+                                                           const T* __restrict__ dout, float* __restrict__ dw, int N,
+                                                           int S, int C, int tiles_per_block) {
+    extern __shared__ float sm[];
+    const int DS = C + 4;
+    float* s_d = sm;                 // [64][C+4]
+    float* s_p = s_d + 64 * DS;      // [64][52]
+    const int tid = threadIdx.x;
+    const int O = S / 2;
+    const int64_t total = (int64_t)N * O * O;
+    const int items = (C / 4) * 16;
+    float acc[4][12];                // up to 4 items per thread (C <= 256)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 12; ++b) acc[a][b] = 0.f;
+    for (int tile = 0; tile < tiles_per_block; ++tile) {
+        const int64_t p0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * 64;
+        if (p0 >= total) break;
+        __syncthreads();
+        for (int i = tid; i < 64 * C; i += 256) {
+            const int t = i / C, c = i - t * C;
+            const int64_t p = p0 + t;
+            float v = 0.f;
+            if (p < total) {
+                const float o = to_f<T>(out[p * C + c]);
+                v = to_f<T>(dout[p * C + c]) * (o > 0.f ? 1.f : 0.2f);
+            }
+            s_d[t * DS + c] = v;
+        }
+        for (int i = tid; i < 64 * 48; i += 256) {
+            const int t = i / 48, k = i - t * 48;
+            const int64_t p = p0 + t;
+            float v = 0.f;
+            if (p < total) {
+                const int ox = (int)(p % O), oy = (int)((p / O) % O), n = (int)(p / ((int64_t)O * O));
+                const int ci = k % 3, kw = (k / 3) % 4, kh = k / 12;
+                const int iy = 2 * oy + kh - 1, ix = 2 * ox + kw - 1;
+                if (iy >= 0 && iy < S && ix >= 0 && ix < S) v = img[(((int64_t)n * 3 + ci) * S + iy) * S + ix];
+            }
+            s_p[t * 52 + k] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int it = tid + 256 * a;
+            if (it < items) {
+                const int cg = it / 16, kg = it - cg * 16;
+                for (int t = 0; t < 64; ++t) {
+                    float dv[4], pv[3];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) dv[u] = s_d[t * DS + cg * 4 + u];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) pv[u] = s_p[t * 52 + kg * 3 + u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int v2 = 0; v2 < 3; ++v2) acc[a][u * 3 + v2] += dv[u] * pv[v2];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int it = tid + 256 * a;
+        if (it < items) {
+            const int cg = it / 16, kg = it - cg * 16;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v2 = 0; v2 < 3; ++v2)
+                    atomicAdd(&dw[(cg * 4 + u) * 48 + kg * 3 + v2], acc[a][u * 3 + v2]);
+        }
+    }
+}
+
+// dimg[n][ci][iy][ix] = sum over the (<=4) output pixels reading it, all co
+template <typename T>
+__global__ __launch_bounds__(256) void d_stem_dgrad_kernel(const float* __restrict__ w, const T* __restrict__ out,
+                                                           const T* __restrict__ dout, float* __restrict__ dimg,
+                                                           int N, int S, int C) {
+    constexpr int V = Vec16<T>::N;
+    extern __shared__ float s_w[];       // [48][C]
+    for (int i = threadIdx.x; i < 48 * C; i += blockDim.x) {
+        const int co = i / 48, k = i - co * 48;
+        s_w[k * C + co] = w[i];
+    }
+    __syncthreads();
+    const int O = S / 2;
+    const int64_t total = (int64_t)N * S * S;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        const int ix = (int)(p % S), iy = (int)((p / S) % S), n = (int)(p / ((int64_t)S * S));
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kh = ((iy + 1) & 1) + 2 * j;
+            const int oy = (iy + 1 - kh) / 2;
+            if (oy < 0 || oy >= O || iy + 1 - kh < 0) continue;
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+                const int kw = ((ix + 1) & 1) + 2 * i2;
+                const int ox = (ix + 1 - kw) / 2;
+                if (ox < 0 || ox >= O || ix + 1 - kw < 0) continue;
+                const int64_t q = (((int64_t)n * O + oy) * O + ox) * C;
+                for (int cv = 0; cv < C / V; ++cv) {
+                    Vec16<T> ov = ld16(out + q + cv * V), dv = ld16(dout + q + cv * V);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        const float dp = dv.get(k) * (ov.get(k) > 0.f ? 1.f : 0.2f);
+                        const int co = cv * V + k;
+#pragma unroll
+                        for (int ci = 0; ci < 3; ++ci) acc[ci] += dp * s_w[((kh * 4 + kw) * 3 + ci) * C + co];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) dimg[(((int64_t)n * 3 + ci) * S + iy) * S + ix] = acc[ci];
+    }
+}
+
+// ------------------------------------------------------------------ logits head
+template <typename T>
+__global__ __launch_bounds__(256) void logits_fwd_kernel(const T* __restrict__ h, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ prob,
+                                                         int K) {
+    constexpr int V = Vec16<T>::N;
+    __shared__ float sh[16];
+    const int b = blockIdx.x;
+    float acc = 0.f;
+    for (int k = threadIdx.x * V; k < K; k += blockDim.x * V) {
+        Vec16<T> v = ld16(h + (int64_t)b * K + k);
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc += v.get(i) * w[k + i];
+    }
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) prob[b] = 1.f / (1.f + expf(-(acc + bias[0])));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void logits_bwd_kernel(const T* __restrict__ h, const float* __restrict__ w,
+                                                         const float* __restrict__ prob,
+                                                         const float* __restrict__ dprob, T* __restrict__ dh,
+                                                         float* __restrict__ dw, float* __restrict__ dbias, int B,
+                                                         int K, int accumulate) {
+    constexpr int V = Vec16<T>::N;
+    extern __shared__ float s_dl[];      // [B]
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float p = prob[b];
+        s_dl[b] = dprob[b] * p * (1.f - p);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0 && dbias) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += s_dl[b];
+        dbias[0] += s;
+    }
+    const int k = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (k >= K) return;
+    float wv[V], gw[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { wv[i] = w[k + i]; gw[i] = 0.f; }
+    for (int b = 0; b < B; ++b) {
+        const float dl = s_dl[b];
+        Vec16<T> hv = ld16(h + (int64_t)b * K + k), o;
+        if (accumulate) o = ld16(dh + (int64_t)b * K + k);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            gw[i] += dl * hv.get(i);
+            o.set(i, dl * wv[i] + (accumulate ? o.get(i) : 0.f));
+        }
+        st16(dh + (int64_t)b * K + k, o);
+    }
+    if (dw) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) dw[k + i] += gw[i];
+    }
+}
+
+// ------------------------------------------------------------------ conditioning concat
+template <typename T>
+__global__ void cond_cat_fwd_kernel(const T* __restrict__ h, const float* __restrict__ sent, T* __restrict__ out,
+                                    int B, int C, int E) {
+    const int CE = C + E;
+    const int64_t total = (int64_t)B * 16 * CE;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CE);
+        const int64_t row = i / CE;          // b*16 + s
+        out[i] = c < C ? h[row * C + c] : from_f<T>(sent[(row / 16) * E + (c - C)]);
+    }
+}
+
+template <typename T>
+__global__ void cond_cat_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dh, float* __restrict__ dsent,
+                                    int B, int C, int E, int accumulate) {
+    const int CE = C + E;
+    const int64_t nh = (int64_t)B * 16 * C;
+    const int64_t total = nh + (dsent ? (int64_t)B * E : 0);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < nh) {
+            const int c = (int)(i % C);
+            const int64_t row = i / C;
+            float v = to_f<T>(dout[row * CE + c]);
+            if (accumulate) v += to_f<T>(dh[i]);
+            dh[i] = from_f<T>(v);
+        } else {
+            const int64_t j = i - nh;
+            const int e = (int)(j % E), b = (int)(j / E);
+            float s = 0.f;
+            for (int sp = 0; sp < 16; ++sp) s += to_f<T>(dout[((int64_t)b * 16 + sp) * CE + C + e]);
+            dsent[j] += s;
+        }
+    }
+}
+
+inline int grid_for(int64_t items, int cap = 8192) {
+    int64_t b = (items + 255) / 256;
+    if (b < 1) b = 1;
+    return (int)(b > cap ? cap : b);
+}
+
+template <typename K> void set_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace
+
+#define CH_SWITCH(C_, CALL)                              \
+    switch (C_) {                                        \
+        case 32: { constexpr int C = 32; CALL; } break;  \
+        case 64: { constexpr int C = 64; CALL; } break;  \
+        case 128: { constexpr int C = 128; CALL; } break;\
+        default: return SBA_E_ARG;                       \
+    }
+
+extern "C" int sba_img_head_fwd(int dtype, const void* h, const float* w, float* img, int N, int H, int W, int C_,
+                                void* stream) {
+    if (!h || !w || !img || N <= 0 || H <= 0 || W <= 0) return SBA_E_ARG;
+    const int64_t total = (int64_t)N * H * W;
+    if (total > 0x7fffffffLL * 64) return SBA_E_ARG;
+    SBA_DISPATCH(dtype, CH_SWITCH(C_, hipLaunchKernelGGL((img_head_fwd_kernel<T, C>), dim3(cdiv(total, 256)),
+                                                        dim3(256), 0, (hipStream_t)stream, (const T*)h, w, img, N,
+                                                        H, W)));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_img_head_bwd(int dtype, const void* h, const float* w, const float* img, const float* dimg,
+                                void* dh, float* dw, int N, int H, int W, int C_, int accumulate, void* stream) {
+    if (!h || !w || !img || !dimg || !dh || !dw || N <= 0 || H <= 0 || W <= 0) return SBA_E_ARG;
+    if (C_ > 64) return SBA_E_ARG;       // LDS budget of the fused wgrad reduction
+    const int64_t total = (int64_t)N * H * W;
+    SBA_DISPATCH(dtype, CH_SWITCH(C_, {
+        const size_t sh = sizeof(float) * (27 * C + 256 * (C + 1) + 256 * 28);
+        set_lds(img_head_bwd_kernel<T, C>, sh);
+        hipLaunchKernelGGL((img_head_bwd_kernel<T, C>), dim3(cdiv(total, 256)), dim3(256), sh, (hipStream_t)stream,
+                           (const T*)h, w, img, dimg, (T*)dh, dw, N, H, W, accumulate);
+    }));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_d_stem_fwd(int dtype, const float* img, const float* w, void* out, int N, int S, int C,
+                              void* stream) {
+    if (!img || !w || !out || N <= 0 || S <= 0 || S % 2 || C <= 0 || C % 8 || C > 256) return SBA_E_ARG;
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    const int64_t total = (int64_t)N * (S / 2) * (S / 2) * (C / V);
+    const size_t sh = sizeof(float) * 48 * C;
+    SBA_DISPATCH(dtype, {
+        set_lds(d_stem_fwd_kernel<T>, sh);
+        hipLaunchKernelGGL((d_stem_fwd_kernel<T>), dim3(grid_for(total, 4096)), dim3(256), sh, (hipStream_t)stream,
+                           img, w, (T*)out, N, S, C);
+    });
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_d_stem_bwd(int dtype, const float* img, const float* w, const void* out, const void* dout,
+                              float* dimg, float* dw, int N, int S, int C, void* stream) {
+    if (!img || !w || !out || !dout || N <= 0 || S <= 0 || S % 2 || C <= 0 || C % 8 || C > 256) return SBA_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dw) {
+        const int64_t pix = (int64_t)N * (S / 2) * (S / 2);
+        const int64_t tiles = (pix + 63) / 64;
+        int tpb = (int)((tiles + 511) / 512);
+        if (tpb < 1) tpb = 1;
+        const int blocks = (int)((tiles + tpb - 1) / tpb);
+        const size_t sh = sizeof(float) * (64 * (C + 4) + 64 * 52);
+        SBA_DISPATCH(dtype, {
+            set_lds(d_stem_wgrad_kernel<T>, sh);
+            hipLaunchKernelGGL((d_stem_wgrad_kernel<T>), dim3(blocks), dim3(256), sh, st, img, (const T*)out,
+                               (const T*)dout, dw, N, S, C, tpb);
+        });
+    }
+    if (dimg) {
+        const size_t sh = sizeof(float) * 48 * C;
+        SBA_DISPATCH(dtype, {
+            set_lds(d_stem_dgrad_kernel<T>, sh);
+            hipLaunchKernelGGL((d_stem_dgrad_kernel<T>), dim3(grid_for((int64_t)N * S * S, 4096)), dim3(256), sh, st,
+                               w, (const T*)out, (const T*)dout, dimg, N, S, C);
+        });
+    }
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_logits_fwd(int dtype, const void* h, const float* w, const float* bias, float* prob, int B,
+                              int K, void* stream) {
+    if (!h || !w || !bias || !prob || B <= 0 || K <= 0 || K % 8) return SBA_E_ARG;
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((logits_fwd_kernel<T>), dim3(B), dim3(256), 0, (hipStream_t)stream,
+                                           (const T*)h, w, bias, prob, K));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_logits_bwd(int dtype, const void* h, const float* w, const float* prob, const float* dprob,
+                              void* dh, float* dw, float* dbias, int B, int K, int accumulate, void* stream) {
+    if (!h || !w || !prob || !dprob || !dh || B <= 0 || B > 4096 || K <= 0 || K % 8) return SBA_E_ARG;
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((logits_bwd_kernel<T>), dim3(cdiv(K / V, 256)), dim3(256),
+                                           sizeof(float) * B, (hipStream_t)stream, (const T*)h, w, prob, dprob,
+                                           (T*)dh, dw, dbias, B, K, accumulate));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_cond_cat_fwd(int dtype, const void* h, const float* sent, void* out, int B, int C, int E,
+                                void* stream) {
+    if (!h || !sent || !out || B <= 0 || C <= 0 || E <= 0) return SBA_E_ARG;
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((cond_cat_fwd_kernel<T>), dim3(grid_for((int64_t)B * 16 * (C + E))),
+                                           dim3(256), 0, (hipStream_t)stream, (const T*)h, sent, (T*)out, B, C, E));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_cond_cat_bwd(int dtype, const void* dout, void* dh, float* dsent, int B, int C, int E,
+                                int accumulate, void* stream) {
+    if (!dout || !dh || B <= 0 || C <= 0 || E <= 0) return SBA_E_ARG;
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((cond_cat_bwd_kernel<T>), dim3(grid_for((int64_t)B * 16 * C + B * E)),
+                                           dim3(256), 0, (hipStream_t)stream, (const T*)dout, (T*)dh, dsent, B, C, E,
+                                           accumulate));
+    return SBA_CHECK_LAUNCH();
+}

@@ -1,0 +1,543 @@
+// Implicit-GEMM convolution kernels for gfx950 (MI355X): forward / data-gradient
+// (one kernel, driven by a tap table) and weight-gradient.  NHWC activations,
+// [Cout][tap][Cin] packed weights, MFMA 32x32 tiles with f32 accumulation
+// (v_mfma_f32_32x32x16_bf16 for bf16 storage, v_mfma_f32_32x32x2_f32 for f32).
+//
+// Replaces cuDNN under nn.Conv2d forward/backward in the reference
+// (model.py:32-35 conv3x3, :552 downBlock conv4x4 s2, :41 fused nearest x2).
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// MFMA over one 64-byte K slab held in LDS as rows of ROWB bytes
+// ---------------------------------------------------------------------------
+template <typename T> struct Mma;
+
+template <> struct Mma<bf16_t> {
+    // slab = 32 bf16 = two 16-deep MFMA steps; lane l holds row (l&31), k = 8*(l>>5)+j
+    template <int TM, int TN, int ROWB>
+    static __device__ __forceinline__ void slab(const unsigned char* a_rows, const unsigned char* b_rows,
+                                                int lane, f32x16_t (&acc)[TM][TN]) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const bf16x8_t*>(a_rows + (i * 32 + r) * ROWB + kk * 32 + h * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const bf16x8_t*>(b_rows + (j * 32 + r) * ROWB + kk * 32 + h * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+};
+
+template <> struct Mma<float> {
+    // slab = 16 floats = eight 2-deep MFMA steps; lane l holds row (l&31), k = (l>>5)
+    template <int TM, int TN, int ROWB>
+    static __device__ __forceinline__ void slab(const unsigned char* a_rows, const unsigned char* b_rows,
+                                                int lane, f32x16_t (&acc)[TM][TN]) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const float*>(a_rows + (i * 32 + r) * ROWB + (2 * kk + h) * 4);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const float*>(b_rows + (j * 32 + r) * ROWB + (2 * kk + h) * 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// forward / data-gradient implicit GEMM
+//   rows  = output pixels of the (OHs x OWs) sub-grid, M = N*OHs*OWs
+//   cols  = output channels
+//   K     = ntaps * Cin, walked in 64-byte slabs (one tap, 32 bf16 / 16 f32 channels)
+// 256 threads = 4 waves laid out (BM/WM) x (BN/WN); each wave owns WM x WN.
+// LDS: double-buffered A[BM] and B[BN] rows of 80 B (64 data + 16 pad: the
+// pad makes the 16-lane ds_read_b128 groups hit 16 distinct 4-bank slots).
+// ---------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                    T* __restrict__ y, const T* __restrict__ addend,
+                                                    float* __restrict__ stats, const sba_conv_geom g,
+                                                    const int M) {
+    constexpr int ROWB = 80;
+    constexpr int KS = 64 / (int)sizeof(T);      // channels per slab
+    constexpr int CH = 16 / (int)sizeof(T);      // elements per 16-byte chunk
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int AI = BM / 64, BI = BN / 64;    // 16-byte loads per thread per slab
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves");
+    static_assert(BM % 64 == 0 && BN % 64 == 0, "tile");
+    constexpr int TILE_BYTES = (BM + BN) * ROWB;
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES + BM * 4 + BN * 8];
+    int* rowoff = reinterpret_cast<int*>(lds + 2 * TILE_BYTES);
+    float* s_stat = reinterpret_cast<float*>(lds + 2 * TILE_BYTES + BM * 4);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+    const int m_base = blockIdx.x * BM, n_base = blockIdx.y * BN;
+    const int IHL = g.ups ? 2 * g.IH : g.IH, IWL = g.ups ? 2 * g.IW : g.IW;
+    const int sub = g.OHs * g.OWs;
+
+    // per-thread description of the A rows it stages (fixed over the K loop)
+    const int chunk = tid & 3;
+    int a_iy0[AI], a_ix0[AI], a_nb[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m_base + (tid >> 2) + 64 * i;
+        if (m < M) {
+            const int n = m / sub, rem = m - n * sub;
+            const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
+            a_iy0[i] = oy * g.sy;
+            a_ix0[i] = ox * g.sx;
+            a_nb[i] = n * g.IH * g.IW;
+        } else {
+            a_iy0[i] = -100000;   // always out of bounds -> zero rows
+            a_ix0[i] = 0;
+            a_nb[i] = 0;
+        }
+    }
+    for (int r = tid; r < BM; r += 256) {
+        const int m = m_base + r;
+        int off = -1;
+        if (m < M) {
+            const int n = m / sub, rem = m - n * sub;
+            const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
+            off = (n * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox;
+        }
+        rowoff[r] = off;
+    }
+    for (int c = tid; c < 2 * BN; c += 256) s_stat[c] = 0.f;
+
+    const int cpt = g.Cin / KS;               // slabs per tap
+    const int nsteps = g.ntaps * cpt;
+    // tap offsets packed 4 bits each (offset + 8) so that the per-step lookup is
+    // scalar shifts instead of a dynamically indexed kernarg array
+    uint64_t tyb = 0, txb = 0;
+#pragma unroll
+    for (int t = 0; t < SBA_MAX_TAPS; ++t) {
+        tyb |= (uint64_t)((g.ty[t] + 8) & 15) << (4 * t);
+        txb |= (uint64_t)((g.tx[t] + 8) & 15) << (4 * t);
+    }
+
+    uint4 ra[AI], rb[BI];
+    auto gload = [&](int step) {
+        const int tap = step / cpt;
+        const int c0 = (step - tap * cpt) * KS + chunk * CH;
+        const int ty = (int)((tyb >> (4 * tap)) & 15) - 8, tx = (int)((txb >> (4 * tap)) & 15) - 8;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            int iy = a_iy0[i] + ty, ix = a_ix0[i] + tx;
+            const bool ok = (iy >= 0) & (iy < IHL) & (ix >= 0) & (ix < IWL);
+            if (g.ups) { iy >>= 1; ix >>= 1; }
+            ra[i] = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const T* p = x + ((int64_t)(a_nb[i] + iy * g.IW + ix) * g.Cin + c0);
+                ra[i] = *reinterpret_cast<const uint4*>(p);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int co = n_base + (tid >> 2) + 64 * i;
+            rb[i] = make_uint4(0, 0, 0, 0);
+            if (co < g.Cout) {
+                const T* p = w + (((int64_t)co * g.ntaps + tap) * g.Cin + c0);
+                rb[i] = *reinterpret_cast<const uint4*>(p);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* base = lds + buf * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+            *reinterpret_cast<uint4*>(base + ((tid >> 2) + 64 * i) * ROWB + chunk * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i)
+            *reinterpret_cast<uint4*>(base + (BM + (tid >> 2) + 64 * i) * ROWB + chunk * 16) = rb[i];
+    };
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) gload(s + 1);
+        const unsigned char* base = lds + buf * TILE_BYTES;
+        Mma<T>::template slab<TM, TN, ROWB>(base + wm0 * ROWB, base + (BM + wn0) * ROWB, lane, acc);
+        if (s + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col_l = lane & 31, rsel = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = n_base + wn0 + j * 32 + col_l;
+        float csum = 0.f, csq = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
+                const int pix = rowoff[row];
+                float v = acc[i][j][r];
+                csum += v;
+                csq += v * v;
+                if (pix >= 0 && co < g.Cout) {
+                    const int64_t o = (int64_t)pix * g.Cout + co;
+                    if (addend) v += to_f<T>(addend[o]);
+                    y[o] = from_f<T>(v);
+                }
+            }
+        }
+        if (stats) {
+            csum += __shfl_xor(csum, 32, 64);
+            csq += __shfl_xor(csq, 32, 64);
+            if (lane < 32) {
+                atomicAdd(&s_stat[wn0 + j * 32 + col_l], csum);
+                atomicAdd(&s_stat[BN + wn0 + j * 32 + col_l], csq);
+            }
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        for (int c = tid; c < BN; c += 256) {
+            const int co = n_base + c;
+            if (co < g.Cout) {
+                atomicAdd(&stats[co], s_stat[c]);
+                atomicAdd(&stats[g.Cout + co], s_stat[BN + c]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient: dw[co][tap][ci] += sum_pixels dy[pixel][co] * x[gather(pixel,tap)][ci]
+// Workgroup = one 64(co) x 64(ci) tile of one tap; its 4 waves each walk their
+// own 16-pixel slices of the workgroup's pixel range, then reduce through LDS.
+// Both operands are pixel-major in memory; the MFMA wants 8 consecutive
+// pixels per lane, so bf16 fragments are read with ds_read_b64_tr_b16 (4
+// pixels x 16 channels transposed per 16-lane group); f32 fragments are single
+// elements and need no transpose.
+// ---------------------------------------------------------------------------
+template <typename T> struct WgFrag;
+
+template <> struct WgFrag<bf16_t> {
+    static constexpr int ROWS = 64 * 2 + 64;   // bytes per pixel row: 128 data + 64 pad (bank spread)
+    // fragment of channels [c32, c32+32) over pixels [0,16) of a slice
+    static __device__ __forceinline__ bf16x8_t load(const unsigned char* slice, int c32, int lane) {
+        const int g16 = lane >> 4, i16 = lane & 15;
+        const int cbase = c32 + 16 * (g16 & 1), kbase = 8 * (g16 >> 1);
+        const int q = i16 >> 2, p = i16 & 3;
+        const unsigned char* a0 = slice + (kbase + q) * ROWS + (cbase + 4 * p) * 2;
+        typedef __attribute__((address_space(3))) s16x4_t* lptr;
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * ROWS));
+        bf16x8_t r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    }
+    static __device__ __forceinline__ void mma(const unsigned char* sa, const unsigned char* sb, int lane,
+                                               f32x16_t (&acc)[2][2]) {
+        bf16x8_t a[2], b[2];
+        a[0] = load(sa, 0, lane); a[1] = load(sa, 32, lane);
+        b[0] = load(sb, 0, lane); b[1] = load(sb, 32, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+};
+
+template <> struct WgFrag<float> {
+    static constexpr int ROWS = 64 * 4 + 64;
+    static __device__ __forceinline__ void mma(const unsigned char* sa, const unsigned char* sb, int lane,
+                                               f32x16_t (&acc)[2][2]) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const float*>(sa + (2 * kk + h) * ROWS + (i * 32 + r) * 4);
+                b[i] = *reinterpret_cast<const float*>(sb + (2 * kk + h) * ROWS + (i * 32 + r) * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                    float* __restrict__ dw, const sba_conv_geom g,
+                                                    const int M, const int chunks_per_split,
+                                                    const int use_atomic) {
+    constexpr int ROWS = WgFrag<T>::ROWS;
+    constexpr int CH = 16 / (int)sizeof(T);          // elements per 16-byte chunk
+    constexpr int CPR = 64 / CH;                     // chunks per 64-channel pixel row
+    constexpr int LPT = 16 * CPR / 64;               // 16-byte loads per lane per slice
+    constexpr int SLICE = 16 * ROWS;
+    static_assert(4 * 2 * SLICE >= 64 * 64 * 4, "reduction buffer fits in the staging area");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 2 * SLICE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int co0 = blockIdx.x * 64;
+    const int ci_tiles = (g.Cin + 63) / 64;
+    const int tap = blockIdx.y / ci_tiles, ci0 = (blockIdx.y - tap * ci_tiles) * 64;
+    int ty = 0, tx = 0;
+#pragma unroll
+    for (int t = 0; t < SBA_MAX_TAPS; ++t)
+        if (t == tap) { ty = g.ty[t]; tx = g.tx[t]; }
+    const int IHL = g.ups ? 2 * g.IH : g.IH, IWL = g.ups ? 2 * g.IW : g.IW;
+    const int sub = g.OHs * g.OWs;
+
+    unsigned char* sa = lds + wid * 2 * SLICE;
+    unsigned char* sb = sa + SLICE;
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int chunk_lo = blockIdx.z * chunks_per_split;
+    const int total_chunks = (M + 63) / 64;
+    const int chunk_hi = min(chunk_lo + chunks_per_split, total_chunks);
+
+    for (int ck = chunk_lo; ck < chunk_hi; ++ck) {
+        const int m0 = ck * 64 + wid * 16;          // this wave's 16 pixels
+        uint4 va[LPT], vb[LPT];
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) {
+            const int idx = lane + 64 * u;
+            const int pix = idx / CPR, cc = idx - pix * CPR;
+            const int m = m0 + pix;
+            va[u] = make_uint4(0, 0, 0, 0);
+            vb[u] = make_uint4(0, 0, 0, 0);
+            if (m < M) {
+                const int n = m / sub, rem = m - n * sub;
+                const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
+                const int co = co0 + cc * CH;
+                if (co < g.Cout) {
+                    const int64_t po = (int64_t)(n * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox;
+                    va[u] = *reinterpret_cast<const uint4*>(dy + po * g.Cout + co);
+                }
+                int iy = oy * g.sy + ty, ix = ox * g.sx + tx;
+                const bool ok = (iy >= 0) & (iy < IHL) & (ix >= 0) & (ix < IWL);
+                if (g.ups) { iy >>= 1; ix >>= 1; }
+                const int ci = ci0 + cc * CH;
+                if (ok && ci < g.Cin) {
+                    const int64_t pi = (int64_t)(n * g.IH + iy) * g.IW + ix;
+                    vb[u] = *reinterpret_cast<const uint4*>(x + pi * g.Cin + ci);
+                }
+            }
+        }
+        __syncthreads();    // previous slice fully consumed by this wave's MFMA reads
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) {
+            const int idx = lane + 64 * u;
+            const int pix = idx / CPR, cc = idx - pix * CPR;
+            *reinterpret_cast<uint4*>(sa + pix * ROWS + cc * 16) = va[u];
+            *reinterpret_cast<uint4*>(sb + pix * ROWS + cc * 16) = vb[u];
+        }
+        __syncthreads();
+        WgFrag<T>::mma(sa, sb, lane, acc);
+    }
+
+    // cross-wave reduction through LDS, then one (atomic) add per element
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);
+    for (int i = tid; i < 64 * 64; i += 256) red[i] = 0.f;
+    __syncthreads();
+    const int col_l = lane & 31, rsel = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + rsel;   // co
+                atomicAdd(&red[row * 64 + j * 32 + col_l], acc[i][j][r]);
+            }
+    __syncthreads();
+    for (int i = tid; i < 64 * 64; i += 256) {
+        const int co = co0 + (i >> 6), ci = ci0 + (i & 63);
+        if (co < g.Cout && ci < g.Cin) {
+            float* p = dw + ((int64_t)co * g.ntaps + tap) * g.Cin + ci;
+            if (use_atomic) atomicAdd(p, red[i]);
+            else *p += red[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// weight packing and 2x2 sum pooling
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int KH,
+                                   int KW, int Cin, int mode) {
+    const int64_t n = (int64_t)Cout * KH * KW * Cin;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        // i indexes the OUTPUT (so that writes are coalesced)
+        float v;
+        if (mode == 0) {
+            v = w[i];
+        } else if (mode == 1) {
+            // out[ci][kh'][kw'][co] = w[co][KH-1-kh'][KW-1-kw'][ci]
+            const int co = (int)(i % Cout);
+            int64_t t = i / Cout;
+            const int kw = (int)(t % KW); t /= KW;
+            const int kh = (int)(t % KH);
+            const int ci = (int)(t / KH);
+            v = w[(((int64_t)co * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * Cin + ci];
+        } else {
+            // out[cls][ci][j*2+i2][co], cls = py*2+px, kh = (1-py)+2j, kw = (1-px)+2*i2  (KH=KW=4)
+            const int co = (int)(i % Cout);
+            int64_t t = i / Cout;
+            const int tp = (int)(t % 4); t /= 4;
+            const int ci = (int)(t % Cin);
+            const int cls = (int)(t / Cin);
+            const int py = cls >> 1, px = cls & 1, j = tp >> 1, i2 = tp & 1;
+            const int kh = (1 - py) + 2 * j, kw = (1 - px) + 2 * i2;
+            v = w[(((int64_t)co * 4 + kh) * 4 + kw) * Cin + ci];
+        }
+        out[i] = from_f<T>(v);
+    }
+}
+
+template <typename T>
+__global__ void pool2x2_kernel(const T* __restrict__ up, T* __restrict__ dx, int N, int H, int W, int C) {
+    constexpr int V = Vec16<T>::N;
+    const int cv = C / V;
+    const int64_t total = (int64_t)N * H * W * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V;
+        int64_t p = i / cv;
+        const int xx = (int)(p % W); p /= W;
+        const int yy = (int)(p % H);
+        const int n = (int)(p / H);
+        const T* b = up + (((int64_t)n * 2 * H + 2 * yy) * 2 * W + 2 * xx) * C + c;
+        Vec16<T> v00 = ld16(b), v01 = ld16(b + C), v10 = ld16(b + (int64_t)2 * W * C),
+                 v11 = ld16(b + (int64_t)2 * W * C + C), o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) o.set(k, v00.get(k) + v01.get(k) + v10.get(k) + v11.get(k));
+        st16(dx + (((int64_t)n * H + yy) * W + xx) * C + c, o);
+    }
+}
+
+template <typename T>
+int launch_igemm(const void* x, const void* w, void* y, const void* addend, float* stats,
+                 const sba_conv_geom& g, hipStream_t st) {
+    const int M = g.N * g.OHs * g.OWs;
+    const T* xp = (const T*)x; const T* wp = (const T*)w; T* yp = (T*)y; const T* ap = (const T*)addend;
+    if (g.Cout % 128 == 0 && M >= 4096) {
+        dim3 grid(cdiv(M, 128), cdiv(g.Cout, 128));
+        hipLaunchKernelGGL((igemm_kernel<T, 128, 128, 64, 64>), grid, dim3(256), 0, st, xp, wp, yp, ap, stats, g, M);
+    } else if (M >= 8192) {
+        dim3 grid(cdiv(M, 256), cdiv(g.Cout, 64));
+        hipLaunchKernelGGL((igemm_kernel<T, 256, 64, 64, 64>), grid, dim3(256), 0, st, xp, wp, yp, ap, stats, g, M);
+    } else {
+        dim3 grid(cdiv(M, 64), cdiv(g.Cout, 64));
+        hipLaunchKernelGGL((igemm_kernel<T, 64, 64, 32, 32>), grid, dim3(256), 0, st, xp, wp, yp, ap, stats, g, M);
+    }
+    return SBA_CHECK_LAUNCH();
+}
+
+bool geom_ok(const sba_conv_geom* g, int dtype) {
+    if (!g) return false;
+    const int ks = dtype == SBA_BF16 ? 32 : 16;
+    if (g->ntaps < 1 || g->ntaps > SBA_MAX_TAPS) return false;
+    for (int t = 0; t < g->ntaps; ++t)
+        if (g->ty[t] < -8 || g->ty[t] > 7 || g->tx[t] < -8 || g->tx[t] > 7) return false;
+    if (g->Cin <= 0 || g->Cin % ks != 0) return false;
+    if (g->N <= 0 || g->IH <= 0 || g->IW <= 0 || g->OH <= 0 || g->OW <= 0 || g->Cout <= 0) return false;
+    if (g->OHs <= 0 || g->OWs <= 0 || g->osy <= 0 || g->osx <= 0) return false;
+    // every written output pixel must lie inside OH x OW
+    if ((g->OHs - 1) * g->osy + g->ooy >= g->OH || (g->OWs - 1) * g->osx + g->oox >= g->OW) return false;
+    if (g->ooy < 0 || g->oox < 0) return false;
+    if ((int64_t)g->N * g->OHs * g->OWs > 0x7fffffff) return false;
+    if ((int64_t)g->N * g->IH * g->IW > 0x7fffffff / 2 || (int64_t)g->N * g->OH * g->OW > 0x7fffffff / 2)
+        return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int sba_conv_igemm(int dtype, const void* x, const void* w, void* y, const void* addend,
+                              float* stats, const sba_conv_geom* g, void* stream) {
+    if (!x || !w || !y || !geom_ok(g, dtype)) return SBA_E_ARG;
+    SBA_DISPATCH(dtype, return launch_igemm<T>(x, w, y, addend, stats, *g, (hipStream_t)stream));
+    return SBA_E_ARG;
+}
+
+extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* dw, const sba_conv_geom* g,
+                              int ksplit, void* stream) {
+    if (!x || !dy || !dw || !geom_ok(g, dtype)) return SBA_E_ARG;
+    if (g->Cin % 8 != 0 || g->Cout % 8 != 0) return SBA_E_ARG;
+    const int M = g->N * g->OHs * g->OWs;
+    const int total_chunks = cdiv(M, 64);
+    if (ksplit < 1) ksplit = 1;
+    if (ksplit > total_chunks) ksplit = total_chunks;
+    const int cps = cdiv(total_chunks, ksplit);
+    ksplit = cdiv(total_chunks, cps);
+    dim3 grid(cdiv(g->Cout, 64), cdiv(g->Cin, 64) * g->ntaps, ksplit);
+    if (grid.y > 65535 || grid.z > 65535) return SBA_E_ARG;
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((wgrad_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
+                                           (const T*)x, (const T*)dy, dw, *g, M, cps, ksplit > 1 ? 1 : 0));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_pack_weight(int dtype, const float* w, void* out, int Cout, int KH, int KW, int Cin,
+                               int mode, void* stream) {
+    if (!w || !out || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || mode < 0 || mode > 2) return SBA_E_ARG;
+    if (mode == 2 && (KH != 4 || KW != 4)) return SBA_E_ARG;
+    const int64_t n = (int64_t)Cout * KH * KW * Cin;
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(blocks), dim3(256), 0,
+                                           (hipStream_t)stream, w, (T*)out, Cout, KH, KW, Cin, mode));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_pool2x2_sum(int dtype, const void* dup, void* dx, int N, int H, int W, int C, void* stream) {
+    if (!dup || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0) return SBA_E_ARG;
+    const int64_t total = (int64_t)N * H * W * (C / (dtype == SBA_BF16 ? 8 : 4));
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((pool2x2_kernel<T>), dim3(blocks), dim3(256), 0,
+                                           (hipStream_t)stream, (const T*)dup, (T*)dx, N, H, W, C));
+    return SBA_CHECK_LAUNCH();
+}

@@ -1,0 +1,194 @@
+// Small dense f32 layers of the generator's conditioning path (gfx950): CA_NET
+// (model.py:271-299), MAPPING_NET (:301-321), INIT_STAGE_G.fc (:354), AdaIN style
+// (:330) and the attention key projection conv_context (GlobalAttention.py:75,97).
+// Batch is 20-64 rows, so these are weight-bandwidth bound GEMVs, not MFMA work:
+// one wave streams one weight row with coalesced loads, activations sit in LDS.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         int B, int K, int N) {
+    extern __shared__ float s_x[];       // [B][K]
+    for (int i = threadIdx.x; i < B * K; i += blockDim.x) s_x[i] = x[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int n = blockIdx.x * 4 + wid; n < N; n += gridDim.x * 4) {
+        const float* wr = w + (int64_t)n * K;
+        for (int b = 0; b < B; ++b) {
+            float acc = 0.f;
+            for (int k = lane; k < K; k += 64) acc += wr[k] * s_x[b * K + k];
+            acc = wave_sum(acc);
+            if (lane == 0) y[(int64_t)b * N + n] = acc + (bias ? bias[n] : 0.f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ dw, float* __restrict__ dbias, int B,
+                                                           int K, int N) {
+    extern __shared__ float s_x[];       // [B][K]
+    for (int i = threadIdx.x; i < B * K; i += blockDim.x) s_x[i] = x[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int n = blockIdx.x * 4 + wid; n < N; n += gridDim.x * 4) {
+        float sb = 0.f;
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            const int k = k0 + lane;
+            float acc = 0.f;
+            for (int b = 0; b < B; ++b) {
+                const float d = dy[(int64_t)b * N + n];
+                if (k < K) acc += d * s_x[b * K + k];
+                if (k0 == 0) sb += d;
+            }
+            if (k < K) dw[(int64_t)n * K + k] += acc;
+        }
+        if (dbias && lane == 0) dbias[n] += sb;
+    }
+}
+
+// dx[b][k] += sum over this block's n-range of dy[b][n] w[n][k]   (dx zeroed by the caller)
+__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* __restrict__ w, const float* __restrict__ dy,
+                                                           float* __restrict__ dx, int B, int K, int N, int nper) {
+    const int n0 = blockIdx.x * nper, n1 = min(n0 + nper, N);
+    for (int i = threadIdx.x; i < B * K; i += blockDim.x) {
+        const int b = i / K, k = i - b * K;
+        float acc = 0.f;
+        for (int n = n0; n < n1; ++n) acc += dy[(int64_t)b * N + n] * w[(int64_t)n * K + k];
+        atomicAdd(&dx[i], acc);
+    }
+}
+
+// CA_NET tail: h[B][4C]: GLU -> x[0..2C) = h[:, :2C] * sigmoid(h[:, 2C:]); mu = x[:C], logvar = x[C:]
+__global__ void ca_fwd_kernel(const float* __restrict__ h, const float* __restrict__ eps, float* __restrict__ c,
+                              float* __restrict__ mu, float* __restrict__ logvar, int B, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, j = i - b * C;
+    const float* hr = h + (int64_t)b * 4 * C;
+    const float m = hr[j] * sigmoidf_(hr[2 * C + j]);
+    const float lv = hr[C + j] * sigmoidf_(hr[3 * C + j]);
+    mu[i] = m;
+    logvar[i] = lv;
+    c[i] = eps[i] * expf(0.5f * lv) + m;
+}
+
+__global__ void ca_bwd_kernel(const float* __restrict__ h, const float* __restrict__ eps,
+                              const float* __restrict__ dc, const float* __restrict__ dmu,
+                              const float* __restrict__ dlogvar, float* __restrict__ dh, int B, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, j = i - b * C;
+    const float* hr = h + (int64_t)b * 4 * C;
+    float* dr = dh + (int64_t)b * 4 * C;
+    const float sm = sigmoidf_(hr[2 * C + j]), sl = sigmoidf_(hr[3 * C + j]);
+    const float lv = hr[C + j] * sl;
+    const float gc = dc ? dc[i] : 0.f;
+    const float gm = gc + (dmu ? dmu[i] : 0.f);
+    const float gl = gc * eps[i] * 0.5f * expf(0.5f * lv) + (dlogvar ? dlogvar[i] : 0.f);
+    dr[j] = gm * sm;
+    dr[2 * C + j] = gm * hr[j] * sm * (1.f - sm);
+    dr[C + j] = gl * sl;
+    dr[3 * C + j] = gl * hr[C + j] * sl * (1.f - sl);
+}
+
+// attention key projection: src[b][i][l] = sum_c W[i][c] words[b][c][l]
+__global__ void ctx_proj_fwd_kernel(const float* __restrict__ words, const float* __restrict__ W,
+                                    float* __restrict__ src, int B, int idf, int cdf, int L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * idf * L) return;
+    const int l = i % L, o = (i / L) % idf, b = i / (L * idf);
+    float acc = 0.f;
+    for (int c = 0; c < cdf; ++c) acc += W[o * cdf + c] * words[((int64_t)b * cdf + c) * L + l];
+    src[i] = acc;
+}
+
+// dW[i][c] += sum_{b,l} dsrc[b][i][l] words[b][c][l];  dwords[b][c][l] = sum_i W[i][c] dsrc[b][i][l]
+__global__ void ctx_proj_bwd_kernel(const float* __restrict__ words, const float* __restrict__ W,
+                                    const float* __restrict__ dsrc, float* __restrict__ dW,
+                                    float* __restrict__ dwords, int B, int idf, int cdf, int L) {
+    const int nW = idf * cdf;
+    const int total = nW + (dwords ? B * cdf * L : 0);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        if (i < nW) {
+            const int o = i / cdf, c = i - o * cdf;
+            float acc = 0.f;
+            for (int b = 0; b < B; ++b)
+                for (int l = 0; l < L; ++l)
+                    acc += dsrc[((int64_t)b * idf + o) * L + l] * words[((int64_t)b * cdf + c) * L + l];
+            dW[i] += acc;
+        } else {
+            const int j = i - nW;
+            const int l = j % L, c = (j / L) % cdf, b = j / (L * cdf);
+            float acc = 0.f;
+            for (int o = 0; o < idf; ++o) acc += W[o * cdf + c] * dsrc[((int64_t)b * idf + o) * L + l];
+            dwords[j] = acc;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sba_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N,
+                              void* stream) {
+    if (!x || !w || !y || B <= 0 || K <= 0 || N <= 0) return SBA_E_ARG;
+    const size_t sh = sizeof(float) * B * K;
+    if (sh > 64 * 1024) return SBA_E_ARG;
+    int blocks = cdiv(N, 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3(blocks), dim3(256), sh, (hipStream_t)stream, x, w, bias, y, B, K, N);
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* dbias,
+                              int B, int K, int N, void* stream) {
+    if (!x || !w || !dy || B <= 0 || K <= 0 || N <= 0) return SBA_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t sh = sizeof(float) * B * K;
+    if (sh > 64 * 1024) return SBA_E_ARG;
+    if (dw) {
+        int blocks = cdiv(N, 4);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(blocks), dim3(256), sh, st, x, dy, dw, dbias, B, K, N);
+    }
+    if (dx) {
+        if (hipMemsetAsync(dx, 0, sizeof(float) * B * K, st) != hipSuccess) return SBA_E_LAUNCH;
+        const int nper = N >= 4096 ? 64 : (N >= 512 ? 16 : 4);
+        hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(cdiv(N, nper)), dim3(256), 0, st, w, dy, dx, B, K, N, nper);
+    }
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_ca_fwd(const float* h, const float* eps, float* c, float* mu, float* logvar, int B, int C,
+                          void* stream) {
+    if (!h || !eps || !c || !mu || !logvar || B <= 0 || C <= 0) return SBA_E_ARG;
+    hipLaunchKernelGGL(ca_fwd_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, h, eps, c, mu,
+                       logvar, B, C);
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_ca_bwd(const float* h, const float* eps, const float* dc, const float* dmu, const float* dlogvar,
+                          float* dh, int B, int C, void* stream) {
+    if (!h || !eps || !dh || B <= 0 || C <= 0) return SBA_E_ARG;
+    hipLaunchKernelGGL(ca_bwd_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, h, eps, dc, dmu,
+                       dlogvar, dh, B, C);
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_ctx_proj_fwd(const float* words, const float* W, float* src, int B, int idf, int cdf, int L,
+                                void* stream) {
+    if (!words || !W || !src || B <= 0 || idf <= 0 || cdf <= 0 || L <= 0) return SBA_E_ARG;
+    hipLaunchKernelGGL(ctx_proj_fwd_kernel, dim3(cdiv((int64_t)B * idf * L, 256)), dim3(256), 0,
+                       (hipStream_t)stream, words, W, src, B, idf, cdf, L);
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_ctx_proj_bwd(const float* words, const float* W, const float* dsrc, float* dW, float* dwords,
+                                int B, int idf, int cdf, int L, void* stream) {
+    if (!words || !W || !dsrc || !dW || B <= 0 || idf <= 0 || cdf <= 0 || L <= 0) return SBA_E_ARG;
+    const int total = idf * cdf + (dwords ? B * cdf * L : 0);
+    hipLaunchKernelGGL(ctx_proj_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, words, W,
+                       dsrc, dW, dwords, B, idf, cdf, L);
+    return SBA_CHECK_LAUNCH();
+}

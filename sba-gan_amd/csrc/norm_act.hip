@@ -1,0 +1,587 @@
+// BatchNorm(train)+activation, BatchNorm1d+GLU, InstanceNorm/AdaIN kernels (gfx950).
+// All are HBM-bound streaming kernels: 16-byte vector accesses along the NHWC
+// channel axis, f32 math, per-channel reductions through LDS then global atomics.
+//
+// Reference: model.py:43-44 (BN+GLU), :62-65,70 (ResBlock BN, residual add),
+// :543-544,553-554 (BN+LeakyReLU 0.2), :353-356 (BatchNorm1d+GLU), :324-339 (AdaIN).
+#include "common.h"
+
+namespace {
+
+constexpr float LRELU_SLOPE = 0.2f;
+
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rmean,
+                                   float* __restrict__ rvar, int64_t* __restrict__ nbt,
+                                   float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_o, float* __restrict__ rstd_o, int C,
+                                   float count, float eps, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    const float mean = stats[c] / count;
+    float var = stats[C + c] / count - mean * mean;
+    var = fmaxf(var, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    mean_o[c] = mean;
+    rstd_o[c] = rstd;
+    if (rmean) {
+        const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+    }
+}
+
+// ---- forward: out = act(y*scale+shift) (+residual) ----
+template <typename T, int ACT>
+__global__ void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, const T* __restrict__ residual,
+                                  T* __restrict__ out, int64_t rows, int C, int out_cstride, int out_coff) {
+    constexpr int V = Vec16<T>::N;
+    const int Co = ACT == SBA_ACT_GLU ? C / 2 : C;
+    const int cv = Co / V;
+    const int64_t total = rows * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cv;
+        const int c = (int)(i - row * cv) * V;
+        Vec16<T> a = ld16(y + row * C + c), o;
+        if (ACT == SBA_ACT_GLU) {
+            Vec16<T> gt = ld16(y + row * C + Co + c);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float n = a.get(k) * scale[c + k] + shift[c + k];
+                const float gp = gt.get(k) * scale[Co + c + k] + shift[Co + c + k];
+                o.set(k, n * sigmoidf_(gp));
+            }
+        } else {
+            Vec16<T> r;
+            if (residual) r = ld16(residual + row * Co + c);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float n = a.get(k) * scale[c + k] + shift[c + k];
+                if (ACT == SBA_ACT_LRELU) n = n > 0.f ? n : LRELU_SLOPE * n;
+                if (residual) n += r.get(k);
+                o.set(k, n);
+            }
+        }
+        st16(out + row * out_cstride + out_coff + c, o);
+    }
+}
+
+// ---- backward pass 1: per-channel sum(dz), sum(dz*xhat) ----
+// thread mapping: each thread keeps a fixed set of channel vectors and strides over rows
+template <typename T, int ACT>
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ dout,
+                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                     float* __restrict__ red, int64_t rows, int C, int dcs, int dco) {
+    constexpr int V = Vec16<T>::N;
+    const int Co = ACT == SBA_ACT_GLU ? C / 2 : C;
+    const int cv = Co / V;                                  // power of two
+    extern __shared__ float s_acc[];                        // [2*C]
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.f;
+    __syncthreads();
+    const int tpr = cv < (int)blockDim.x ? cv : (int)blockDim.x;   // threads per row
+    const int rpi = blockDim.x / tpr;                               // rows per iteration
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    for (int cvi = tc; cvi < cv; cvi += tpr) {
+        const int c = cvi * V;
+        float s0[V], s1[V], g0[V], g1[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { s0[k] = s1[k] = g0[k] = g1[k] = 0.f; }
+        for (int64_t row = (int64_t)blockIdx.x * rpi + tr; row < rows; row += (int64_t)gridDim.x * rpi) {
+            Vec16<T> a = ld16(y + row * C + c);
+            Vec16<T> d = ld16(dout + row * dcs + dco + c);
+            if (ACT == SBA_ACT_GLU) {
+                Vec16<T> gt = ld16(y + row * C + Co + c);
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const float n = a.get(k) * scale[c + k] + shift[c + k];
+                    const float gp = gt.get(k) * scale[Co + c + k] + shift[Co + c + k];
+                    const float s = sigmoidf_(gp), dd = d.get(k);
+                    const float dza = dd * s, dzg = dd * n * s * (1.f - s);
+                    s0[k] += dza;
+                    s1[k] += dza * (a.get(k) - mean[c + k]) * rstd[c + k];
+                    g0[k] += dzg;
+                    g1[k] += dzg * (gt.get(k) - mean[Co + c + k]) * rstd[Co + c + k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    float dz = d.get(k);
+                    if (ACT == SBA_ACT_LRELU) {
+                        const float n = a.get(k) * scale[c + k] + shift[c + k];
+                        dz = n > 0.f ? dz : LRELU_SLOPE * dz;
+                    }
+                    s0[k] += dz;
+                    s1[k] += dz * (a.get(k) - mean[c + k]) * rstd[c + k];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            atomicAdd(&s_acc[c + k], s0[k]);
+            atomicAdd(&s_acc[C + c + k], s1[k]);
+            if (ACT == SBA_ACT_GLU) {
+                atomicAdd(&s_acc[Co + c + k], g0[k]);
+                atomicAdd(&s_acc[C + Co + c + k], g1[k]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&red[i], s_acc[i]);
+}
+
+// ---- backward pass 2: dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)) ----
+template <typename T, int ACT>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ y, const T* __restrict__ dout,
+                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ red, T* __restrict__ dy,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows,
+                                    int C, int dcs, int dco) {
+    constexpr int V = Vec16<T>::N;
+    const int Co = ACT == SBA_ACT_GLU ? C / 2 : C;
+    const int cv = Co / V;
+    const float inv = 1.f / (float)rows;
+    if (blockIdx.x == 0 && dgamma) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            dgamma[c] += red[C + c];
+            dbeta[c] += red[c];
+        }
+    }
+    const int64_t total = rows * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cv;
+        const int c = (int)(i - row * cv) * V;
+        Vec16<T> a = ld16(y + row * C + c);
+        Vec16<T> d = ld16(dout + row * dcs + dco + c);
+        Vec16<T> o;
+        if (ACT == SBA_ACT_GLU) {
+            Vec16<T> gt = ld16(y + row * C + Co + c), og;
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const int ca = c + k, cg = Co + c + k;
+                const float n = a.get(k) * scale[ca] + shift[ca];
+                const float gp = gt.get(k) * scale[cg] + shift[cg];
+                const float s = sigmoidf_(gp), dd = d.get(k);
+                const float dza = dd * s, dzg = dd * n * s * (1.f - s);
+                const float xa = (a.get(k) - mean[ca]) * rstd[ca];
+                const float xg = (gt.get(k) - mean[cg]) * rstd[cg];
+                o.set(k, scale[ca] * (dza - red[ca] * inv - xa * red[C + ca] * inv));
+                og.set(k, scale[cg] * (dzg - red[cg] * inv - xg * red[C + cg] * inv));
+            }
+            st16(dy + row * C + Co + c, og);
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const int ca = c + k;
+                float dz = d.get(k);
+                if (ACT == SBA_ACT_LRELU) {
+                    const float n = a.get(k) * scale[ca] + shift[ca];
+                    dz = n > 0.f ? dz : LRELU_SLOPE * dz;
+                }
+                const float xa = (a.get(k) - mean[ca]) * rstd[ca];
+                o.set(k, scale[ca] * (dz - red[ca] * inv - xa * red[C + ca] * inv));
+            }
+        }
+        st16(dy + row * C + c, o);
+    }
+}
+
+// ---- BatchNorm1d + GLU on [B][F] f32 with the NCHW->NHWC view permutation ----
+// feature f' in [0,F/2) pairs with gate f'+F/2; view(B, F/2/16, 4, 4): f' = c*16 + s
+template <typename T>
+__global__ void bn1d_glu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, float* __restrict__ rmean,
+                                    float* __restrict__ rvar, int64_t* __restrict__ nbt,
+                                    float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                    T* __restrict__ out, int B, int F, float eps, float momentum) {
+    const int fh = F / 2, Cg = fh / 16;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f == 0 && nbt) *nbt += 1;
+    if (f >= fh) return;
+    float m[2], r[2], sc[2], sh[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int ff = f + h * fh;
+        float s = 0.f, q = 0.f;
+        for (int b = 0; b < B; ++b) { const float v = y[(int64_t)b * F + ff]; s += v; }
+        const float mean = s / B;
+        for (int b = 0; b < B; ++b) { const float v = y[(int64_t)b * F + ff] - mean; q += v * v; }
+        const float var = q / B;
+        m[h] = mean; r[h] = rsqrtf(var + eps);
+        sc[h] = gamma[ff] * r[h]; sh[h] = beta[ff] - mean * sc[h];
+        mean_o[ff] = mean; rstd_o[ff] = r[h];
+        if (rmean) {
+            const float unb = B > 1 ? var * B / (B - 1.f) : var;
+            rmean[ff] = (1.f - momentum) * rmean[ff] + momentum * mean;
+            rvar[ff] = (1.f - momentum) * rvar[ff] + momentum * unb;
+        }
+    }
+    const int c = f / 16, s16 = f % 16;
+    for (int b = 0; b < B; ++b) {
+        const float n = y[(int64_t)b * F + f] * sc[0] + sh[0];
+        const float gp = y[(int64_t)b * F + f + fh] * sc[1] + sh[1];
+        out[((int64_t)b * 16 + s16) * Cg + c] = from_f<T>(n * sigmoidf_(gp));
+    }
+}
+
+template <typename T>
+__global__ void bn1d_glu_bwd_kernel(const float* __restrict__ y, const T* __restrict__ dout,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    float* __restrict__ dy, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, int B, int F) {
+    const int fh = F / 2, Cg = fh / 16;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= fh) return;
+    const int c = f / 16, s16 = f % 16;
+    const int fa = f, fg = f + fh;
+    const float sca = gamma[fa] * rstd[fa], sha = beta[fa] - mean[fa] * sca;
+    const float scg = gamma[fg] * rstd[fg], shg = beta[fg] - mean[fg] * scg;
+    float a0 = 0.f, a1 = 0.f, g0 = 0.f, g1 = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float ya = y[(int64_t)b * F + fa], yg = y[(int64_t)b * F + fg];
+        const float n = ya * sca + sha, gp = yg * scg + shg, s = sigmoidf_(gp);
+        const float dd = to_f<T>(dout[((int64_t)b * 16 + s16) * Cg + c]);
+        const float dza = dd * s, dzg = dd * n * s * (1.f - s);
+        a0 += dza; a1 += dza * (ya - mean[fa]) * rstd[fa];
+        g0 += dzg; g1 += dzg * (yg - mean[fg]) * rstd[fg];
+    }
+    dgamma[fa] += a1; dbeta[fa] += a0;
+    dgamma[fg] += g1; dbeta[fg] += g0;
+    const float inv = 1.f / B;
+    for (int b = 0; b < B; ++b) {
+        const float ya = y[(int64_t)b * F + fa], yg = y[(int64_t)b * F + fg];
+        const float n = ya * sca + sha, gp = yg * scg + shg, s = sigmoidf_(gp);
+        const float dd = to_f<T>(dout[((int64_t)b * 16 + s16) * Cg + c]);
+        const float dza = dd * s, dzg = dd * n * s * (1.f - s);
+        dy[(int64_t)b * F + fa] = sca * (dza - a0 * inv - (ya - mean[fa]) * rstd[fa] * a1 * inv);
+        dy[(int64_t)b * F + fg] = scg * (dzg - g0 * inv - (yg - mean[fg]) * rstd[fg] * g1 * inv);
+    }
+}
+
+// ---- InstanceNorm statistics / AdaIN ----
+// grid (N, splits); threads [rows][C/V]; accumulates (sum, sumsq) into mean/rstd buffers
+template <typename T>
+__global__ void instnorm_accum_kernel(const T* __restrict__ h, float* __restrict__ sum,
+                                      float* __restrict__ sumsq, int HW, int C) {
+    constexpr int V = Vec16<T>::N;
+    const int cv = C / V, n = blockIdx.x;
+    const int rpi = blockDim.x / cv;
+    const int tc = threadIdx.x % cv, tr = threadIdx.x / cv;
+    extern __shared__ float s_acc[];   // [2*C]
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.f;
+    __syncthreads();
+    float s0[V], s1[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) s0[k] = s1[k] = 0.f;
+    if (tr < rpi) {
+        for (int p = blockIdx.y * rpi + tr; p < HW; p += gridDim.y * rpi) {
+            Vec16<T> a = ld16(h + ((int64_t)n * HW + p) * C + tc * V);
+#pragma unroll
+            for (int k = 0; k < V; ++k) { const float v = a.get(k); s0[k] += v; s1[k] += v * v; }
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            atomicAdd(&s_acc[tc * V + k], s0[k]);
+            atomicAdd(&s_acc[C + tc * V + k], s1[k]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        atomicAdd(&sum[n * C + i], s_acc[i]);
+        atomicAdd(&sumsq[n * C + i], s_acc[C + i]);
+    }
+}
+
+__global__ void instnorm_finalize_kernel(float* __restrict__ mean, float* __restrict__ rstd, int NC,
+                                         float HW, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC) return;
+    const float m = mean[i] / HW;
+    const float var = fmaxf(rstd[i] / HW - m * m, 0.f);
+    mean[i] = m;
+    rstd[i] = rsqrtf(var + eps);
+}
+
+template <typename T>
+__global__ void adain_fwd_kernel(const T* __restrict__ h, const float* __restrict__ mean,
+                                 const float* __restrict__ rstd, const float* __restrict__ style,
+                                 T* __restrict__ out, int N, int HW, int C, int ocs, int oco) {
+    constexpr int V = Vec16<T>::N;
+    const int cv = C / V;
+    const int64_t total = (int64_t)N * HW * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cv;
+        const int c = (int)(i - row * cv) * V;
+        const int n = (int)(row / HW);
+        Vec16<T> a = ld16(h + row * C + c), o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xh = (a.get(k) - mean[n * C + c + k]) * rstd[n * C + c + k];
+            o.set(k, (style[n * 2 * C + c + k] + 1.f) * xh + style[n * 2 * C + C + c + k]);
+        }
+        st16(out + row * ocs + oco + c, o);
+    }
+}
+
+// red[n][c][0] += sum dout*xhat, red[n][c][1] += sum dout
+template <typename T>
+__global__ void adain_bwd_reduce_kernel(const T* __restrict__ h, const T* __restrict__ dout,
+                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                        float* __restrict__ red, int HW, int C, int dcs, int dco) {
+    constexpr int V = Vec16<T>::N;
+    const int cv = C / V, n = blockIdx.x;
+    const int rpi = blockDim.x / cv;
+    const int tc = threadIdx.x % cv, tr = threadIdx.x / cv;
+    extern __shared__ float s_acc[];   // [2*C]
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.f;
+    __syncthreads();
+    float s0[V], s1[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) s0[k] = s1[k] = 0.f;
+    if (tr < rpi) {
+        for (int p = blockIdx.y * rpi + tr; p < HW; p += gridDim.y * rpi) {
+            const int64_t row = (int64_t)n * HW + p;
+            Vec16<T> a = ld16(h + row * C + tc * V);
+            Vec16<T> d = ld16(dout + row * dcs + dco + tc * V);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const int c = tc * V + k;
+                const float xh = (a.get(k) - mean[n * C + c]) * rstd[n * C + c];
+                s0[k] += d.get(k) * xh;
+                s1[k] += d.get(k);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            atomicAdd(&s_acc[tc * V + k], s0[k]);
+            atomicAdd(&s_acc[C + tc * V + k], s1[k]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        atomicAdd(&red[(n * C + i) * 2 + 0], s_acc[i]);
+        atomicAdd(&red[(n * C + i) * 2 + 1], s_acc[C + i]);
+    }
+}
+
+template <typename T>
+__global__ void adain_bwd_apply_kernel(const T* __restrict__ h, const T* __restrict__ dout,
+                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                       const float* __restrict__ style, const float* __restrict__ red,
+                                       T* __restrict__ dh, float* __restrict__ dstyle, int N, int HW,
+                                       int C, int dcs, int dco, int accumulate) {
+    constexpr int V = Vec16<T>::N;
+    const int cv = C / V;
+    const float inv = 1.f / HW;
+    if (blockIdx.x == 0 && dstyle) {
+        for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
+            const int n = i / C, c = i - n * C;
+            dstyle[n * 2 * C + c] = red[i * 2 + 0];
+            dstyle[n * 2 * C + C + c] = red[i * 2 + 1];
+        }
+    }
+    const int64_t total = (int64_t)N * HW * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cv;
+        const int c = (int)(i - row * cv) * V;
+        const int n = (int)(row / HW);
+        Vec16<T> a = ld16(h + row * C + c);
+        Vec16<T> d = ld16(dout + row * dcs + dco + c);
+        Vec16<T> o;
+        if (accumulate) o = ld16(dh + row * C + c);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int nc = n * C + c + k;
+            const float xh = (a.get(k) - mean[nc]) * rstd[nc];
+            const float g = (style[n * 2 * C + c + k] + 1.f) * rstd[nc];
+            float v = g * (d.get(k) - red[nc * 2 + 1] * inv - xh * red[nc * 2 + 0] * inv);
+            if (accumulate) v += o.get(k);
+            o.set(k, v);
+        }
+        st16(dh + row * C + c, o);
+    }
+}
+
+inline int grid_for(int64_t items, int cap = 4096) {
+    int64_t b = (items + 255) / 256;
+    if (b < 1) b = 1;
+    return (int)(b > cap ? cap : b);
+}
+inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace
+
+extern "C" int sba_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, int64_t* nbt, float* scale, float* shift, float* mean,
+                               float* rstd, int C, int64_t count, float eps, float momentum, void* stream) {
+    if (!stats || !gamma || !beta || !scale || !shift || !mean || !rstd || C <= 0 || count <= 0) return SBA_E_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, gamma,
+                       beta, running_mean, running_var, nbt, scale, shift, mean, rstd, C, (float)count, eps,
+                       momentum);
+    return SBA_CHECK_LAUNCH();
+}
+
+#define ACT_SWITCH(act, CALL)                                                   \
+    switch (act) {                                                              \
+        case SBA_ACT_NONE: { constexpr int ACT = SBA_ACT_NONE; CALL; } break;   \
+        case SBA_ACT_GLU: { constexpr int ACT = SBA_ACT_GLU; CALL; } break;     \
+        case SBA_ACT_LRELU: { constexpr int ACT = SBA_ACT_LRELU; CALL; } break; \
+        default: return SBA_E_ARG;                                              \
+    }
+
+static bool bn_shape_ok(int dtype, int64_t rows, int C, int act) {
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    const int Co = act == SBA_ACT_GLU ? C / 2 : C;
+    return rows > 0 && C > 0 && pow2(C) && Co % V == 0 && C <= 4096;
+}
+
+extern "C" int sba_bn_act_fwd(int dtype, const void* y, const float* scale, const float* shift,
+                              const void* residual, void* out, int64_t rows, int C, int act,
+                              int out_cstride, int out_coff, void* stream) {
+    if (!y || !scale || !shift || !out || !bn_shape_ok(dtype, rows, C, act)) return SBA_E_ARG;
+    if (act == SBA_ACT_GLU && residual) return SBA_E_ARG;
+    const int Co = act == SBA_ACT_GLU ? C / 2 : C;
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    if (out_cstride < Co + out_coff || out_cstride % V || out_coff % V) return SBA_E_ARG;
+    const int blocks = grid_for(rows * (Co / V));
+    SBA_DISPATCH(dtype, ACT_SWITCH(act, hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT>), dim3(blocks), dim3(256),
+                                                           0, (hipStream_t)stream, (const T*)y, scale, shift,
+                                                           (const T*)residual, (T*)out, rows, C, out_cstride,
+                                                           out_coff)));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_bn_act_bwd_reduce(int dtype, const void* y, const void* dout, const float* scale,
+                                     const float* shift, const float* mean, const float* rstd, float* red,
+                                     int64_t rows, int C, int act, int dcs, int dco, void* stream) {
+    if (!y || !dout || !scale || !shift || !mean || !rstd || !red || !bn_shape_ok(dtype, rows, C, act))
+        return SBA_E_ARG;
+    const int Co = act == SBA_ACT_GLU ? C / 2 : C;
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    if (dcs < Co + dco || dcs % V || dco % V) return SBA_E_ARG;
+    const int cv = Co / V;
+    const int rpi = cv < 256 ? 256 / cv : 1;
+    int blocks = cdiv(rows, (int64_t)rpi * 8);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    const size_t sh = 2 * (size_t)C * sizeof(float);
+    SBA_DISPATCH(dtype, ACT_SWITCH(act, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, ACT>), dim3(blocks),
+                                                           dim3(256), sh, (hipStream_t)stream, (const T*)y,
+                                                           (const T*)dout, scale, shift, mean, rstd, red, rows, C,
+                                                           dcs, dco)));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_bn_act_bwd_apply(int dtype, const void* y, const void* dout, const float* scale,
+                                    const float* shift, const float* mean, const float* rstd, const float* gamma,
+                                    const float* red, void* dy, float* dgamma, float* dbeta, int64_t rows, int C,
+                                    int act, int dcs, int dco, void* stream) {
+    (void)gamma;
+    if (!y || !dout || !scale || !shift || !mean || !rstd || !red || !dy || !bn_shape_ok(dtype, rows, C, act))
+        return SBA_E_ARG;
+    if ((dgamma == nullptr) != (dbeta == nullptr)) return SBA_E_ARG;
+    const int Co = act == SBA_ACT_GLU ? C / 2 : C;
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    if (dcs < Co + dco || dcs % V || dco % V) return SBA_E_ARG;
+    const int blocks = grid_for(rows * (Co / V));
+    SBA_DISPATCH(dtype, ACT_SWITCH(act, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, ACT>), dim3(blocks), dim3(256),
+                                                           0, (hipStream_t)stream, (const T*)y, (const T*)dout,
+                                                           scale, shift, mean, rstd, red, (T*)dy, dgamma, dbeta,
+                                                           rows, C, dcs, dco)));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_bn1d_glu_fwd(int dtype, const float* y, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, int64_t* nbt, float* mean, float* rstd,
+                                void* out, int B, int F, float eps, float momentum, void* stream) {
+    if (!y || !gamma || !beta || !mean || !rstd || !out || B <= 0 || F <= 0 || F % 32 != 0) return SBA_E_ARG;
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((bn1d_glu_fwd_kernel<T>), dim3(cdiv(F / 2, 256)), dim3(256), 0,
+                                           (hipStream_t)stream, y, gamma, beta, running_mean, running_var, nbt,
+                                           mean, rstd, (T*)out, B, F, eps, momentum));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_bn1d_glu_bwd(int dtype, const float* y, const void* dout, const float* gamma, const float* beta,
+                                const float* mean, const float* rstd, float* dy, float* dgamma, float* dbeta,
+                                int B, int F, void* stream) {
+    if (!y || !dout || !gamma || !beta || !mean || !rstd || !dy || !dgamma || !dbeta || B <= 0 || F <= 0 ||
+        F % 32 != 0)
+        return SBA_E_ARG;
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((bn1d_glu_bwd_kernel<T>), dim3(cdiv(F / 2, 256)), dim3(256), 0,
+                                           (hipStream_t)stream, y, (const T*)dout, gamma, beta, mean, rstd, dy,
+                                           dgamma, dbeta, B, F));
+    return SBA_CHECK_LAUNCH();
+}
+
+static bool in_shape_ok(int dtype, int N, int HW, int C) {
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    return N > 0 && HW > 0 && C > 0 && C % V == 0 && C / V <= 256 && pow2(C / V);
+}
+
+extern "C" int sba_instnorm_stats(int dtype, const void* h, float* mean, float* rstd, int N, int HW, int C,
+                                  float eps, void* stream) {
+    if (!h || !mean || !rstd || !in_shape_ok(dtype, N, HW, C)) return SBA_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(mean, 0, sizeof(float) * N * C, st) != hipSuccess) return SBA_E_LAUNCH;
+    if (hipMemsetAsync(rstd, 0, sizeof(float) * N * C, st) != hipSuccess) return SBA_E_LAUNCH;
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    const int rpi = 256 / (C / V);
+    int splits = cdiv(HW, rpi * 16);
+    if (splits > 256) splits = 256;
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((instnorm_accum_kernel<T>), dim3(N, splits), dim3(256),
+                                           2 * C * sizeof(float), st, (const T*)h, mean, rstd, HW, C));
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, st, mean, rstd, N * C,
+                       (float)HW, eps);
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_adain_fwd(int dtype, const void* h, const float* mean, const float* rstd, const float* style,
+                             void* out, int N, int HW, int C, int ocs, int oco, void* stream) {
+    if (!h || !mean || !rstd || !style || !out || !in_shape_ok(dtype, N, HW, C)) return SBA_E_ARG;
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    if (ocs < C + oco || ocs % V || oco % V) return SBA_E_ARG;
+    const int blocks = grid_for((int64_t)N * HW * (C / V));
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((adain_fwd_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                                           (const T*)h, mean, rstd, style, (T*)out, N, HW, C, ocs, oco));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_adain_bwd_reduce(int dtype, const void* h, const void* dout, const float* mean,
+                                    const float* rstd, float* red, int N, int HW, int C, int dcs, int dco,
+                                    void* stream) {
+    if (!h || !dout || !mean || !rstd || !red || !in_shape_ok(dtype, N, HW, C)) return SBA_E_ARG;
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    if (dcs < C + dco || dcs % V || dco % V) return SBA_E_ARG;
+    const int rpi = 256 / (C / V);
+    int splits = cdiv(HW, rpi * 16);
+    if (splits > 256) splits = 256;
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((adain_bwd_reduce_kernel<T>), dim3(N, splits), dim3(256),
+                                           2 * C * sizeof(float), (hipStream_t)stream, (const T*)h,
+                                           (const T*)dout, mean, rstd, red, HW, C, dcs, dco));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_adain_bwd_apply(int dtype, const void* h, const void* dout, const float* mean,
+                                   const float* rstd, const float* style, const float* red, void* dh,
+                                   float* dstyle, int N, int HW, int C, int dcs, int dco, int accumulate,
+                                   void* stream) {
+    if (!h || !dout || !mean || !rstd || !style || !red || !dh || !in_shape_ok(dtype, N, HW, C)) return SBA_E_ARG;
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    if (dcs < C + dco || dcs % V || dco % V) return SBA_E_ARG;
+    const int blocks = grid_for((int64_t)N * HW * (C / V));
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((adain_bwd_apply_kernel<T>), dim3(blocks), dim3(256), 0,
+                                           (hipStream_t)stream, (const T*)h, (const T*)dout, mean, rstd, style,
+                                           red, (T*)dh, dstyle, N, HW, C, dcs, dco, accumulate));
+    return SBA_CHECK_LAUNCH();
+}

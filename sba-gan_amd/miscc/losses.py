@@ -1,0 +1,124 @@
+"""Losses of the adversarial step with the reference's names and positional signatures
+(AttnGAN2/code/miscc/losses.py:11-214), computed by fused HIP kernels.
+
+Differences from the reference, none of which change a result:
+  * no host synchronisation: cap_lens is read on the device (the reference calls
+    .tolist(), losses.py:71), and the per-term log strings (losses.py:184,205, five
+    .item() syncs) are replaced by a dict of device scalars;
+  * words_loss evaluates all B x B (caption, image) pairs in one launch instead of a Python
+    loop over captions, and does not return the per-caption attention maps (they are only
+    used by the PNG visualiser); the third return value is an empty list;
+  * the same-class mask is built on the host with numpy exactly like the reference
+    (losses.py:24-32,73-76) -- it is integer work on `class_ids`, a host array.
+"""
+import numpy as np
+import torch
+
+from miscc.config import cfg
+from sbagan import ops
+
+
+def cosine_similarity(x1, x2, dim=1, eps=1e-8):
+    """losses.py:11-17 (API parity; the training path uses the fused kernels)."""
+    w12 = torch.sum(x1 * x2, dim)
+    w1 = torch.norm(x1, 2, dim)
+    w2 = torch.norm(x2, 2, dim)
+    return (w12 / (w1 * w2).clamp(min=eps)).squeeze()
+
+
+_MASK_CACHE = {}
+
+
+def class_mask(class_ids, batch_size, device):
+    """masks[i][j] = (class_ids[j] == class_ids[i]) and j != i  (losses.py:24-32).  Bit-exact
+    integer work on the host; cached per (ids, device) so a training loop with fixed ids
+    uploads it once."""
+    if class_ids is None:
+        return None
+    ids = np.asarray(class_ids).reshape(-1)[:batch_size]
+    key = (ids.tobytes(), str(ids.dtype), batch_size, str(device))
+    m = _MASK_CACHE.get(key)
+    if m is None:
+        masks = []
+        for i in range(batch_size):
+            mask = (ids == ids[i]).astype(np.uint8)
+            mask[i] = 0
+            masks.append(mask.reshape((1, -1)))
+        m = torch.from_numpy(np.concatenate(masks, 0)).to(device)
+        if len(_MASK_CACHE) > 64:
+            _MASK_CACHE.clear()
+        _MASK_CACHE[key] = m
+    return m
+
+
+def sent_loss(cnn_code, rnn_code, labels, class_ids, batch_size, eps=1e-8):
+    """losses.py:20-59.  labels must be arange(batch_size) (the only value the reference
+    ever passes, trainer.py:150) or None."""
+    if labels is None:
+        return None, None
+    mask = class_mask(class_ids, batch_size, cnn_code.device)
+    return ops.SentLossFn.apply(cnn_code, rnn_code, mask, float(cfg.TRAIN.SMOOTH.GAMMA3), float(eps))
+
+
+def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size):
+    """losses.py:62-132."""
+    if labels is None:
+        return None, None, []
+    mask = class_mask(class_ids, batch_size, img_features.device)
+    s = cfg.TRAIN.SMOOTH
+    l0, l1 = ops.WordsLossFn.apply(img_features, words_emb, cap_lens, mask,
+                                   (float(s.GAMMA1), float(s.GAMMA2), float(s.GAMMA3)))
+    return l0, l1, []
+
+
+def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake_labels):
+    """losses.py:136-161: two separate trunk passes (real, fake.detach()), five heads,
+    errD = (real + cond_real)/2 + (fake + cond_fake + cond_wrong)/3."""
+    real_features = netD(real_imgs)
+    fake_features = netD(fake_imgs.detach())
+    cond_real = netD.COND_DNET(real_features, conditions)
+    cond_fake = netD.COND_DNET(fake_features, conditions)
+    batch_size = real_features.size(0)
+    cond_wrong = netD.COND_DNET(real_features[:(batch_size - 1)], conditions[1:batch_size])
+    if netD.UNCOND_DNET is not None:
+        real = netD.UNCOND_DNET(real_features)
+        fake = netD.UNCOND_DNET(fake_features)
+        return ops.BCEMultiFn.apply((1., 1., 0., 0., 0.), (.5, .5, 1. / 3, 1. / 3, 1. / 3),
+                                    real, cond_real, fake, cond_fake, cond_wrong)
+    return ops.BCEMultiFn.apply((1., 0., 0.), (1., .5, .5), cond_real, cond_fake, cond_wrong)
+
+
+def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sent_emb, match_labels,
+                   cap_lens, class_ids):
+    """losses.py:164-206.  Returns (errG_total, logs) where logs is a dict of device scalars
+    {'g_loss0', ..., 'w_loss', 's_loss'} (format with .item() outside the step)."""
+    numDs = len(netsD)
+    batch_size = real_labels.size(0)
+    logs = {}
+    errG_total = 0
+    for i in range(numDs):
+        features = netsD[i](fake_imgs[i])
+        cond_logits = netsD[i].COND_DNET(features, sent_emb)
+        if netsD[i].UNCOND_DNET is not None:
+            logits = netsD[i].UNCOND_DNET(features)
+            g_loss = ops.BCEMultiFn.apply((1., 1.), (1., 1.), logits, cond_logits)
+        else:
+            g_loss = ops.BCEMultiFn.apply((1.,), (1.,), cond_logits)
+        errG_total = errG_total + g_loss
+        logs['g_loss%d' % i] = g_loss.detach()
+        if i == (numDs - 1):
+            region_features, cnn_code = image_encoder(fake_imgs[i])
+            w_loss0, w_loss1, _ = words_loss(region_features, words_embs, match_labels, cap_lens,
+                                             class_ids, batch_size)
+            w_loss = (w_loss0 + w_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+            s_loss0, s_loss1 = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size)
+            s_loss = (s_loss0 + s_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+            errG_total = errG_total + w_loss + s_loss
+            logs['w_loss'] = w_loss.detach()
+            logs['s_loss'] = s_loss.detach()
+    return errG_total, logs
+
+
+def KL_loss(mu, logvar):
+    """losses.py:210-214."""
+    return ops.KLFn.apply(mu, logvar)

@@ -1,0 +1,102 @@
+"""ctypes binding of libsbagan_hip.so (the C ABI declared in include/sbagan_hip.h).
+
+The library is loaded eagerly and every symbol the header declares is bound with
+explicit argtypes; a missing library or symbol raises at import time -- there is
+no CPU or PyTorch fallback behind these calls.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, byref, c_char_p, c_float, c_int, c_int8, c_int32, c_int64,
+                    c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libsbagan_hip.so')
+
+SBA_F32, SBA_BF16 = 0, 1
+ACT_NONE, ACT_GLU, ACT_LRELU = 0, 1, 2
+MAX_TAPS = 16
+
+
+class ConvGeom(Structure):
+    _fields_ = [('N', c_int32), ('IH', c_int32), ('IW', c_int32), ('Cin', c_int32),
+                ('OH', c_int32), ('OW', c_int32), ('Cout', c_int32),
+                ('OHs', c_int32), ('OWs', c_int32),
+                ('sy', c_int32), ('sx', c_int32),
+                ('osy', c_int32), ('osx', c_int32), ('ooy', c_int32), ('oox', c_int32),
+                ('ups', c_int32), ('ntaps', c_int32),
+                ('ty', c_int8 * MAX_TAPS), ('tx', c_int8 * MAX_TAPS)]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError('libsbagan_hip.so not built: run `python __graft_entry__.py` or '
+                      '`make -C sba-gan_amd/csrc` (expected %s)' % LIB_PATH)
+lib = ctypes.CDLL(LIB_PATH)
+
+P, I, F, L = c_void_p, c_int, c_float, c_int64
+G = POINTER(ConvGeom)
+
+# name -> argtypes; mirrors include/sbagan_hip.h one to one
+SIGNATURES = {
+    'sba_conv_igemm': [I, P, P, P, P, P, G, P],
+    'sba_conv_wgrad': [I, P, P, P, G, I, P],
+    'sba_pack_weight': [I, P, P, I, I, I, I, I, P],
+    'sba_pool2x2_sum': [I, P, P, I, I, I, I, P],
+    'sba_bn_finalize': [P, P, P, P, P, P, P, P, P, P, I, L, F, F, P],
+    'sba_bn_act_fwd': [I, P, P, P, P, P, L, I, I, I, I, P],
+    'sba_bn_act_bwd_reduce': [I, P, P, P, P, P, P, P, L, I, I, I, I, P],
+    'sba_bn_act_bwd_apply': [I, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P],
+    'sba_bn1d_glu_fwd': [I, P, P, P, P, P, P, P, P, P, I, I, F, F, P],
+    'sba_bn1d_glu_bwd': [I, P, P, P, P, P, P, P, P, P, I, I, P],
+    'sba_linear_fwd': [P, P, P, P, I, I, I, P],
+    'sba_linear_bwd': [P, P, P, P, P, P, I, I, I, P],
+    'sba_ca_fwd': [P, P, P, P, P, I, I, P],
+    'sba_ca_bwd': [P, P, P, P, P, P, I, I, P],
+    'sba_ctx_proj_fwd': [P, P, P, I, I, I, I, P],
+    'sba_ctx_proj_bwd': [P, P, P, P, P, I, I, I, I, P],
+    'sba_instnorm_stats': [I, P, P, P, I, I, I, F, P],
+    'sba_adain_fwd': [I, P, P, P, P, P, I, I, I, I, I, P],
+    'sba_adain_bwd_reduce': [I, P, P, P, P, P, I, I, I, I, I, P],
+    'sba_adain_bwd_apply': [I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    'sba_word_attn_fwd': [I, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    'sba_word_attn_bwd': [I, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P],
+    'sba_img_head_fwd': [I, P, P, P, I, I, I, I, P],
+    'sba_img_head_bwd': [I, P, P, P, P, P, P, I, I, I, I, I, P],
+    'sba_d_stem_fwd': [I, P, P, P, I, I, I, P],
+    'sba_d_stem_bwd': [I, P, P, P, P, P, P, I, I, I, P],
+    'sba_logits_fwd': [I, P, P, P, P, I, I, P],
+    'sba_logits_bwd': [I, P, P, P, P, P, P, P, I, I, I, P],
+    'sba_cond_cat_fwd': [I, P, P, P, I, I, I, P],
+    'sba_cond_cat_bwd': [I, P, P, P, I, I, I, I, P],
+    'sba_bce_multi': [P, P, P, P, I, P, P, P],
+    'sba_kl_loss': [P, P, P, P, P, I, P],
+    'sba_damsm_words_fwd': [P, P, P, P, P, P, P, I, I, I, I, F, F, P],
+    'sba_damsm_words_bwd': [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, P],
+    'sba_damsm_sent_fwd': [P, P, P, I, I, F, F, P],
+    'sba_damsm_sent_bwd': [P, P, P, P, P, I, I, F, F, P],
+    'sba_ce_pair': [P, P, F, P, P, P, I, P],
+    'sba_combine2': [P, P, P, P, P, I, P],
+    'sba_adam_prepare': [P, F, F, F, P],
+    'sba_adam_step': [P, P, P, P, P, P, P, L, F, F, F, F, P],
+    'sba_cast': [I, P, I, P, L, P],
+}
+
+for _name, _args in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError if the .so lacks a declared symbol
+    _fn.argtypes = _args
+    _fn.restype = c_int
+lib.sba_version.restype = c_char_p
+lib.sba_version.argtypes = []
+
+_ERR = {-1: 'SBA_E_ARG (unsupported shape/alignment/enum)', -2: 'SBA_E_LAUNCH (HIP launch failed)'}
+
+
+def call(name, *args):
+    """Invoke a C-ABI entry point; non-zero status becomes RuntimeError (the
+    reference surfaces errors as Python exceptions)."""
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError('%s failed: %s' % (name, _ERR.get(rc, rc)))
+
+
+def version():
+    return lib.sba_version().decode()

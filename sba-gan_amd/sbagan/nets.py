@@ -1,0 +1,533 @@
+"""Module classes of the hot path with the reference's constructor / forward /
+state_dict surface (AttnGAN2/code/model.py, model_bert.py, GlobalAttention.py),
+implemented over the HIP operators in sbagan.ops.
+
+The nn.Module tree only HOLDS parameters (same attribute names and
+nn.Sequential indices as the reference, so `load_state_dict` of reference
+checkpoints works); every forward goes through a fused autograd Function.
+Conv weights are OIHW tensors stored channels_last ([O][KH][KW][I] in memory),
+which is the packed layout the implicit-GEMM kernels read.
+"""
+import torch
+import torch.nn as nn
+
+from miscc.config import cfg
+
+from . import ops
+from .ops import ACT_GLU, ACT_LRELU, ACT_NONE, CL
+
+
+# ----------------------------------------------------------------------------
+# parameter holders
+# ----------------------------------------------------------------------------
+class _Slot(nn.Module):
+    """Occupies an nn.Sequential index that holds a parameter-less module in the
+    reference (nn.Upsample, GLU, LeakyReLU, Tanh, Sigmoid)."""
+
+    def forward(self, x):
+        return x
+
+
+def _conv(cin, cout, k, stride=1, pad=0, bias=False):
+    m = nn.Conv2d(cin, cout, k, stride, pad, bias=bias)
+    m.weight.data = m.weight.data.contiguous(memory_format=CL)
+    return m
+
+
+def conv1x1(in_planes, out_planes, bias=False):
+    return _conv(in_planes, out_planes, 1, 1, 0, bias)
+
+
+def conv3x3(in_planes, out_planes):
+    return _conv(in_planes, out_planes, 3, 1, 1, False)
+
+
+class GLU(nn.Module):
+    """model.py:15-23 (kept for API parity; the fused blocks apply it in-kernel)."""
+
+    def forward(self, x):
+        nc = x.size(1)
+        assert nc % 2 == 0, 'channels dont divide 2!'
+        nc = nc // 2
+        return x[:, :nc] * torch.sigmoid(x[:, nc:])
+
+
+class _Layer(object):
+    """(conv, bn, packed weight) triple handed to the autograd Functions."""
+
+    def __init__(self, conv, bn):
+        self.conv, self.bn = conv, bn
+        self.pw = ops.PackedWeight(conv.weight)
+
+
+class _ConvBNAct(nn.Sequential):
+    """nn.Sequential-shaped holder whose forward is ONE fused conv+BN+activation."""
+    kind = '3x3'
+    act = ACT_NONE
+    conv_idx = 0
+
+    def _layer(self):
+        l = self.__dict__.get('_l')
+        if l is None:
+            l = _Layer(self[self.conv_idx], self[self.conv_idx + 1])
+            self.__dict__['_l'] = l
+        return l
+
+    def forward(self, x, residual=None):
+        l = self._layer()
+        return ops.ConvBNActFn.apply(x, l.conv.weight, l.bn.weight, l.bn.bias, l, self.kind, self.act, residual)
+
+
+class _UpBlock(_ConvBNAct):
+    kind, act, conv_idx = '3x3up', ACT_GLU, 1
+
+
+class _Block3x3LeakRelu(_ConvBNAct):
+    kind, act, conv_idx = '3x3', ACT_LRELU, 0
+
+
+class _DownBlock(_ConvBNAct):
+    kind, act, conv_idx = '4x4s2', ACT_LRELU, 0
+
+
+def upBlock(in_planes, out_planes):
+    """model.py:39-45: Upsample(x2 nearest), conv3x3, BatchNorm2d, GLU."""
+    return _UpBlock(_Slot(), conv3x3(in_planes, out_planes * 2), nn.BatchNorm2d(out_planes * 2), _Slot())
+
+
+def Block3x3_leakRelu(in_planes, out_planes):
+    """model.py:540-546."""
+    return _Block3x3LeakRelu(conv3x3(in_planes, out_planes), nn.BatchNorm2d(out_planes), _Slot())
+
+
+def downBlock(in_planes, out_planes):
+    """model.py:550-556."""
+    return _DownBlock(_conv(in_planes, out_planes, 4, 2, 1), nn.BatchNorm2d(out_planes), _Slot())
+
+
+class ResBlock(nn.Module):
+    """model.py:57-71."""
+
+    def __init__(self, channel_num):
+        super(ResBlock, self).__init__()
+        self.block = nn.Sequential(
+            conv3x3(channel_num, channel_num * 2), nn.BatchNorm2d(channel_num * 2), _Slot(),
+            conv3x3(channel_num, channel_num), nn.BatchNorm2d(channel_num))
+
+    def _layers(self):
+        if '_l1' not in self.__dict__:
+            self.__dict__['_l1'] = _Layer(self.block[0], self.block[1])
+            self.__dict__['_l2'] = _Layer(self.block[3], self.block[4])
+        return self.__dict__['_l1'], self.__dict__['_l2']
+
+    @property
+    def l1(self):
+        return self._layers()[0]
+
+    @property
+    def l2(self):
+        return self._layers()[1]
+
+    def forward(self, x):
+        l1, l2 = self._layers()
+        return ops.ResBlockFn.apply(x, l1.conv.weight, l1.bn.weight, l1.bn.bias,
+                                    l2.conv.weight, l2.bn.weight, l2.bn.bias, self)
+
+
+def _linear(x, lin):
+    return ops.LinearFn.apply(x, lin.weight, lin.bias)
+
+
+# ----------------------------------------------------------------------------
+# attention (GlobalAttention.py)
+# ----------------------------------------------------------------------------
+def func_attention(query, context, gamma1):
+    """GlobalAttention.py:31-69 for one (query, context) batch; provided for API parity
+    (the training path uses the fused all-pairs kernel behind miscc.losses.words_loss).
+    Returns (weightedContext B x ndf x T, attn B x T x ih x iw)."""
+    B, T = query.size(0), query.size(2)
+    ih, iw = context.size(2), context.size(3)
+    S = ih * iw
+    ctx = context.reshape(B, -1, S)
+    attn = torch.bmm(ctx.transpose(1, 2), query)
+    attn = torch.softmax(attn.reshape(B * S, T), dim=1).view(B, S, T)
+    attn = torch.softmax(attn.transpose(1, 2).reshape(B * T, S) * gamma1, dim=1).view(B, T, S)
+    return torch.bmm(ctx, attn.transpose(1, 2)), attn.view(B, T, ih, iw)
+
+
+class GlobalAttentionGeneral(nn.Module):
+    """GlobalAttention.py:72-121.  `reference_mask_order` keeps the reference's
+    row-ordering quirk of the mask (:105-108); set it False for the per-sample mask."""
+
+    def __init__(self, idf, cdf):
+        super(GlobalAttentionGeneral, self).__init__()
+        self.conv_context = conv1x1(cdf, idf)
+        self.sm = nn.Softmax(dim=1)
+        self.mask = None
+        self.reference_mask_order = True
+
+    def applyMask(self, mask):
+        self.mask = mask  # batch x sourceL
+
+    def forward(self, input, context):
+        mode = 0 if self.reference_mask_order else 1
+        out, att = ops.WordAttnFn.apply(input, context, self.conv_context.weight, self.mask, mode)
+        return out, att
+
+
+# ----------------------------------------------------------------------------
+# generator
+# ----------------------------------------------------------------------------
+class CA_NET(nn.Module):
+    """model.py:271-299.  The N(0,1) draw of reparametrize (:289-293) comes from
+    torch's generator unless `eps` is injected (tests / golden parity)."""
+
+    def __init__(self):
+        super(CA_NET, self).__init__()
+        self.t_dim = cfg.TEXT.EMBEDDING_DIM
+        self.c_dim = cfg.GAN.CONDITION_DIM
+        self.fc = nn.Linear(self.t_dim, self.c_dim * 4, bias=True)
+        self.relu = GLU()
+        self.eps = None
+
+    def forward(self, text_embedding):
+        h = _linear(text_embedding, self.fc)
+        eps = self.eps
+        if eps is None:
+            eps = torch.randn((h.size(0), self.c_dim), dtype=torch.float32, device=h.device)
+        return ops.CAFn.apply(h, eps)
+
+
+class MAPPING_NET(nn.Module):
+    """model.py:301-321 (6 layers) / model_bert.py:334-356 (8 layers)."""
+
+    def __init__(self, n_layers=6):
+        super(MAPPING_NET, self).__init__()
+        self.z_dim = cfg.GAN.Z_DIM
+        self.w_dim = cfg.GAN.W_DIM
+        layers = [nn.Linear(self.z_dim, self.w_dim, bias=False)]
+        layers += [nn.Linear(self.w_dim, self.w_dim, bias=False) for _ in range(n_layers - 1)]
+        self.fc = nn.Sequential(*layers)
+
+    def forward(self, z_code):
+        x = z_code
+        for lin in self.fc:
+            x = _linear(x, lin)
+        return x
+
+
+class ADAIN_NORM(nn.Module):
+    """model.py:324-339."""
+
+    def __init__(self, ngf):
+        super(ADAIN_NORM, self).__init__()
+        self.norm = nn.InstanceNorm2d(ngf)
+        self.style = nn.Linear(cfg.GAN.W_DIM, ngf * 2)
+
+    def forward(self, h_code, w_code):
+        return ops.AdainFn.apply(h_code, _linear(w_code, self.style))
+
+
+class _FcBnGlu(nn.Sequential):
+    """INIT_STAGE_G.fc: Linear(no bias), BatchNorm1d, GLU (model.py:353-356)."""
+
+    @property
+    def bn(self):
+        return self[1]
+
+    def forward(self, x):
+        return ops.FcBnGluFn.apply(x, self[0].weight, self[1].weight, self[1].bias, self)
+
+
+class INIT_STAGE_G(nn.Module):
+    """model.py:342-383; `cond_only` selects model_bert.py:377-425 (input = c_code)."""
+
+    def __init__(self, ngf, ncf, cond_only=False):
+        super(INIT_STAGE_G, self).__init__()
+        self.gf_dim = ngf
+        self.cond_only = cond_only
+        self.in_dim = ncf if cond_only else cfg.GAN.Z_DIM + ncf
+        self.fc = _FcBnGlu(nn.Linear(self.in_dim, ngf * 4 * 4 * 2, bias=False),
+                           nn.BatchNorm1d(ngf * 4 * 4 * 2), _Slot())
+        self.upsample1 = upBlock(ngf, ngf // 2)
+        self.upsample2 = upBlock(ngf // 2, ngf // 4)
+        self.upsample3 = upBlock(ngf // 4, ngf // 8)
+        self.upsample4 = upBlock(ngf // 8, ngf // 16)
+
+    def forward(self, *args):
+        if self.cond_only:      # model_bert.py:402: forward(c_code, z_code, w_code)
+            x = args[0]
+        else:                   # model.py:363: forward(z_code, c_code)
+            z_code, c_code = args[0], args[1]
+            x = torch.cat((c_code, z_code), 1)
+        out = self.fc(x)
+        out = self.upsample1(out)
+        out = self.upsample2(out)
+        out = self.upsample3(out)
+        return self.upsample4(out)
+
+
+class NEXT_STAGE_G(nn.Module):
+    """model.py:386-423 (`adain`) / model_bert.py:428-468 (`adain2`)."""
+
+    def __init__(self, ngf, nef, ncf, adain_name='adain'):
+        super(NEXT_STAGE_G, self).__init__()
+        self.gf_dim, self.ef_dim, self.cf_dim = ngf, nef, ncf
+        self.num_residual = cfg.GAN.R_NUM
+        self._adain_name = adain_name
+        self.att = GlobalAttentionGeneral(ngf, nef)
+        setattr(self, adain_name, ADAIN_NORM(ngf))
+        self.residual = nn.Sequential(*[ResBlock(ngf * 2) for _ in range(cfg.GAN.R_NUM)])
+        self.upsample = upBlock(ngf * 2, ngf)
+        self.return_attention = True
+
+    def forward(self, h_code, c_code, w_code, word_embs, mask):
+        self.att.applyMask(mask)
+        adain = getattr(self, self._adain_name)
+        style = _linear(w_code, adain.style)
+        mode = 0 if self.att.reference_mask_order else 1
+        hc, att = ops.AttnAdainCatFn.apply(h_code, style, word_embs, self.att.conv_context.weight, mask,
+                                           self.return_attention, mode)
+        out = hc
+        for blk in self.residual:
+            out = blk(out)
+        out = self.upsample(out)
+        return out, (att if self.return_attention else None)
+
+
+class GET_IMAGE_G(nn.Module):
+    """model.py:426-437."""
+
+    def __init__(self, ngf):
+        super(GET_IMAGE_G, self).__init__()
+        self.gf_dim = ngf
+        self.img = nn.Sequential(conv3x3(ngf, 3), _Slot())
+
+    def forward(self, h_code):
+        return ops.ImgHeadFn.apply(h_code, self.img[0].weight)
+
+
+class _GBase(nn.Module):
+    def _build(self, n_map, cond_only, adain_name):
+        ngf, nef, ncf = cfg.GAN.GF_DIM, cfg.TEXT.EMBEDDING_DIM, cfg.GAN.CONDITION_DIM
+        self.ca_net = CA_NET()
+        self.mapping_net = MAPPING_NET(n_map)
+        self.branch_num = cfg.TREE.BRANCH_NUM
+        if self.branch_num > 0:
+            self.h_net1 = INIT_STAGE_G(ngf * 16, ncf, cond_only)
+            self.img_net1 = GET_IMAGE_G(ngf)
+        if self.branch_num > 1:
+            self.h_net2 = NEXT_STAGE_G(ngf, nef, ncf, adain_name)
+            self.img_net2 = GET_IMAGE_G(ngf)
+        if self.branch_num > 2:
+            self.h_net3 = NEXT_STAGE_G(ngf, nef, ncf, adain_name)
+            self.img_net3 = GET_IMAGE_G(ngf)
+
+    def set_return_attention(self, flag):
+        """The B x L x H x W attention maps are unused in training (trainer.py:262); turning them
+        off saves materialising them.  Default True = reference behaviour."""
+        for m in self.modules():
+            if isinstance(m, NEXT_STAGE_G):
+                m.return_attention = flag
+
+    def _run(self, z1, w2, w3, sent_emb, word_embs, mask):
+        fake_imgs, att_maps = [], []
+        c_code, mu, logvar = self.ca_net(sent_emb)
+        if self.branch_num > 0:
+            h = self.h_net1(c_code, z1, None) if self.h_net1.cond_only else self.h_net1(z1, c_code)
+            fake_imgs.append(self.img_net1(h))
+        if self.branch_num > 1:
+            h, att1 = self.h_net2(h, c_code, w2, word_embs, mask)
+            fake_imgs.append(self.img_net2(h))
+            if att1 is not None:
+                att_maps.append(att1)
+        if self.branch_num > 2:
+            h, att2 = self.h_net3(h, c_code, w3, word_embs, mask)
+            fake_imgs.append(self.img_net3(h))
+            if att2 is not None:
+                att_maps.append(att2)
+        return fake_imgs, att_maps, mu, logvar
+
+
+class G_NET(_GBase):
+    """model.py:440-492: forward(z_code, sent_emb, word_embs, mask) ->
+    (fake_imgs list, att_maps list, mu, logvar)."""
+
+    def __init__(self):
+        super(G_NET, self).__init__()
+        self._build(6, False, 'adain')
+
+    def forward(self, z_code, sent_emb, word_embs, mask):
+        w = self.mapping_net(z_code)
+        return self._run(z_code, w, w, sent_emb, word_embs, mask)
+
+
+class G_NET_BERT(_GBase):
+    """model_bert.py G_NET: 8-layer mapping net, c-only initial stage, `adain2`."""
+
+    def __init__(self):
+        super(G_NET_BERT, self).__init__()
+        self._build(8, True, 'adain2')
+
+    def forward(self, z_code, sent_emb, word_embs, mask):
+        w = self.mapping_net(z_code)
+        return self._run(z_code, w, w, sent_emb, word_embs, mask)
+
+
+class G_NET_MIX(_GBase):
+    """model_bert.py:485-539: z_code is 2 x B x nz; w(z[0]) styles stage 2, w(z[1]) stage 3."""
+
+    def __init__(self):
+        super(G_NET_MIX, self).__init__()
+        self._build(8, True, 'adain2')
+
+    def forward(self, z_code, sent_emb, word_embs, mask):
+        w1 = self.mapping_net(z_code[0])
+        w2 = self.mapping_net(z_code[1])
+        return self._run(z_code, w1, w2, sent_emb, word_embs, mask)
+
+
+# ----------------------------------------------------------------------------
+# discriminators
+# ----------------------------------------------------------------------------
+class _EncodeBy16(nn.Sequential):
+    """encode_image_by_16times (model.py:560-578), same nn.Sequential indices."""
+
+    def _layers(self):
+        if '_ls' not in self.__dict__:
+            self.__dict__['_ls'] = [_Layer(self[2], self[3]), _Layer(self[5], self[6]), _Layer(self[8], self[9])]
+        return self.__dict__['_ls']
+
+    def forward(self, x):
+        h = ops.DStemFn.apply(x, self[0].weight)
+        for l in self._layers():
+            h = ops.ConvBNActFn.apply(h, l.conv.weight, l.bn.weight, l.bn.bias, l, '4x4s2', ACT_LRELU, None)
+        return h
+
+
+def encode_image_by_16times(ndf):
+    return _EncodeBy16(
+        _conv(3, ndf, 4, 2, 1), _Slot(),
+        _conv(ndf, ndf * 2, 4, 2, 1), nn.BatchNorm2d(ndf * 2), _Slot(),
+        _conv(ndf * 2, ndf * 4, 4, 2, 1), nn.BatchNorm2d(ndf * 4), _Slot(),
+        _conv(ndf * 4, ndf * 8, 4, 2, 1), nn.BatchNorm2d(ndf * 8), _Slot())
+
+
+class D_GET_LOGITS(nn.Module):
+    """model.py:581-607."""
+
+    def __init__(self, ndf, nef, bcondition=False):
+        super(D_GET_LOGITS, self).__init__()
+        self.df_dim, self.ef_dim, self.bcondition = ndf, nef, bcondition
+        if bcondition:
+            self.jointConv = Block3x3_leakRelu(ndf * 8 + nef, ndf * 8)
+        self.outlogits = nn.Sequential(_conv(ndf * 8, 1, 4, 4, 0, bias=True), _Slot())
+
+    def forward(self, h_code, c_code=None):
+        if self.bcondition and c_code is not None:
+            h_c_code = self.jointConv(ops.CondCatFn.apply(h_code, c_code.reshape(-1, self.ef_dim)))
+        else:
+            h_c_code = h_code
+        o = self.outlogits[0]
+        return ops.LogitsFn.apply(h_c_code, o.weight, o.bias)
+
+
+class _DBase(nn.Module):
+    def _heads(self, b_jcu):
+        ndf, nef = cfg.GAN.DF_DIM, cfg.TEXT.EMBEDDING_DIM
+        self.UNCOND_DNET = D_GET_LOGITS(ndf, nef, bcondition=False) if b_jcu else None
+        self.COND_DNET = D_GET_LOGITS(ndf, nef, bcondition=True)
+
+
+class D_NET64(_DBase):
+    """model.py:611-625."""
+
+    def __init__(self, b_jcu=True):
+        super(D_NET64, self).__init__()
+        ndf = cfg.GAN.DF_DIM
+        self.img_code_s16 = encode_image_by_16times(ndf)
+        self._heads(b_jcu)
+
+    def forward(self, x_var):
+        return self.img_code_s16(x_var)
+
+
+class D_NET128(_DBase):
+    """model.py:629-648."""
+
+    def __init__(self, b_jcu=True):
+        super(D_NET128, self).__init__()
+        ndf = cfg.GAN.DF_DIM
+        self.img_code_s16 = encode_image_by_16times(ndf)
+        self.img_code_s32 = downBlock(ndf * 8, ndf * 16)
+        self.img_code_s32_1 = Block3x3_leakRelu(ndf * 16, ndf * 8)
+        self._heads(b_jcu)
+
+    def forward(self, x_var):
+        x = self.img_code_s16(x_var)
+        x = self.img_code_s32(x)
+        return self.img_code_s32_1(x)
+
+
+class D_NET256(_DBase):
+    """model.py:652-674."""
+
+    def __init__(self, b_jcu=True):
+        super(D_NET256, self).__init__()
+        ndf = cfg.GAN.DF_DIM
+        self.img_code_s16 = encode_image_by_16times(ndf)
+        self.img_code_s32 = downBlock(ndf * 8, ndf * 16)
+        self.img_code_s64 = downBlock(ndf * 16, ndf * 32)
+        self.img_code_s64_1 = Block3x3_leakRelu(ndf * 32, ndf * 16)
+        self.img_code_s64_2 = Block3x3_leakRelu(ndf * 16, ndf * 8)
+        self._heads(b_jcu)
+
+    def forward(self, x_var):
+        x = self.img_code_s16(x_var)
+        x = self.img_code_s32(x)
+        x = self.img_code_s64(x)
+        x = self.img_code_s64_1(x)
+        return self.img_code_s64_2(x)
+
+
+# ----------------------------------------------------------------------------
+# text encoder (module API kept; frozen + eval() in GAN training, trainer.py:64-73;
+# not a hand-written-kernel target: SURVEY.md section 2 row 7)
+# ----------------------------------------------------------------------------
+class RNN_ENCODER(nn.Module):
+    """model.py:75-159: Embedding -> dropout -> bi-LSTM over packed sequences ->
+    (words_emb B x nhidden x Lmax, sent_emb B x nhidden)."""
+
+    def __init__(self, ntoken, ninput=300, drop_prob=0.5, nhidden=128, nlayers=1, bidirectional=True):
+        super(RNN_ENCODER, self).__init__()
+        self.n_steps = cfg.TEXT.WORDS_NUM
+        self.ntoken, self.ninput, self.drop_prob = ntoken, ninput, drop_prob
+        self.nlayers, self.bidirectional = nlayers, bidirectional
+        self.rnn_type = cfg.RNN_TYPE
+        self.num_directions = 2 if bidirectional else 1
+        self.nhidden = nhidden // self.num_directions
+        self.encoder = nn.Embedding(ntoken, ninput)
+        self.drop = nn.Dropout(drop_prob)
+        rnn = {'LSTM': nn.LSTM, 'GRU': nn.GRU}.get(self.rnn_type)
+        if rnn is None:
+            raise NotImplementedError
+        self.rnn = rnn(ninput, self.nhidden, nlayers, batch_first=True, dropout=drop_prob,
+                       bidirectional=bidirectional)
+        self.encoder.weight.data.uniform_(-0.1, 0.1)
+
+    def init_hidden(self, bsz):
+        w = next(self.parameters()).data
+        z = lambda: w.new_zeros(self.nlayers * self.num_directions, bsz, self.nhidden)
+        return (z(), z()) if self.rnn_type == 'LSTM' else z()
+
+    def forward(self, captions, cap_lens, hidden, mask=None):
+        from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+        emb = self.drop(self.encoder(captions))
+        lens = cap_lens.data.tolist()
+        emb = pack_padded_sequence(emb, lens, batch_first=True)
+        output, hidden = self.rnn(emb, hidden)
+        output = pad_packed_sequence(output, batch_first=True)[0]
+        words_emb = output.transpose(1, 2)
+        h = hidden[0] if self.rnn_type == 'LSTM' else hidden
+        sent_emb = h.transpose(0, 1).contiguous().view(-1, self.nhidden * self.num_directions)
+        return words_emb, sent_emb

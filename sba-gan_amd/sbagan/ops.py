@@ -1,0 +1,850 @@
+"""Host-side operators over the C-ABI HIP library: tensor plumbing (torch owns the
+device memory and the stream), convolution geometry, packed-weight caching, and the
+torch.autograd.Function wrappers the module classes in model.py are built from.
+
+Activations are logical NCHW tensors with channels_last strides, i.e. NHWC in
+memory, of dtype COMPUTE_DTYPE (bfloat16 by default, float32 for the exact-f32
+MFMA path).  Parameters, their gradients, statistics and losses are float32.
+
+Parameter gradients are ACCUMULATED IN PLACE into `param.grad` by the kernels
+(the reference only ever uses `loss.backward(); optimizer.step()`,
+trainer.py:269-297); the autograd Functions therefore return None for
+parameters.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GLU, ACT_LRELU, ACT_NONE, ConvGeom, call
+
+CL = torch.channels_last
+COMPUTE_DTYPE = torch.bfloat16
+BN_EPS, BN_MOMENTUM, IN_EPS = 1e-5, 0.1, 1e-5
+
+_WEIGHT_EPOCH = [0]          # bumped whenever parameters are changed behind torch's back
+
+
+def set_compute_dtype(dt):
+    global COMPUTE_DTYPE
+    assert dt in (torch.bfloat16, torch.float32)
+    COMPUTE_DTYPE = dt
+    _WEIGHT_EPOCH[0] += 1
+
+
+def compute_dtype():
+    return COMPUTE_DTYPE
+
+
+def weights_changed():
+    """Call after parameters were modified through raw pointers (fused Adam)."""
+    _WEIGHT_EPOCH[0] += 1
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return _lib.SBA_F32
+    if t.dtype == torch.bfloat16:
+        return _lib.SBA_BF16
+    raise TypeError('unsupported activation dtype %s' % t.dtype)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError('sbagan HIP operators need CUDA/HIP tensors (got a %s tensor); there is no CPU '
+                           'fallback' % t.device)
+
+
+def as_act(x, dtype=None):
+    """logical NCHW, NHWC in memory, compute dtype."""
+    dtype = dtype or COMPUTE_DTYPE
+    if x.dtype != dtype:
+        x = x.to(dtype)
+    if x.dim() == 4 and not x.is_contiguous(memory_format=CL):
+        x = x.contiguous(memory_format=CL)
+    return x
+
+
+def empty_act(n, c, h, w, like):
+    return torch.empty((n, c, h, w), dtype=like.dtype, device=like.device, memory_format=CL)
+
+
+def param_grad(p):
+    """f32 gradient buffer of a parameter with the parameter's own memory layout."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
+    return p.grad
+
+
+# ----------------------------------------------------------------------------
+# convolution geometry
+# ----------------------------------------------------------------------------
+_GEOM_CACHE = {}
+
+
+def _geom(key):
+    g = _GEOM_CACHE.get(key)
+    if g is not None:
+        return g
+    kind, N, IH, IW, Cin, Cout, extra = key
+    g = ConvGeom()
+    g.N, g.IH, g.IW, g.Cin, g.Cout = N, IH, IW, Cin, Cout
+    g.sy = g.sx = 1
+    g.osy = g.osx = 1
+    g.ooy = g.oox = 0
+    g.ups = 0
+    if kind in ('3x3', '3x3up'):
+        up = 2 if kind == '3x3up' else 1
+        g.OH, g.OW = IH * up, IW * up
+        g.OHs, g.OWs = g.OH, g.OW
+        g.ups = 1 if kind == '3x3up' else 0
+        g.ntaps = 9
+        for t in range(9):
+            g.ty[t], g.tx[t] = t // 3 - 1, t % 3 - 1
+    elif kind == '4x4s2':
+        g.OH, g.OW = IH // 2, IW // 2
+        g.OHs, g.OWs = g.OH, g.OW
+        g.sy = g.sx = 2
+        g.ntaps = 16
+        for t in range(16):
+            g.ty[t], g.tx[t] = t // 4 - 1, t % 4 - 1
+    elif kind == '4x4s2_dgrad':
+        # input = dY (IH x IW), output = dX (2IH x 2IW), parity class extra = (py, px)
+        py, px = extra
+        g.OH, g.OW = IH * 2, IW * 2
+        g.OHs, g.OWs = IH, IW
+        g.osy = g.osx = 2
+        g.ooy, g.oox = py, px
+        g.ntaps = 4
+        for t in range(4):
+            g.ty[t], g.tx[t] = py - t // 2, px - t % 2
+    else:
+        raise ValueError(kind)
+    _GEOM_CACHE[key] = g
+    return g
+
+
+def _conv_out_hw(kind, H, W):
+    if kind == '3x3':
+        return H, W
+    if kind == '3x3up':
+        return 2 * H, 2 * W
+    if kind == '4x4s2':
+        return H // 2, W // 2
+    raise ValueError(kind)
+
+
+class PackedWeight(object):
+    """Packed copies of one OIHW conv parameter (stored channels_last, i.e.
+    [O][KH][KW][I] f32 in memory): the forward operand in the compute dtype and
+    the data-gradient operand, rebuilt lazily when the parameter changes."""
+
+    def __init__(self, param):
+        self.param = param
+        self._fwd = self._dgrad = None
+        self._kf = self._kd = None
+
+    def _key(self, dtype):
+        return (self.param._version, _WEIGHT_EPOCH[0], dtype, self.param.data_ptr())
+
+    def _master(self):
+        p = self.param.detach()
+        if not p.is_contiguous(memory_format=CL):
+            raise RuntimeError('conv parameters must be stored channels_last (use sbagan layers)')
+        return p
+
+    def fwd(self, dtype):
+        if dtype == torch.float32:
+            return self._master()
+        k = self._key(dtype)
+        if self._kf != k:
+            p = self._master()
+            O, I, KH, KW = p.shape
+            if self._fwd is None or self._fwd.dtype != dtype:
+                self._fwd = torch.empty(O * KH * KW * I, dtype=dtype, device=p.device)
+            call('sba_pack_weight', _lib.SBA_BF16, _p(p), _p(self._fwd), O, KH, KW, I, 0, _stream())
+            self._kf = k
+        return self._fwd
+
+    def dgrad(self, dtype, kind):
+        k = self._key(dtype) + (kind,)
+        if self._kd != k:
+            p = self._master()
+            O, I, KH, KW = p.shape
+            if self._dgrad is None or self._dgrad.dtype != dtype:
+                self._dgrad = torch.empty(O * KH * KW * I, dtype=dtype, device=p.device)
+            mode = 2 if kind == '4x4s2' else 1
+            dcode = _lib.SBA_BF16 if dtype == torch.bfloat16 else _lib.SBA_F32
+            call('sba_pack_weight', dcode, _p(p), _p(self._dgrad), O, KH, KW, I, mode, _stream())
+            self._kd = k
+        return self._dgrad
+
+
+# ----------------------------------------------------------------------------
+# raw (non-autograd) building blocks
+# ----------------------------------------------------------------------------
+def conv_forward(x, pw, kind, want_stats=True, addend=None):
+    """y = conv(x) in NHWC; returns (y, stats) with stats = per-channel (sum, sumsq)."""
+    _need_gpu(x)
+    N, Cin, H, W = x.shape
+    O = pw.param.shape[0]
+    OH, OW = _conv_out_hw(kind, H, W)
+    y = empty_act(N, O, OH, OW, x)
+    stats = torch.zeros(2 * O, dtype=torch.float32, device=x.device) if want_stats else None
+    g = _geom((kind, N, H, W, Cin, O, None))
+    call('sba_conv_igemm', _dt(x), _p(x), _p(pw.fwd(x.dtype)), _p(y), _p(addend), _p(stats),
+         ctypes.byref(g), _stream())
+    return y, stats
+
+
+def conv_dgrad(dy, pw, kind, in_hw, addend=None):
+    """dx = conv_transpose(dy); `addend` (same shape as dx) is added in the epilogue."""
+    N, O, OH, OW = dy.shape
+    I = pw.param.shape[1]
+    H, W = in_hw
+    wd = pw.dgrad(dy.dtype, kind)
+    if kind in ('3x3', '3x3up'):
+        g = _geom(('3x3', N, OH, OW, O, I, None))
+        if kind == '3x3':
+            dx = empty_act(N, I, H, W, dy)
+            call('sba_conv_igemm', _dt(dy), _p(dy), _p(wd), _p(dx), _p(addend), None, ctypes.byref(g), _stream())
+            return dx
+        dup = empty_act(N, I, OH, OW, dy)
+        call('sba_conv_igemm', _dt(dy), _p(dy), _p(wd), _p(dup), None, None, ctypes.byref(g), _stream())
+        dx = empty_act(N, I, H, W, dy)
+        call('sba_pool2x2_sum', _dt(dy), _p(dup), _p(dx), N, H, W, I, _stream())
+        if addend is not None:
+            dx += addend
+        return dx
+    if kind == '4x4s2':
+        dx = empty_act(N, I, H, W, dy)
+        esz = dy.element_size()
+        for cls in range(4):
+            g = _geom(('4x4s2_dgrad', N, OH, OW, O, I, (cls // 2, cls % 2)))
+            wptr = wd.data_ptr() + cls * I * 4 * O * esz
+            call('sba_conv_igemm', _dt(dy), _p(dy), wptr, _p(dx), _p(addend), None, ctypes.byref(g), _stream())
+        return dx
+    raise ValueError(kind)
+
+
+def _ksplit(tiles, M):
+    chunks = (M + 63) // 64
+    want = max(1, (1536 + tiles - 1) // tiles)
+    return max(1, min(want, chunks))
+
+
+def conv_wgrad(x, dy, param, kind):
+    """param.grad[O][KH][KW][I] += dy^T (*) x."""
+    N, Cin, H, W = x.shape
+    O = dy.shape[1]
+    g = _geom((kind, N, H, W, Cin, O, None))
+    gbuf = param_grad(param)
+    M = N * g.OHs * g.OWs
+    tiles = ((O + 63) // 64) * ((Cin + 63) // 64) * g.ntaps
+    call('sba_conv_wgrad', _dt(x), _p(x), _p(dy), _p(gbuf), ctypes.byref(g), _ksplit(tiles, M), _stream())
+
+
+class BNState(object):
+    """per-forward BatchNorm quantities: rows of aux = scale, shift, mean, rstd."""
+    __slots__ = ('aux', 'C', 'rows')
+
+
+def bn_prepare(stats, bn, rows, training):
+    C = bn.weight.numel()
+    st = BNState()
+    st.C, st.rows = C, rows
+    st.aux = torch.empty((4, C), dtype=torch.float32, device=bn.weight.device)
+    a = st.aux
+    if training:
+        call('sba_bn_finalize', _p(stats), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
+             _p(bn.num_batches_tracked), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), C, rows, BN_EPS, BN_MOMENTUM,
+             _stream())
+    else:   # inference: running statistics (host-side tensor math on [C] vectors, off the training path)
+        with torch.no_grad():
+            rstd = torch.rsqrt(bn.running_var + BN_EPS)
+            a[0] = bn.weight * rstd
+            a[1] = bn.bias - bn.running_mean * a[0]
+            a[2] = bn.running_mean
+            a[3] = rstd
+    return st
+
+
+def bn_act_forward(y, st, act, residual=None):
+    N, C, H, W = y.shape
+    Co = C // 2 if act == ACT_GLU else C
+    out = empty_act(N, Co, H, W, y)
+    call('sba_bn_act_fwd', _dt(y), _p(y), _p(st.aux[0]), _p(st.aux[1]), _p(residual), _p(out), N * H * W, C,
+         act, Co, 0, _stream())
+    return out
+
+
+def bn_act_backward(y, dout, st, bn, act, need_param_grad=True):
+    N, C, H, W = y.shape
+    Co = C // 2 if act == ACT_GLU else C
+    rows = N * H * W
+    a = st.aux
+    red = torch.zeros(2 * C, dtype=torch.float32, device=y.device)
+    call('sba_bn_act_bwd_reduce', _dt(y), _p(y), _p(dout), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(red),
+         rows, C, act, Co, 0, _stream())
+    dy = torch.empty_like(y)
+    dg = db = None
+    if need_param_grad:
+        dg, db = param_grad(bn.weight), param_grad(bn.bias)
+    call('sba_bn_act_bwd_apply', _dt(y), _p(y), _p(dout), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]),
+         _p(bn.weight), _p(red), _p(dy), _p(dg), _p(db), rows, C, act, Co, 0, _stream())
+    return dy
+
+
+# ----------------------------------------------------------------------------
+# autograd Functions
+# ----------------------------------------------------------------------------
+def _c(t):
+    """gradient tensors arrive with arbitrary strides: force the NHWC layout."""
+    if t.dim() == 4:
+        return t.contiguous(memory_format=CL)
+    return t.contiguous()
+
+
+class ConvBNActFn(torch.autograd.Function):
+    """conv (3x3 / nearest-x2 + 3x3 / 4x4 s2) -> BatchNorm(train) -> GLU | LeakyReLU | none (+ residual).
+    upBlock model.py:39-45, Block3x3_leakRelu :540-546, downBlock :550-556, ResBlock halves :60-65."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, layer, kind, act, residual):
+        x = as_act(x)
+        y, stats = conv_forward(x, layer.pw, kind)
+        N, C, H, W = y.shape
+        st = bn_prepare(stats, layer.bn, N * H * W, layer.bn.training)
+        out = bn_act_forward(y, st, act, residual)
+        ctx.layer, ctx.kind, ctx.act, ctx.st = layer, kind, act, st
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y = ctx.saved_tensors
+        layer, kind, act = ctx.layer, ctx.kind, ctx.act
+        dout = _c(dout)
+        dy = bn_act_backward(y, dout, ctx.st, layer.bn, act, ctx.needs_input_grad[2])
+        if ctx.needs_input_grad[1]:
+            conv_wgrad(x, dy, layer.conv.weight, kind)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_dgrad(dy, layer.pw, kind, x.shape[2:])
+        dres = dout if (ctx.has_res and ctx.needs_input_grad[7]) else None
+        return dx, None, None, None, None, None, None, dres
+
+
+class ResBlockFn(torch.autograd.Function):
+    """ResBlock (model.py:57-71) as one node so that the skip gradient is added in the
+    epilogue of the first conv's data-gradient instead of a separate pass."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, blk):
+        x = as_act(x)
+        y1, s1 = conv_forward(x, blk.l1.pw, '3x3')
+        N, C1, H, W = y1.shape
+        st1 = bn_prepare(s1, blk.l1.bn, N * H * W, blk.l1.bn.training)
+        a1 = bn_act_forward(y1, st1, ACT_GLU)
+        y2, s2 = conv_forward(a1, blk.l2.pw, '3x3')
+        st2 = bn_prepare(s2, blk.l2.bn, N * H * W, blk.l2.bn.training)
+        out = bn_act_forward(y2, st2, ACT_NONE, residual=x)
+        ctx.blk, ctx.st1, ctx.st2 = blk, st1, st2
+        ctx.save_for_backward(x, y1, a1, y2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y1, a1, y2 = ctx.saved_tensors
+        blk = ctx.blk
+        dout = _c(dout)
+        need_p = ctx.needs_input_grad[1]
+        dy2 = bn_act_backward(y2, dout, ctx.st2, blk.l2.bn, ACT_NONE, need_p)
+        if need_p:
+            conv_wgrad(a1, dy2, blk.l2.conv.weight, '3x3')
+        da1 = conv_dgrad(dy2, blk.l2.pw, '3x3', a1.shape[2:])
+        dy1 = bn_act_backward(y1, da1, ctx.st1, blk.l1.bn, ACT_GLU, need_p)
+        if need_p:
+            conv_wgrad(x, dy1, blk.l1.conv.weight, '3x3')
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_dgrad(dy1, blk.l1.pw, '3x3', x.shape[2:], addend=dout)
+        return dx, None, None, None, None, None, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """f32 dense layer y = x W^T + b (nn.Linear; model.py:278,306-313,330,354)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_gpu(x)
+        x = x.float().contiguous()
+        B, K = x.shape
+        N = weight.shape[0]
+        y = torch.empty((B, N), dtype=torch.float32, device=x.device)
+        call('sba_linear_fwd', _p(x), _p(weight), _p(bias), _p(y), B, K, N, _stream())
+        ctx.save_for_backward(x, weight)
+        ctx.bias = bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        B, K = x.shape
+        N = weight.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = param_grad(weight) if ctx.needs_input_grad[1] else None
+        db = param_grad(ctx.bias) if (ctx.bias is not None and ctx.needs_input_grad[2]) else None
+        call('sba_linear_bwd', _p(x), _p(weight), _p(dy), _p(dx), _p(dw), _p(db), B, K, N, _stream())
+        return dx, None, None
+
+
+class CAFn(torch.autograd.Function):
+    """CA_NET tail: GLU, split, reparametrise with an explicit eps (model.py:281-294)."""
+
+    @staticmethod
+    def forward(ctx, h, eps):
+        B, C4 = h.shape
+        C = C4 // 4
+        h = h.contiguous()
+        eps = eps.float().contiguous()
+        c, mu, lv = (torch.empty((B, C), dtype=torch.float32, device=h.device) for _ in range(3))
+        call('sba_ca_fwd', _p(h), _p(eps), _p(c), _p(mu), _p(lv), B, C, _stream())
+        ctx.save_for_backward(h, eps)
+        return c, mu, lv
+
+    @staticmethod
+    def backward(ctx, dc, dmu, dlv):
+        h, eps = ctx.saved_tensors
+        B, C4 = h.shape
+        dh = torch.empty_like(h)
+        dc = None if dc is None else dc.contiguous()
+        dmu = None if dmu is None else dmu.contiguous()
+        dlv = None if dlv is None else dlv.contiguous()
+        call('sba_ca_bwd', _p(h), _p(eps), _p(dc), _p(dmu), _p(dlv), _p(dh), B, C4 // 4, _stream())
+        return dh, None
+
+
+class FcBnGluFn(torch.autograd.Function):
+    """INIT_STAGE_G.fc: Linear(no bias) -> BatchNorm1d(train) -> GLU -> view(B, ngf, 4, 4)
+    (model.py:353-356,372-373); the output is written NHWC."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, mod):
+        _need_gpu(x)
+        x = x.float().contiguous()
+        B, K = x.shape
+        F = weight.shape[0]
+        y = torch.empty((B, F), dtype=torch.float32, device=x.device)
+        call('sba_linear_fwd', _p(x), _p(weight), None, _p(y), B, K, F, _stream())
+        bn = mod.bn
+        aux = torch.empty((2, F), dtype=torch.float32, device=x.device)
+        out = torch.empty((B, F // 32, 4, 4), dtype=COMPUTE_DTYPE, device=x.device, memory_format=CL)
+        if not bn.training:
+            raise RuntimeError('INIT_STAGE_G.fc BatchNorm1d eval mode: use sbagan.infer (not on the training path)')
+        call('sba_bn1d_glu_fwd', _dt(out), _p(y), _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
+             _p(bn.running_var), _p(bn.num_batches_tracked), _p(aux[0]), _p(aux[1]), _p(out), B, F, BN_EPS,
+             BN_MOMENTUM, _stream())
+        ctx.mod, ctx.aux = mod, aux
+        ctx.save_for_backward(x, y, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, weight = ctx.saved_tensors
+        bn = ctx.mod.bn
+        dout = _c(dout)
+        B, K = x.shape
+        F = weight.shape[0]
+        dy = torch.empty_like(y)
+        call('sba_bn1d_glu_bwd', _dt(dout), _p(y), _p(dout), _p(bn.weight), _p(bn.bias), _p(ctx.aux[0]),
+             _p(ctx.aux[1]), _p(dy), _p(param_grad(bn.weight)), _p(param_grad(bn.bias)), B, F, _stream())
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        call('sba_linear_bwd', _p(x), _p(weight), _p(dy), _p(dx), _p(param_grad(weight)), None, B, K, F, _stream())
+        return dx, None, None, None, None
+
+
+def _mask_u8(mask):
+    if mask is None:
+        return None
+    return mask.to(torch.uint8).contiguous()
+
+
+class AttnAdainCatFn(torch.autograd.Function):
+    """Entry of NEXT_STAGE_G (model.py:415-418): word attention (GlobalAttention.py:82-121),
+    AdaIN (model.py:332-339) and the channel concat, written straight into one NHWC
+    tensor [adain(h) | ctx].  Returns (h_c_code, att or empty)."""
+
+    @staticmethod
+    def forward(ctx, h, style, words, w_ctx, mask, want_att, mask_mode):
+        h = as_act(h)
+        N, C, H, W = h.shape
+        HW = H * W
+        words = words.float().contiguous()
+        cdf, L = words.shape[1], words.shape[2]
+        style = style.float().contiguous()
+        m8 = _mask_u8(mask)
+        dev = h.device
+        src = torch.empty((N, C, L), dtype=torch.float32, device=dev)
+        wc = w_ctx.detach().reshape(C, cdf)
+        call('sba_ctx_proj_fwd', _p(words), _p(wc), _p(src), N, C, cdf, L, _stream())
+        out = empty_act(N, 2 * C, H, W, h)
+        att = torch.empty((N, L, H, W), dtype=torch.float32, device=dev) if want_att else None
+        call('sba_word_attn_fwd', _dt(h), _p(h), _p(src), _p(m8), _p(out), _p(att), N, HW, C, L, mask_mode,
+             2 * C, C, _stream())
+        mr = torch.empty((2, N, C), dtype=torch.float32, device=dev)
+        call('sba_instnorm_stats', _dt(h), _p(h), _p(mr[0]), _p(mr[1]), N, HW, C, IN_EPS, _stream())
+        call('sba_adain_fwd', _dt(h), _p(h), _p(mr[0]), _p(mr[1]), _p(style), _p(out), N, HW, C, 2 * C, 0,
+             _stream())
+        ctx.save_for_backward(h, style, words, src, mr)
+        ctx.m8, ctx.w_ctx, ctx.mask_mode = m8, w_ctx, mask_mode
+        if att is None:
+            att = torch.empty(0, device=dev)
+        ctx.mark_non_differentiable(att)
+        return out, att
+
+    @staticmethod
+    def backward(ctx, dout, _datt):
+        h, style, words, src, mr = ctx.saved_tensors
+        dout = _c(dout)
+        N, C, H, W = h.shape
+        HW = H * W
+        cdf, L = words.shape[1], words.shape[2]
+        dev = h.device
+        dh = torch.empty_like(h)
+        dsrc = torch.zeros((N, C, L), dtype=torch.float32, device=dev)
+        call('sba_word_attn_bwd', _dt(h), _p(h), _p(src), _p(ctx.m8), _p(dout), _p(dh), _p(dsrc), N, HW, C, L,
+             ctx.mask_mode, 2 * C, C, 0, _stream())
+        red = torch.zeros((N, C, 2), dtype=torch.float32, device=dev)
+        call('sba_adain_bwd_reduce', _dt(h), _p(h), _p(dout), _p(mr[0]), _p(mr[1]), _p(red), N, HW, C, 2 * C, 0,
+             _stream())
+        dstyle = torch.empty_like(style)
+        call('sba_adain_bwd_apply', _dt(h), _p(h), _p(dout), _p(mr[0]), _p(mr[1]), _p(style), _p(red), _p(dh),
+             _p(dstyle), N, HW, C, 2 * C, 0, 1, _stream())
+        dwords = torch.empty_like(words) if ctx.needs_input_grad[2] else None
+        wc = ctx.w_ctx.detach().reshape(C, cdf)
+        if ctx.needs_input_grad[3] or dwords is not None:
+            dW = param_grad(ctx.w_ctx) if ctx.needs_input_grad[3] else torch.zeros_like(wc)
+            call('sba_ctx_proj_bwd', _p(words), _p(wc), _p(dsrc), _p(dW), _p(dwords), N, C, cdf, L, _stream())
+        return dh, dstyle, dwords, None, None, None, None
+
+
+class WordAttnFn(torch.autograd.Function):
+    """Stand-alone GlobalAttentionGeneral.forward (GlobalAttention.py:82-121)."""
+
+    @staticmethod
+    def forward(ctx, h, words, w_ctx, mask, mask_mode):
+        h = as_act(h)
+        N, C, H, W = h.shape
+        words = words.float().contiguous()
+        cdf, L = words.shape[1], words.shape[2]
+        m8 = _mask_u8(mask)
+        src = torch.empty((N, C, L), dtype=torch.float32, device=h.device)
+        wc = w_ctx.detach().reshape(C, cdf)
+        call('sba_ctx_proj_fwd', _p(words), _p(wc), _p(src), N, C, cdf, L, _stream())
+        out = empty_act(N, C, H, W, h)
+        att = torch.empty((N, L, H, W), dtype=torch.float32, device=h.device)
+        call('sba_word_attn_fwd', _dt(h), _p(h), _p(src), _p(m8), _p(out), _p(att), N, H * W, C, L, mask_mode, C, 0,
+             _stream())
+        ctx.save_for_backward(h, words, src)
+        ctx.m8, ctx.w_ctx, ctx.mask_mode = m8, w_ctx, mask_mode
+        ctx.mark_non_differentiable(att)
+        return out, att
+
+    @staticmethod
+    def backward(ctx, dout, _datt):
+        h, words, src = ctx.saved_tensors
+        dout = _c(dout)
+        N, C, H, W = h.shape
+        cdf, L = words.shape[1], words.shape[2]
+        dh = torch.empty_like(h)
+        dsrc = torch.zeros((N, C, L), dtype=torch.float32, device=h.device)
+        call('sba_word_attn_bwd', _dt(h), _p(h), _p(src), _p(ctx.m8), _p(dout), _p(dh), _p(dsrc), N, H * W, C, L,
+             ctx.mask_mode, C, 0, 0, _stream())
+        dwords = torch.empty_like(words) if ctx.needs_input_grad[1] else None
+        wc = ctx.w_ctx.detach().reshape(C, cdf)
+        dW = param_grad(ctx.w_ctx) if ctx.needs_input_grad[2] else torch.zeros_like(wc)
+        call('sba_ctx_proj_bwd', _p(words), _p(wc), _p(dsrc), _p(dW), _p(dwords), N, C, cdf, L, _stream())
+        return dh, dwords, None, None, None
+
+
+class AdainFn(torch.autograd.Function):
+    """Stand-alone ADAIN_NORM core (model.py:336-337) given style = Linear(w)."""
+
+    @staticmethod
+    def forward(ctx, h, style):
+        h = as_act(h)
+        N, C, H, W = h.shape
+        style = style.float().contiguous()
+        mr = torch.empty((2, N, C), dtype=torch.float32, device=h.device)
+        call('sba_instnorm_stats', _dt(h), _p(h), _p(mr[0]), _p(mr[1]), N, H * W, C, IN_EPS, _stream())
+        out = torch.empty_like(h)
+        call('sba_adain_fwd', _dt(h), _p(h), _p(mr[0]), _p(mr[1]), _p(style), _p(out), N, H * W, C, C, 0, _stream())
+        ctx.save_for_backward(h, style, mr)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, style, mr = ctx.saved_tensors
+        dout = _c(dout)
+        N, C, H, W = h.shape
+        red = torch.zeros((N, C, 2), dtype=torch.float32, device=h.device)
+        call('sba_adain_bwd_reduce', _dt(h), _p(h), _p(dout), _p(mr[0]), _p(mr[1]), _p(red), N, H * W, C, C, 0,
+             _stream())
+        dh = torch.empty_like(h)
+        dstyle = torch.empty_like(style)
+        call('sba_adain_bwd_apply', _dt(h), _p(h), _p(dout), _p(mr[0]), _p(mr[1]), _p(style), _p(red), _p(dh),
+             _p(dstyle), N, H * W, C, C, 0, 0, _stream())
+        return dh, dstyle
+
+
+class ImgHeadFn(torch.autograd.Function):
+    """GET_IMAGE_G: conv3x3(ngf->3) + tanh, NHWC features -> NCHW f32 image (model.py:426-437)."""
+
+    @staticmethod
+    def forward(ctx, h, weight):
+        h = as_act(h)
+        N, C, H, W = h.shape
+        if not weight.is_contiguous(memory_format=CL):
+            raise RuntimeError('img head weight must be channels_last')
+        img = torch.empty((N, 3, H, W), dtype=torch.float32, device=h.device)
+        call('sba_img_head_fwd', _dt(h), _p(h), _p(weight), _p(img), N, H, W, C, _stream())
+        ctx.save_for_backward(h, weight, img)
+        return img
+
+    @staticmethod
+    def backward(ctx, dimg):
+        h, weight, img = ctx.saved_tensors
+        dimg = dimg.float().contiguous()
+        N, C, H, W = h.shape
+        dh = torch.empty_like(h)
+        dw = param_grad(weight) if ctx.needs_input_grad[1] else torch.zeros_like(weight)
+        call('sba_img_head_bwd', _dt(h), _p(h), _p(weight), _p(img), _p(dimg), _p(dh), _p(dw), N, H, W, C, 0,
+             _stream())
+        return dh, None
+
+
+class DStemFn(torch.autograd.Function):
+    """conv4x4 s2 (3->ndf) + LeakyReLU(0.2): NCHW f32 image -> NHWC features (model.py:563-564)."""
+
+    @staticmethod
+    def forward(ctx, img, weight):
+        _need_gpu(img)
+        img = img.float().contiguous()
+        N, _, S, S2 = img.shape
+        assert S == S2
+        C = weight.shape[0]
+        out = torch.empty((N, C, S // 2, S // 2), dtype=COMPUTE_DTYPE, device=img.device, memory_format=CL)
+        call('sba_d_stem_fwd', _dt(out), _p(img), _p(weight), _p(out), N, S, C, _stream())
+        ctx.save_for_backward(img, weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        img, weight, out = ctx.saved_tensors
+        dout = _c(dout)
+        N, _, S, _ = img.shape
+        C = weight.shape[0]
+        dimg = torch.empty_like(img) if ctx.needs_input_grad[0] else None
+        dw = param_grad(weight) if ctx.needs_input_grad[1] else None
+        if dimg is not None or dw is not None:
+            call('sba_d_stem_bwd', _dt(out), _p(img), _p(weight), _p(out), _p(dout), _p(dimg), _p(dw), N, S, C,
+                 _stream())
+        return dimg, None
+
+
+class LogitsFn(torch.autograd.Function):
+    """outlogits: conv4x4 s4 (8ndf->1, bias) + sigmoid on the 4x4 map (model.py:590-592,606-607)."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias):
+        h = as_act(h)
+        B, C, H, W = h.shape
+        assert H == 4 and W == 4
+        prob = torch.empty(B, dtype=torch.float32, device=h.device)
+        call('sba_logits_fwd', _dt(h), _p(h), _p(weight), _p(bias), _p(prob), B, 16 * C, _stream())
+        ctx.save_for_backward(h, weight, prob)
+        ctx.bias = bias
+        return prob
+
+    @staticmethod
+    def backward(ctx, dprob):
+        h, weight, prob = ctx.saved_tensors
+        dprob = dprob.float().contiguous()
+        B, C = h.shape[0], h.shape[1]
+        dh = torch.empty_like(h)
+        dw = param_grad(weight) if ctx.needs_input_grad[1] else None
+        db = param_grad(ctx.bias) if ctx.needs_input_grad[2] else None
+        call('sba_logits_bwd', _dt(h), _p(h), _p(weight), _p(prob), _p(dprob), _p(dh), _p(dw), _p(db), B, 16 * C, 0,
+             _stream())
+        return dh, None, None
+
+
+class CondCatFn(torch.autograd.Function):
+    """cat(h_code, c_code tiled 4x4) along channels (model.py:597-600)."""
+
+    @staticmethod
+    def forward(ctx, h, sent):
+        h = as_act(h)
+        B, C = h.shape[0], h.shape[1]
+        sent = sent.float().contiguous()
+        E = sent.shape[1]
+        out = empty_act(B, C + E, 4, 4, h)
+        call('sba_cond_cat_fwd', _dt(h), _p(h), _p(sent), _p(out), B, C, E, _stream())
+        ctx.dims = (B, C, E)
+        ctx.like = h
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, C, E = ctx.dims
+        dout = _c(dout)
+        dh = empty_act(B, C, 4, 4, dout)
+        ds = torch.zeros((B, E), dtype=torch.float32, device=dout.device) if ctx.needs_input_grad[1] else None
+        call('sba_cond_cat_bwd', _dt(dout), _p(dout), _p(dh), _p(ds), B, C, E, 0, _stream())
+        return dh, ds
+
+
+class BCEMultiFn(torch.autograd.Function):
+    """sum_s weight_s * BCELoss(prob_s, target_s) in one launch (losses.py:144-158,175-182)."""
+
+    @staticmethod
+    def forward(ctx, targets, weights, *probs):
+        dev = probs[0].device
+        sizes = [int(p.numel()) for p in probs]
+        cat = torch.cat([p.float().reshape(-1) for p in probs])
+        offs = [0]
+        for s in sizes:
+            offs.append(offs[-1] + s)
+        key = (tuple(offs), tuple(targets), tuple(weights), dev)
+        meta = _BCE_META.get(key)
+        if meta is None:
+            meta = (torch.tensor(offs, dtype=torch.int32, device=dev),
+                    torch.tensor(targets, dtype=torch.float32, device=dev),
+                    torch.tensor(weights, dtype=torch.float32, device=dev))
+            _BCE_META[key] = meta
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dprob = torch.empty_like(cat)
+        call('sba_bce_multi', _p(cat), _p(meta[0]), _p(meta[1]), _p(meta[2]), len(sizes), _p(loss), _p(dprob),
+             _stream())
+        ctx.sizes = sizes
+        ctx.save_for_backward(dprob)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dprob,) = ctx.saved_tensors
+        d = dprob * g
+        return (None, None) + tuple(d.split(ctx.sizes))
+
+
+_BCE_META = {}
+
+
+class KLFn(torch.autograd.Function):
+    """KL_loss (losses.py:210-214)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        mu, logvar = mu.contiguous(), logvar.contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=mu.device)
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(logvar)
+        call('sba_kl_loss', _p(mu), _p(logvar), _p(loss), _p(dmu), _p(dlv), mu.numel(), _stream())
+        ctx.save_for_backward(dmu, dlv)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dmu, dlv = ctx.saved_tensors
+        return dmu * g, dlv * g
+
+
+class WordsLossFn(torch.autograd.Function):
+    """words_loss (losses.py:62-132): returns (loss0, loss1)."""
+
+    @staticmethod
+    def forward(ctx, feat, words, cap_lens, mask, gammas):
+        _need_gpu(feat)
+        g1, g2, g3 = gammas
+        B, nef = feat.shape[0], feat.shape[1]
+        R = feat.shape[2] * feat.shape[3]
+        feat = feat.float().contiguous()
+        words = words.float().contiguous()
+        L = words.shape[2]
+        dev = feat.device
+        cap_lens = cap_lens.to(device=dev, dtype=torch.int64).contiguous()
+        sim = torch.empty((B, B), dtype=torch.float32, device=dev)
+        attn = torch.empty((B * B, L, R), dtype=torch.float32, device=dev)
+        attn1 = torch.empty((B * B, L, R), dtype=torch.float32, device=dev)
+        wctx = torch.empty((B * B, L, nef), dtype=torch.float32, device=dev)
+        call('sba_damsm_words_fwd', _p(feat), _p(words), _p(cap_lens), _p(sim), _p(attn), _p(attn1), _p(wctx), B,
+             nef, R, L, g1, g2, _stream())
+        loss = torch.empty(2, dtype=torch.float32, device=dev)
+        d0, d1 = torch.empty_like(sim), torch.empty_like(sim)
+        call('sba_ce_pair', _p(sim), _p(mask), g3, _p(loss), _p(d0), _p(d1), B, _stream())
+        ctx.save_for_backward(feat, words, cap_lens, sim, attn, attn1, wctx, d0, d1)
+        ctx.g = (g1, g2)
+        ctx.fshape = None
+        return loss[0], loss[1]
+
+    @staticmethod
+    def backward(ctx, gl0, gl1):
+        feat, words, cap_lens, sim, attn, attn1, wctx, d0, d1 = ctx.saved_tensors
+        B, nef, R = feat.shape
+        L = words.shape[2]
+        dev = feat.device
+        z = torch.zeros(1, dtype=torch.float32, device=dev)
+        gl0 = z if gl0 is None else gl0.reshape(1).float()
+        gl1 = z if gl1 is None else gl1.reshape(1).float()
+        dsim = torch.empty_like(sim)
+        call('sba_combine2', _p(dsim), _p(d0), _p(gl0), _p(d1), _p(gl1), B * B, _stream())
+        dfeat = torch.zeros_like(feat)
+        dwords = torch.zeros_like(words) if ctx.needs_input_grad[1] else None
+        call('sba_damsm_words_bwd', _p(feat), _p(words), _p(cap_lens), _p(sim), _p(attn), _p(attn1), _p(wctx),
+             _p(dsim), _p(dfeat), _p(dwords), B, nef, R, L, ctx.g[0], ctx.g[1], _stream())
+        return dfeat, dwords, None, None, None
+
+
+class SentLossFn(torch.autograd.Function):
+    """sent_loss (losses.py:20-59): returns (loss0, loss1)."""
+
+    @staticmethod
+    def forward(ctx, cnn, rnn, mask, gamma3, eps):
+        _need_gpu(cnn)
+        cnn, rnn = cnn.float().contiguous(), rnn.float().contiguous()
+        B, nef = cnn.shape
+        dev = cnn.device
+        s = torch.empty((B, B), dtype=torch.float32, device=dev)
+        call('sba_damsm_sent_fwd', _p(cnn), _p(rnn), _p(s), B, nef, gamma3, eps, _stream())
+        loss = torch.empty(2, dtype=torch.float32, device=dev)
+        d0, d1 = torch.empty_like(s), torch.empty_like(s)
+        call('sba_ce_pair', _p(s), _p(mask), 1.0, _p(loss), _p(d0), _p(d1), B, _stream())
+        ctx.save_for_backward(cnn, rnn, d0, d1)
+        ctx.k = (gamma3, eps)
+        return loss[0], loss[1]
+
+    @staticmethod
+    def backward(ctx, gl0, gl1):
+        cnn, rnn, d0, d1 = ctx.saved_tensors
+        B, nef = cnn.shape
+        dev = cnn.device
+        z = torch.zeros(1, dtype=torch.float32, device=dev)
+        gl0 = z if gl0 is None else gl0.reshape(1).float()
+        gl1 = z if gl1 is None else gl1.reshape(1).float()
+        ds = torch.empty_like(d0)
+        call('sba_combine2', _p(ds), _p(d0), _p(gl0), _p(d1), _p(gl1), B * B, _stream())
+        dcnn = torch.zeros_like(cnn) if ctx.needs_input_grad[0] else None
+        drnn = torch.zeros_like(rnn) if ctx.needs_input_grad[1] else None
+        call('sba_damsm_sent_bwd', _p(cnn), _p(rnn), _p(ds), _p(dcnn), _p(drnn), B, nef, ctx.k[0], ctx.k[1],
+             _stream())
+        return dcnn, drnn, None, None, None

@@ -1,0 +1,184 @@
+"""The adversarial training step of condGANTrainer.train (AttnGAN2/code/trainer.py:238-299)
+re-driven over the HIP modules: same call order, Adam / EMA semantics and label tensors,
+with the host-side inefficiencies of the reference removed (no .item() syncs, one fused
+Adam+EMA launch per network instead of per-tensor loops, flat gradient buffers that are
+zeroed with one memset and all-reduced with one RCCL call per network).
+
+Ordering facts preserved: (a) G forward once, D steps use fake.detach();
+(b) each D optimizer steps BEFORE generator_loss, so the G loss sees the updated D nets and
+their BN running stats move once more in that forward; (c) RNG draw order: noise, then
+CA_NET eps.  The discriminator weight-gradients the reference computes in the G step and
+then discards (trainer.py:270,287) are not computed: D parameters are frozen for that
+backward, which changes no result.
+"""
+import torch
+import torch.distributed as dist
+
+from miscc.config import cfg
+from miscc.losses import KL_loss, discriminator_loss, generator_loss
+
+from . import ops
+from ._lib import call
+
+
+class FlatParams(object):
+    """Re-homes every parameter of `net` into one contiguous f32 buffer (each keeps its own
+    strides, e.g. channels_last conv weights) with matching flat buffers for gradients and
+    Adam moments.  p.grad are persistent views, so kernels accumulate straight into the
+    buffer that is all-reduced and consumed by the fused Adam."""
+
+    def __init__(self, net, with_ema=False):
+        params = [p for p in net.parameters()]
+        self.params = params
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4          # 16-byte aligned starts
+        dev = params[0].device
+        self.n = n
+        self.data = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, o in zip(params, offs):
+            k = p.numel()
+            view = self.data[o:o + k].as_strided(p.shape, p.stride())
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.grad[o:o + k].as_strided(p.shape, p.stride())
+        self.offsets = offs
+        self.avg = self.data.clone() if with_ema else None
+        ops.weights_changed()
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def ema_params(self):
+        """EMA shadow as a list of tensors shaped like the parameters (copy_G_params order)."""
+        return [self.avg[o:o + p.numel()].as_strided(p.shape, p.stride())
+                for p, o in zip(self.params, self.offsets)]
+
+
+class FusedAdam(object):
+    """torch.optim.Adam(lr, betas=(0.5, 0.999)) of trainer.py:136-143 as one launch over a
+    FlatParams buffer (+ the EMA of trainer.py:298-299 when the buffer has a shadow).  The
+    step counter and bias corrections live on the device (graph replayable)."""
+
+    def __init__(self, flat, lr, betas=(0.5, 0.999), eps=1e-8):
+        self.flat, self.lr, self.betas, self.eps = flat, float(lr), betas, eps
+        self.state = torch.zeros(4, dtype=torch.int32, device=flat.data.device)
+
+    def step(self, grad_scale=1.0):
+        f = self.flat
+        st = torch.cuda.current_stream().cuda_stream
+        call('sba_adam_prepare', self.state.data_ptr(), self.lr, self.betas[0], self.betas[1], st)
+        call('sba_adam_step', f.data.data_ptr(), f.grad.data_ptr(), f.m.data_ptr(), f.v.data_ptr(),
+             None if f.avg is None else f.avg.data_ptr(), None, self.state.data_ptr(), f.n,
+             self.betas[0], self.betas[1], self.eps, float(grad_scale), st)
+        ops.weights_changed()
+
+
+def prepare_labels(batch_size, device):
+    """trainer.py:147-157."""
+    real = torch.ones(batch_size, dtype=torch.float32, device=device)
+    fake = torch.zeros(batch_size, dtype=torch.float32, device=device)
+    match = torch.arange(batch_size, dtype=torch.int64, device=device)
+    return real, fake, match
+
+
+def build_mask(captions, num_words):
+    """trainer.py:253-256: mask = (captions == 0)[:, :Lmax]  (integer work, bit-exact)."""
+    mask = (captions == 0)
+    if mask.size(1) > num_words:
+        mask = mask[:, :num_words]
+    return mask
+
+
+def sort_by_caption_length(captions_lens):
+    """datasets.py:32-33: descending sort of the caption lengths, returns (lens, permutation)."""
+    return torch.sort(captions_lens, 0, True)
+
+
+class GANStep(object):
+    """One G+D update.  `netsD` is a list (D_NET64[, D_NET128[, D_NET256]]); `image_encoder` maps
+    the last fake image to (region features B x nef x 17 x 17, global code B x nef)."""
+
+    def __init__(self, netG, netsD, image_encoder, batch_size, lr_g=None, lr_d=None, distributed=False):
+        self.netG, self.netsD, self.image_encoder = netG, netsD, image_encoder
+        dev = next(netG.parameters()).device
+        self.device = dev
+        self.batch_size = batch_size
+        self.flatG = FlatParams(netG, with_ema=True)
+        self.flatD = [FlatParams(d) for d in netsD]
+        self.optG = FusedAdam(self.flatG, cfg.TRAIN.GENERATOR_LR if lr_g is None else lr_g)
+        self.optD = [FusedAdam(f, cfg.TRAIN.DISCRIMINATOR_LR if lr_d is None else lr_d) for f in self.flatD]
+        self.real_labels, self.fake_labels, self.match_labels = prepare_labels(batch_size, dev)
+        self.distributed = distributed and dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.distributed else 1
+        self.comm_stream = torch.cuda.Stream(device=dev) if (self.distributed and dev.type == 'cuda') else None
+        self._d_params = [p for d in netsD for p in d.parameters()]
+
+    # -- data-parallel gradient exchange: one all-reduce per network on a side stream so that it
+    #    overlaps the next network's forward/backward
+    def _allreduce_start(self, flat):
+        if not self.distributed:
+            return None
+        if self.comm_stream is None:
+            return dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, async_op=True)
+        self.comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm_stream):
+            dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM)
+        return self.comm_stream
+
+    def _allreduce_wait(self, h):
+        if h is None:
+            return
+        if isinstance(h, torch.cuda.Stream):
+            torch.cuda.current_stream().wait_stream(h)
+        else:
+            h.wait()
+
+    def step(self, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, eps=None):
+        """Returns a dict of DEVICE scalars (errD0.., errG_total, kl_loss, g_loss*, w_loss, s_loss)."""
+        netG, netsD = self.netG, self.netsD
+        out = {}
+        netG.ca_net.eps = eps
+        fake_imgs, _, mu, logvar = netG(noise, sent_emb, words_embs, mask)
+
+        pending = []
+        for i, netD in enumerate(netsD):
+            self.flatD[i].zero_grad()
+            errD = discriminator_loss(netD, imgs[i], fake_imgs[i], sent_emb, self.real_labels, self.fake_labels)
+            errD.backward()
+            out['errD%d' % i] = errD.detach()
+            h = self._allreduce_start(self.flatD[i])
+            if i > 0:       # finish the previous network while this one's gradients travel
+                self._finish_d(i - 1, pending.pop())
+            pending.append(h)
+        self._finish_d(len(netsD) - 1, pending.pop())
+
+        for p in self._d_params:
+            p.requires_grad_(False)
+        self.flatG.zero_grad()
+        errG_total, logs = generator_loss(netsD, self.image_encoder, fake_imgs, self.real_labels, words_embs,
+                                          sent_emb, self.match_labels, cap_lens, class_ids)
+        kl = KL_loss(mu, logvar)
+        errG_total = errG_total + kl
+        errG_total.backward()
+        for p in self._d_params:
+            p.requires_grad_(True)
+        h = self._allreduce_start(self.flatG)
+        self._allreduce_wait(h)
+        self.optG.step(1.0 / self.world)
+        out['errG_total'] = errG_total.detach()
+        out['kl_loss'] = kl.detach()
+        out.update(logs)
+        self.fake_imgs = [f.detach() for f in fake_imgs]
+        return out
+
+    def _finish_d(self, i, handle):
+        self._allreduce_wait(handle)
+        self.optD[i].step(1.0 / self.world)
+
+    def grad_norm(self, flat):
+        return flat.grad.double().norm()

@@ -1,0 +1,424 @@
+"""GPU parity tests, kernel level: every C-ABI entry point (through sbagan.ops / the module
+classes) against the CPU oracle or a plain torch fp32 CPU reference of the same op.
+
+Tolerances (stated per dtype):
+  float32 path (exact f32 MFMA): elementwise rtol 2e-4 / atol 2e-5 unless noted;
+  bfloat16 path (bf16 storage + MFMA, f32 accumulate): relative L2 error <= 2e-2 per tensor
+  (bf16 has an 8-bit mantissa; elementwise bounds are not meaningful).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from helpers import rel_l2  # noqa: E402
+from oracle import fill  # noqa: E402
+from oracle import sbagan_oracle as O  # noqa: E402
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope='module')
+def dev():
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(autouse=True)
+def _reset_cfg():
+    from miscc.config import cfg, reset_cfg
+    reset_cfg()
+    cfg.GAN.GF_DIM, cfg.GAN.DF_DIM = 32, 64
+    cfg.TRAIN.SMOOTH.GAMMA1, cfg.TRAIN.SMOOTH.GAMMA2, cfg.TRAIN.SMOOTH.GAMMA3 = 4.0, 5.0, 10.0
+    cfg.TRAIN.SMOOTH.LAMBDA = 5.0
+    yield
+
+
+def tol(dt):
+    return dict(l2=3e-5, rtol=2e-4, atol=2e-5) if dt == torch.float32 else dict(l2=2e-2, rtol=None, atol=None)
+
+
+def close(got, ref, dt, name='', scale=1.0):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    t = tol(dt)
+    r = rel_l2(got, ref)
+    assert r <= t['l2'] * scale, '%s: rel L2 %.3e > %.1e' % (name, r, t['l2'] * scale)
+    if t['rtol'] is not None:
+        err = (got - ref).abs()
+        bound = scale * (t['atol'] + t['rtol'] * ref.abs()) + 1e-6 * float(ref.abs().max())
+        assert bool((err <= bound).all()), '%s: max err %.3e' % (name, float(err.max()))
+
+
+def act(x, dt, dev):
+    return x.to(dev).to(dt).contiguous(memory_format=torch.channels_last)
+
+
+def rounded(x, dt):
+    """what the kernel actually sees of an input tensor"""
+    return x.to(dt).float()
+
+
+# ------------------------------------------------------------------ raw convolutions
+CONV_CASES = [
+    # kind, N, Cin, Cout, H, W
+    ('3x3', 2, 64, 64, 16, 16),
+    ('3x3', 3, 32, 128, 7, 5),        # ragged M (105 rows), odd sizes
+    ('3x3', 1, 64, 192, 4, 4),        # Cout not a multiple of 128
+    ('3x3up', 2, 64, 64, 8, 8),
+    ('3x3up', 1, 128, 256, 4, 4),
+    ('3x3up', 3, 32, 64, 5, 3),
+    ('4x4s2', 2, 64, 128, 16, 16),
+    ('4x4s2', 3, 128, 64, 8, 8),
+    ('3x3', 1, 64, 64, 96, 96),       # M = 9216 -> 256-row tiles
+    ('3x3', 1, 64, 128, 72, 64),      # M = 4608 -> 128x128 tiles
+]
+
+
+def torch_conv(x, w, kind):
+    if kind == '3x3':
+        return F.conv2d(x, w, None, 1, 1)
+    if kind == '3x3up':
+        return F.conv2d(x.repeat_interleave(2, 2).repeat_interleave(2, 3), w, None, 1, 1)
+    return F.conv2d(x, w, None, 2, 1)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(dev, dt, case):
+    from sbagan import ops
+    kind, N, Cin, Cout, H, W = case
+    k = 4 if kind == '4x4s2' else 3
+    x = fill.unit((N, Cin, H, W), 1)
+    w = fill.unit((Cout, Cin, k, k), 2) / np.sqrt(Cin * k * k)
+    xr, wr = rounded(x, dt).requires_grad_(True), rounded(w, dt).requires_grad_(True)
+    yref = torch_conv(xr, wr, kind)
+    dy = fill.unit(tuple(yref.shape), 3)
+    dyr = rounded(dy, dt)
+    gx, gw = torch.autograd.grad(yref, [xr, wr], dyr)
+
+    wp = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
+    pw = ops.PackedWeight(wp)
+    xa = act(x, dt, dev)
+    y, stats = ops.conv_forward(xa, pw, kind)
+    torch.cuda.synchronize()
+    close(y, yref, dt, 'y')
+    # BN statistics of the f32 accumulators
+    close(stats[:Cout], yref.sum((0, 2, 3)), torch.float32, 'sum', scale=30 if dt == torch.float32 else 2000)
+    close(stats[Cout:], (yref ** 2).sum((0, 2, 3)), torch.float32, 'sumsq', scale=30 if dt == torch.float32 else 2000)
+    dya = act(dy, dt, dev)
+    dx = ops.conv_dgrad(dya, pw, kind, (H, W))
+    close(dx, gx, dt, 'dx')
+    ops.conv_wgrad(xa, dya, wp, kind)
+    ops.conv_wgrad(xa, dya, wp, kind)        # accumulates: twice -> 2x
+    torch.cuda.synchronize()
+    close(wp.grad * 0.5, gw, dt, 'dw')
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_conv_addend_epilogue(dev, dt):
+    from sbagan import ops
+    x, w = fill.unit((2, 64, 8, 8), 1), fill.unit((64, 64, 3, 3), 2) / 24
+    add = fill.unit((2, 64, 8, 8), 3)
+    wp = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
+    dx = ops.conv_dgrad(act(x, dt, dev), ops.PackedWeight(wp), '3x3', (8, 8), addend=act(add, dt, dev))
+    ref = F.conv_transpose2d(rounded(x, dt), rounded(w, dt), None, 1, 1) + rounded(add, dt)
+    close(dx, ref, dt, 'dgrad+addend')
+
+
+# ------------------------------------------------------------------ fused blocks vs the oracle
+def _load(mod, P, dev):
+    mod.load_state_dict(P)
+    return mod.to(dev).train()
+
+
+def _grads_of(mod):
+    return {n: p.grad for n, p in mod.named_parameters()}
+
+
+def _oracle_P(P, prefix=''):
+    Q = {}
+    for k, v in P.items():
+        Q[prefix + k] = v.clone().requires_grad_(True) if k.endswith(('.weight', '.bias')) else v.clone()
+    return Q
+
+
+def _check_module(mod, Q, dt, prefix, buffers=True, gscale=1.0):
+    for n, p in mod.named_parameters():
+        ref = Q[prefix + n].grad
+        if ref is None:
+            continue
+        close(p.grad, ref, dt, 'grad ' + n, scale=gscale)
+    if buffers:
+        for n, b in mod.named_buffers():
+            if n.endswith(('running_mean', 'running_var')):
+                close(b, Q[prefix + n], dt if dt == torch.float32 else torch.bfloat16, 'buffer ' + n)
+            elif n.endswith('num_batches_tracked'):
+                assert int(b) == int(Q[prefix + n]), n
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('which', ['up', 'leak', 'down', 'res'])
+def test_conv_bn_act_blocks(dev, dt, which):
+    from sbagan import nets, ops
+    ops.set_compute_dtype(dt)
+    N, C, H = 3, 64, 8
+    if which == 'up':
+        mod, fn = nets.upBlock(C, C // 2), lambda x, Q: O.up_block(x, Q, 'm')
+    elif which == 'leak':
+        mod, fn = nets.Block3x3_leakRelu(C, 128), lambda x, Q: O._block3x3_leak(x, Q, 'm', True)
+    elif which == 'down':
+        mod, fn = nets.downBlock(C, 128), lambda x, Q: O._down(x, Q, 'm', 0, 1, True)
+    else:
+        mod, fn = nets.ResBlock(C), lambda x, Q: O.res_block(x, Q, 'm')
+    P = fill.fill_state_dict({k: tuple(v.shape) for k, v in mod.state_dict().items()})
+    _load(mod, P, dev)
+    x = fill.unit((N, C, H, H), 5)
+    xr = rounded(x, dt).requires_grad_(True)
+    Q = _oracle_P(P, 'm.')
+    yref = fn(xr, Q)
+    dy = fill.unit(tuple(yref.shape), 6)
+    yref.backward(rounded(dy, dt))
+    xa = act(x, dt, dev).requires_grad_(True)
+    y = mod(xa)
+    y.backward(act(dy, dt, dev))
+    torch.cuda.synchronize()
+    assert y.dtype == dt and y.is_contiguous(memory_format=torch.channels_last)
+    close(y, yref, dt, 'out', scale=3)
+    close(xa.grad, xr.grad, dt, 'dx', scale=3)
+    _check_module(mod, Q, dt, 'm.', gscale=3)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('mask_mode', [0, 1])
+def test_word_attention(dev, dt, mask_mode):
+    from sbagan import nets, ops
+    ops.set_compute_dtype(dt)
+    B, idf, cdf, L, H = 3, 32, 256, 7, 12
+    att = nets.GlobalAttentionGeneral(idf, cdf)
+    P = fill.fill_state_dict({'conv_context.weight': (idf, cdf, 1, 1)})
+    _load(att, P, dev)
+    att.reference_mask_order = (mask_mode == 0)
+    h, words = fill.unit((B, idf, H, H), 1), fill.unit((B, cdf, L), 2)
+    caps, _ = fill.synthetic_captions(B, L, L, tag=3)
+    mask = (caps == 0)[:, :L]
+    mask[1, 3:] = True
+    hr = rounded(h, dt).requires_grad_(True)
+    wq = P['conv_context.weight'].clone().requires_grad_(True)
+    if mask_mode == 0:
+        cref, aref = O.word_attention(hr, words, wq, mask)
+    else:   # per-sample mask: plain masked attention
+        src = torch.einsum('ic,bcl->bil', wq.view(idf, -1), words)
+        s = torch.bmm(hr.reshape(B, idf, -1).transpose(1, 2), src).masked_fill(mask[:, None, :], -float('inf'))
+        a = torch.softmax(s, 2).transpose(1, 2)
+        cref, aref = torch.bmm(src, a).reshape(B, idf, H, H), a.reshape(B, L, H, H)
+    dctx = fill.unit(tuple(cref.shape), 4)
+    cref.backward(rounded(dctx, dt))
+    ha = act(h, dt, dev).requires_grad_(True)
+    att.applyMask(mask.to(dev))
+    ctx, a = att(ha, words.to(dev))
+    ctx.backward(act(dctx, dt, dev))
+    torch.cuda.synchronize()
+    # bool part of the quirk: exactly the reference's entries are masked out
+    assert torch.equal((a.cpu() == 0), (aref.detach() == 0))
+    close(ctx, cref, dt, 'ctx'); close(a, aref, dt, 'att', scale=2)
+    close(ha.grad, hr.grad, dt, 'dh', scale=2)
+    close(att.conv_context.weight.grad, wq.grad, dt, 'dW', scale=3)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_adain_and_stage_entry(dev, dt):
+    from sbagan import nets, ops
+    from miscc.config import cfg
+    ops.set_compute_dtype(dt)
+    B, ngf, nef, L, H = 2, 32, 256, 6, 16
+    st = nets.NEXT_STAGE_G(ngf, nef, 100)
+    P = fill.fill_state_dict({k: tuple(v.shape) for k, v in st.state_dict().items()})
+    _load(st, P, dev)
+    h, w_code, words = fill.unit((B, ngf, H, H), 1), fill.unit((B, 256), 2), fill.unit((B, nef, L), 3)
+    caps, _ = fill.synthetic_captions(B, L, L, tag=4)
+    mask = (caps == 0)[:, :L]
+    Q = _oracle_P(P, 'h_net2.')
+    hr = rounded(h, dt).requires_grad_(True)
+    wr = w_code.clone().requires_grad_(True)
+    yref, aref = O.next_stage_g(hr, wr, words, mask, Q, 'h_net2')
+    dy = fill.unit(tuple(yref.shape), 5)
+    yref.backward(rounded(dy, dt))
+    ha = act(h, dt, dev).requires_grad_(True)
+    wa = w_code.to(dev).requires_grad_(True)
+    y, a = st(ha, None, wa, words.to(dev), mask.to(dev))
+    y.backward(act(dy, dt, dev))
+    torch.cuda.synchronize()
+    close(y, yref, dt, 'stage out', scale=4); close(a, aref, dt, 'att', scale=2)
+    close(ha.grad, hr.grad, dt, 'dh', scale=5)
+    close(wa.grad, wr.grad, dt, 'dw_code', scale=5)
+    _check_module(st, Q, dt, 'h_net2.', gscale=5)
+    # stand-alone ADAIN_NORM
+    ad = st.adain
+    ad.zero_grad()
+    ha2 = act(h, dt, dev).requires_grad_(True)
+    o = ad(ha2, w_code.to(dev))
+    ref = O.adain_norm(rounded(h, dt), w_code, {k: v.detach() for k, v in Q.items()}, 'h_net2.adain')
+    close(o, ref, dt, 'adain')
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_image_head_and_d_stem_and_logits(dev, dt):
+    from sbagan import nets, ops
+    ops.set_compute_dtype(dt)
+    B, ngf, H = 2, 32, 20
+    head = nets.GET_IMAGE_G(ngf)
+    P = fill.fill_state_dict({'img.0.weight': (3, ngf, 3, 3)})
+    _load(head, P, dev)
+    h = fill.unit((B, ngf, H, H + 3), 1)
+    hr = rounded(h, dt).requires_grad_(True)
+    wq = P['img.0.weight'].clone().requires_grad_(True)
+    ref = O.get_image_g(hr, {'m.img.0.weight': wq}, 'm')
+    dimg = fill.unit(tuple(ref.shape), 2)
+    ref.backward(dimg)
+    ha = act(h, dt, dev).requires_grad_(True)
+    img = head(ha)
+    img.backward(dimg.to(dev))
+    torch.cuda.synchronize()
+    assert img.dtype == torch.float32 and img.is_contiguous()
+    close(img, ref, dt, 'img'); close(ha.grad, hr.grad, dt, 'dh'); close(head.img[0].weight.grad, wq.grad, dt, 'dw', scale=2)
+
+    # discriminator stem + full D_NET64 trunk + heads
+    from miscc.config import cfg
+    cfg.GAN.DF_DIM = 64
+    d = nets.D_NET64()
+    PD = fill.fill_state_dict({k: tuple(v.shape) for k, v in d.state_dict().items()})
+    _load(d, PD, dev)
+    x = fill.uniform((3, 3, 64, 64), 3)
+    sent = fill.unit((3, 256), 4)
+    Q = _oracle_P(PD)
+    xr = x.clone().requires_grad_(True)
+    fr = O.d_net(Q, xr)
+    pr_c = O.d_get_logits(Q, 'COND_DNET', fr, sent)
+    pr_u = O.d_get_logits(Q, 'UNCOND_DNET', fr)
+    gl = fill.unit((3,), 5)
+    ((pr_c * gl).sum() + (pr_u * gl * 0.5).sum()).backward()
+    xa = x.to(dev).requires_grad_(True)
+    f = d(xa)
+    pc = d.COND_DNET(f, sent.to(dev))
+    pu = d.UNCOND_DNET(f)
+    ((pc * gl.to(dev)).sum() + (pu * gl.to(dev) * 0.5).sum()).backward()
+    torch.cuda.synchronize()
+    close(f, fr, dt, 'D feat', scale=3); close(pc, pr_c, dt, 'cond prob', scale=3); close(pu, pr_u, dt, 'uncond prob', scale=3)
+    close(xa.grad, xr.grad, dt, 'dimg', scale=5)
+    _check_module(d, Q, dt, '', gscale=5)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_init_stage_and_conditioning(dev, dt):
+    from sbagan import nets, ops
+    from miscc.config import cfg
+    ops.set_compute_dtype(dt)
+    cfg.TREE.BRANCH_NUM = 1
+    g = nets.G_NET()
+    P = fill.fill_state_dict({k: tuple(v.shape) for k, v in g.state_dict().items()})
+    _load(g, P, dev)
+    B = 4
+    z, sent, eps = fill.unit((B, 100), 1), fill.unit((B, 256), 2), fill.unit((B, 100), 3)
+    Q = _oracle_P(P)
+    imgs_r, _, mu_r, lv_r = O.g_net(Q, z, sent, None, None, eps, 1)
+    dimg = fill.unit(tuple(imgs_r[0].shape), 4)
+    ((imgs_r[0] * dimg).sum() + O.kl_loss(mu_r, lv_r)).backward()
+    from miscc.losses import KL_loss
+    g.ca_net.eps = eps.to(dev)
+    imgs, atts, mu, lv = g(z.to(dev), sent.to(dev), None, None)
+    ((imgs[0] * dimg.to(dev)).sum() + KL_loss(mu, lv)).backward()
+    torch.cuda.synchronize()
+    close(imgs[0], imgs_r[0], dt, 'img64', scale=4)
+    close(mu, mu_r, torch.float32, 'mu'); close(lv, lv_r, torch.float32, 'logvar')
+    _check_module(g, Q, dt, '', gscale=6)
+
+
+def test_damsm_losses(dev):
+    from miscc import losses
+    from miscc.config import cfg
+    B, nef, L = 5, 256, 9
+    feat = fill.unit((B, nef, 17, 17), 1)
+    words = fill.unit((B, nef, L), 2)
+    code, sent = fill.unit((B, nef), 3), fill.unit((B, nef), 4)
+    lens = torch.tensor([9, 7, 7, 5, 2])
+    labels = torch.arange(B)
+    for cids in (np.arange(B), np.array([0, 1, 0, 2, 1])):
+        fr, wr = feat.clone().requires_grad_(True), words.clone().requires_grad_(True)
+        w0, w1 = O.words_loss(fr, wr, labels, lens, cids, B, 4.0, 5.0, 10.0)
+        (w0 * 1.5 + w1 * 0.7).backward()
+        fa, wa = feat.to(dev).requires_grad_(True), words.to(dev).requires_grad_(True)
+        g0, g1, _ = losses.words_loss(fa, wa, labels.to(dev), lens.to(dev), cids, B)
+        (g0 * 1.5 + g1 * 0.7).backward()
+        torch.cuda.synchronize()
+        assert abs(float(g0) - float(w0)) < 2e-4 * max(1, abs(float(w0)))
+        assert abs(float(g1) - float(w1)) < 2e-4 * max(1, abs(float(w1)))
+        close(fa.grad, fr.grad, torch.float32, 'dfeat', scale=20)
+        close(wa.grad, wr.grad, torch.float32, 'dwords', scale=20)
+        cr, sr = code.clone().requires_grad_(True), sent.clone().requires_grad_(True)
+        s0, s1 = O.sent_loss(cr, sr, labels, cids, B, 10.0)
+        (s0 + 2 * s1).backward()
+        ca, sa = code.to(dev).requires_grad_(True), sent.to(dev).requires_grad_(True)
+        t0, t1 = losses.sent_loss(ca, sa, labels.to(dev), cids, B)
+        (t0 + 2 * t1).backward()
+        assert abs(float(t0) - float(s0)) < 1e-4 * max(1, abs(float(s0)))
+        assert abs(float(t1) - float(s1)) < 1e-4 * max(1, abs(float(s1)))
+        close(ca.grad, cr.grad, torch.float32, 'dcnn', scale=10); close(sa.grad, sr.grad, torch.float32, 'drnn', scale=10)
+
+
+def test_bce_kl_adam(dev):
+    from sbagan import ops
+    from sbagan.trainer import FlatParams, FusedAdam
+    p = [torch.tensor([0.3, 0.9, 1e-9, 1.0]), torch.tensor([0.2, 0.5, 0.0])]
+    pr = [t.clone().requires_grad_(True) for t in p]
+    ref = 0.5 * O.bce(pr[0], torch.ones(4)) + (1 / 3) * O.bce(pr[1], torch.zeros(3))
+    ref.backward()
+    pa = [t.to(dev).requires_grad_(True) for t in p]
+    out = ops.BCEMultiFn.apply((1., 0.), (.5, 1. / 3), *pa)
+    (out * 2.0).backward()
+    assert abs(float(out) - float(ref)) < 1e-5 * abs(float(ref))
+    for a, b in zip(pa, pr):
+        close(a.grad * 0.5, b.grad, torch.float32, 'dprob')
+    # Adam + EMA vs the oracle's restatement of torch.optim.Adam, three steps
+    net = torch.nn.Linear(37, 11).to(dev)
+    w0, b0 = net.weight.detach().cpu().clone(), net.bias.detach().cpu().clone()
+    flat = FlatParams(net, with_ema=True)
+    opt = FusedAdam(flat, 2e-4)
+    ps = [w0.clone(), b0.clone()]
+    ms, vs = [torch.zeros_like(t) for t in ps], [torch.zeros_like(t) for t in ps]
+    avg = [t.clone() for t in ps]
+    for step in range(1, 4):
+        gs = [fill.unit(tuple(t.shape), 10 * step + i) * (1e-3 if i else 1.0) for i, t in enumerate(ps)]
+        flat.zero_grad()
+        net.weight.grad += gs[0].to(dev)
+        net.bias.grad += gs[1].to(dev)
+        opt.step()
+        for t, g, m, v, a in zip(ps, gs, ms, vs, avg):
+            O.adam_update(t, g, m, v, step, 2e-4)
+            O.ema_update(a, t)
+    torch.cuda.synchronize()
+    close(net.weight, ps[0], torch.float32, 'adam w'); close(net.bias, ps[1], torch.float32, 'adam b')
+    ema = flat.ema_params()
+    close(ema[0], avg[0], torch.float32, 'ema w'); close(ema[1], avg[1], torch.float32, 'ema b')
+
+
+def test_mask_and_sort_bit_exact(dev):
+    from sbagan.trainer import build_mask, sort_by_caption_length
+    caps, lens = fill.synthetic_captions(6, 20, 18, tag=9)
+    perm = torch.randperm(6)
+    l2, idx = sort_by_caption_length(lens[perm].to(dev))
+    r2, ridx = O.sort_by_caption_length(lens[perm])
+    assert torch.equal(l2.cpu(), r2)
+    m = build_mask(caps.to(dev), 18)
+    assert torch.equal(m.cpu(), O.build_mask(caps, 18)) and m.dtype == torch.bool
+
+
+def test_errors_are_loud(dev):
+    from sbagan import ops, _lib
+    x = torch.zeros((1, 24, 4, 4), device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter(torch.zeros((8, 24, 3, 3), device=dev).contiguous(memory_format=torch.channels_last))
+    with pytest.raises(RuntimeError):      # Cin = 24 is not a multiple of the K slab
+        ops.conv_forward(x, ops.PackedWeight(w), '3x3')
+    with pytest.raises(RuntimeError):      # CPU tensors never silently fall back
+        ops.LinearFn.apply(torch.zeros(2, 3), torch.zeros(4, 3), None)

@@ -1,0 +1,231 @@
+"""GPU parity tests, network and step level: the module classes and the full G+D training step
+against the CPU oracle and against the golden vectors produced by the reference itself
+(tests/golden/step_full_model_b4.npz: bird_style.yml dims, 3 stages, B=4, two steps).
+
+Stated tolerances:
+  float32 path: losses / grad norms rtol 1e-3 at step 0 (north-star: "G/D losses matching the
+    reference to 1e-3 rel"), 1e-2 after an Adam update (see tests/test_oracle_golden.py on why
+    Adam's sign-like first steps amplify rounding); images elementwise 2e-3.
+  bfloat16 path: losses rtol 3e-2 at step 0, images / gradients relative L2 <= 6e-2.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import (FULL, SMOOTH, check, check_param, d_shapes, g_shapes, load_golden, make_inputs,  # noqa: E402
+                     rel_l2)
+from oracle import fill  # noqa: E402
+from oracle import sbagan_oracle as O  # noqa: E402
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope='module')
+def dev():
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(autouse=True)
+def _cfg():
+    from miscc.config import cfg, reset_cfg
+    reset_cfg()
+    cfg.GAN.GF_DIM, cfg.GAN.DF_DIM, cfg.TREE.BRANCH_NUM = 32, 64, 3
+    s = cfg.TRAIN.SMOOTH
+    s.GAMMA1, s.GAMMA2, s.GAMMA3, s.LAMBDA = 4.0, 5.0, 10.0, 5.0
+    yield
+
+
+def _l2tol(dt, k=1.0):
+    return (2e-4 if dt == torch.float32 else 6e-2) * k
+
+
+def _with_grad(P):
+    return {k: (v.clone().requires_grad_(True) if k.endswith(('.weight', '.bias')) else v.clone())
+            for k, v in P.items()}
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('variant', ['model', 'bert', 'mix'])
+def test_generator_forward_backward(dev, dt, variant):
+    import model
+    import model_bert
+    from sbagan import ops
+    ops.set_compute_dtype(dt)
+    B = 2
+    x = make_inputs(FULL, B, 18, lmax=18, tag=900)
+    net = {'model': model.G_NET, 'bert': model_bert.G_NET, 'mix': model_bert.G_NET_MIX}[variant]()
+    v = 'model' if variant == 'model' else 'bert'
+    shapes = g_shapes(FULL, 3, v)
+    assert set(net.state_dict().keys()) == set(shapes.keys())
+    P = fill.fill_state_dict(shapes)
+    net.load_state_dict(P)
+    net.to(dev).train()
+    z = x['z2'] if variant == 'mix' else x['z']
+    eps = fill.unit((B, 100), 901)
+    Q = _with_grad(P)
+    imgs_r, atts_r, mu_r, lv_r = O.g_net(Q, z, x['sent'], x['words'], x['mask'], eps, 3, variant)
+    douts = [fill.unit(tuple(i.shape), 910 + k) for k, i in enumerate(imgs_r)]
+    (sum((i * d).sum() for i, d in zip(imgs_r, douts)) + O.kl_loss(mu_r, lv_r)).backward()
+
+    from miscc.losses import KL_loss
+    net.ca_net.eps = eps.to(dev)
+    imgs, atts, mu, lv = net(z.to(dev), x['sent'].to(dev), x['words'].to(dev), x['mask'].to(dev))
+    (sum((i * d.to(dev)).sum() for i, d in zip(imgs, douts)) + KL_loss(mu, lv)).backward()
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert imgs[k].shape == imgs_r[k].shape and imgs[k].dtype == torch.float32
+        r = rel_l2(imgs[k], imgs_r[k])
+        assert r <= _l2tol(dt, 1 + k), ('img%d' % k, r)
+    for k in range(2):
+        assert rel_l2(atts[k], atts_r[k]) <= _l2tol(dt, 2), 'att%d' % k
+    bad = []
+    for n, p in net.named_parameters():
+        ref = Q[n].grad
+        if ref is None:
+            continue
+        r = rel_l2(p.grad, ref)
+        if r > _l2tol(dt, 5 if dt == torch.float32 else 2):
+            bad.append((n, r))
+    assert not bad, bad
+    for n, b in net.named_buffers():
+        if n.endswith(('running_mean', 'running_var')):
+            assert rel_l2(b, Q[n]) <= _l2tol(dt, 1), n
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('which', [0, 1, 2])
+def test_discriminator_loss(dev, dt, which):
+    import model
+    from miscc.losses import discriminator_loss
+    from sbagan import ops
+    ops.set_compute_dtype(dt)
+    B = 3
+    S = 64 * 2 ** which
+    net = [model.D_NET64, model.D_NET128, model.D_NET256][which]()
+    shapes = d_shapes(FULL, which)
+    assert set(net.state_dict().keys()) == set(shapes.keys())
+    P = fill.fill_state_dict(shapes, salt=which)
+    net.load_state_dict(P)
+    net.to(dev).train()
+    real, fake = fill.uniform((B, 3, S, S), 950), fill.uniform((B, 3, S, S), 951)
+    sent = fill.unit((B, 256), 952)
+    Q = _with_grad(P)
+    ref = O.discriminator_loss(Q, real, fake, sent, torch.ones(B), torch.zeros(B))
+    ref.backward()
+    err = discriminator_loss(net, real.to(dev), fake.to(dev), sent.to(dev), torch.ones(B, device=dev),
+                             torch.zeros(B, device=dev))
+    err.backward()
+    torch.cuda.synchronize()
+    rt = 2e-4 if dt == torch.float32 else 3e-2
+    assert abs(float(err) - float(ref)) <= rt * abs(float(ref)), (float(err), float(ref))
+    bad = []
+    for n, p in net.named_parameters():
+        r = rel_l2(p.grad, Q[n].grad)
+        if r > _l2tol(dt, 5 if dt == torch.float32 else 2.5):
+            bad.append((n, r))
+    assert not bad, bad
+
+
+def _build_step(dev, B, variant='model'):
+    import model
+    import model_bert
+    from sbagan.trainer import GANStep
+    v = 'model' if variant == 'model' else 'bert'
+    netG = {'model': model.G_NET, 'bert': model_bert.G_NET, 'mix': model_bert.G_NET_MIX}[variant]()
+    netG.load_state_dict(fill.fill_state_dict(g_shapes(FULL, 3, v)))
+    netsD = [model.D_NET64(), model.D_NET128(), model.D_NET256()]
+    for i, d in enumerate(netsD):
+        d.load_state_dict(fill.fill_state_dict(d_shapes(FULL, i), salt=i))
+    netG.to(dev).train()
+    for d in netsD:
+        d.to(dev).train()
+    netG.set_return_attention(False)
+    enc = fill.StandInImageEncoder(256, device=dev)
+    return GANStep(netG, netsD, enc, B, lr_g=2e-4, lr_d=2e-4)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_two_training_steps_vs_reference_golden(dev, dt, golden_dir):
+    """The reference's own modules driven in trainer.py order produced these numbers."""
+    from sbagan import ops
+    ops.set_compute_dtype(dt)
+    Gs = load_golden(golden_dir, 'step_full_model_b4.npz')
+    B = 4
+    x = make_inputs(FULL, B, 18, lmax=18, tag=500)
+    st = _build_step(dev, B)
+    imgs = [i.to(dev) for i in x['imgs']]
+    sent, words, mask = x['sent'].to(dev), x['words'].to(dev), x['mask'].to(dev)
+    lens = x['cap_lens'].to(dev)
+    f32 = dt == torch.float32
+    report = {}
+    for step in range(2):
+        noise = fill.unit((B, 100), 550 + step).to(dev)
+        eps = torch.from_numpy(Gs['step%d/eps' % step]).to(dev)
+        out = st.step(imgs, sent, words, mask, lens, x['class_ids'], noise, eps)
+        gn = {'gnormD%d' % i: float(st.grad_norm(st.flatD[i])) for i in range(3)}
+        gn['gnormG'] = float(st.grad_norm(st.flatG))
+        torch.cuda.synchronize()
+        vals = {k: float(v) for k, v in out.items() if torch.is_tensor(v)}
+        vals.update(gn)
+        base = (1e-3 if f32 else 3e-2) * (10 if step else 1)
+        for k in ('errD0', 'errD1', 'errD2', 'errG_total', 'kl_loss', 'gnormD0', 'gnormD1', 'gnormD2', 'gnormG'):
+            ref = float(Gs['step%d/%s' % (step, k)])
+            rel = abs(vals[k] - ref) / max(abs(ref), 1e-12)
+            report['s%d/%s' % (step, k)] = rel
+            tolk = base * (3 if k.startswith('gnorm') else 1)
+            assert rel <= tolk, (step, k, vals[k], ref, rel)
+        for i, f in enumerate(st.fake_imgs):
+            if f32 and step == 0:
+                check(Gs, 'step%d/fake%d' % (step, i), f, rtol=2e-3, atol=2e-4)
+            else:
+                check(Gs, 'step%d/fake%d' % (step, i), f, l2tol=(5e-3 if f32 else 8e-2) * (2 if step else 1))
+    print('relative deviations from the reference:', {k: '%.2e' % v for k, v in report.items()})
+    if f32:
+        for n, p in st.netG.state_dict().items():
+            if n.endswith('num_batches_tracked'):
+                assert int(p) == int(Gs['final/G/%s/sum' % n]), n
+            elif n.endswith(('running_mean', 'running_var')):
+                check(Gs, 'final/G/%s' % n, p, l2tol=1e-2)
+            else:
+                check_param(Gs, 'final/G/%s' % n, p, 4e-4, med=0.15, q90=0.6)
+        for i, d in enumerate(st.netsD):
+            for n, p in d.state_dict().items():
+                if n.endswith('num_batches_tracked'):
+                    assert int(p) == int(Gs['final/D%d/%s/sum' % (i, n)]), n
+                elif n.endswith(('running_mean', 'running_var')):
+                    check(Gs, 'final/D%d/%s' % (i, n), p, l2tol=1e-2)
+                else:
+                    check_param(Gs, 'final/D%d/%s' % (i, n), p, 4e-4, med=0.15, q90=0.6)
+        avg_sum = float(sum(a.double().sum() for a in st.flatG.ema_params()))
+        assert abs(avg_sum - float(Gs['final/avgG_sum'])) <= 1e-3 * abs(float(Gs['final/avgG_sum'])) + 2e-2
+
+
+def test_full_size_step_properties(dev):
+    """BASELINE config 2 shape (B=20, bf16): size-independent properties -- losses finite, every
+    parameter moved by at most lr per step (Adam bound), EMA = 0.999*old + 0.001*new, BN counters
+    advanced exactly as the reference's call pattern implies (D trunk: 2 fwd in the D step + 1 in
+    the G step = 3 per step)."""
+    from sbagan import ops
+    from sbagan.synth import synthetic_batch
+    ops.set_compute_dtype(torch.bfloat16)
+    B = 20
+    st = _build_step(dev, B)
+    b = synthetic_batch(B, device=dev, seed=100)
+    p0 = st.flatG.data.clone()
+    d0 = [f.data.clone() for f in st.flatD]
+    noise = torch.randn((B, 100), device=dev)
+    out = st.step(b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'], b['class_ids'], noise)
+    torch.cuda.synchronize()
+    for k, v in out.items():
+        assert bool(torch.isfinite(v).all()), k
+    lr = 2e-4
+    assert float((st.flatG.data - p0).abs().max()) <= lr * 1.001
+    assert float((st.flatG.data - p0).abs().max()) > 0
+    for f, d in zip(st.flatD, d0):
+        assert float((f.data - d).abs().max()) <= lr * 1.001
+    assert torch.allclose(st.flatG.avg, 0.999 * p0 + 0.001 * st.flatG.data, rtol=0, atol=1e-7)
+    assert int(st.netsD[2].img_code_s16[3].num_batches_tracked) == 3
+    assert int(st.netsD[2].COND_DNET.jointConv[1].num_batches_tracked) == 4     # real, fake, wrong + G step
+    assert int(st.netG.h_net1.upsample1[2].num_batches_tracked) == 1
