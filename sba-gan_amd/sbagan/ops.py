@@ -800,7 +800,8 @@ class WordsLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gl0, gl1):
         feat, words, cap_lens, sim, attn, attn1, wctx, d0, d1 = ctx.saved_tensors
-        B, nef, R = feat.shape
+        B, nef = feat.shape[0], feat.shape[1]
+        R = feat.shape[2] * feat.shape[3]
         L = words.shape[2]
         dev = feat.device
         z = torch.zeros(1, dtype=torch.float32, device=dev)

@@ -52,12 +52,12 @@ def close(got, ref, dt, name='', scale=1.0):
 
 
 def act(x, dt, dev):
-    return x.to(dev).to(dt).contiguous(memory_format=torch.channels_last)
+    return x.detach().to(dev).to(dt).contiguous(memory_format=torch.channels_last).clone()
 
 
 def rounded(x, dt):
     """what the kernel actually sees of an input tensor"""
-    return x.to(dt).float()
+    return x.detach().to(dt).float().clone()
 
 
 # ------------------------------------------------------------------ raw convolutions
