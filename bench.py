@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Benchmark of the SBA-GAN adversarial training step on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full G+D update (trainer.py:245-299 of the reference: G forward, three
+discriminator updates, generator update incl. DAMSM loss and image encoder, Adam, EMA) on
+one synthetic CUB-shaped batch of B=20 per GPU (cfg/bird_style.yml), 3 stages 64/128/256 px,
+inputs resident in HBM.  Rank 0 prints ONE JSON line (see README / DESIGN.md section 6).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'sba-gan_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic GFLOP per image of the step (BASELINE.md section 2, 2*MAC, dead D weight-grads excluded)
+GFLOP_PER_IMG = {1: 6.39, 2: 26.59, 3: 113.95}
+PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}        # MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=20, help='per-GPU batch (cfg/bird_style.yml: 20)')
+    ap.add_argument('--branch', type=int, default=3, help='TREE.BRANCH_NUM: 1/2/3 = 64/128/256 px')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--variant', default='model', choices=['model', 'bert', 'mix'])
+    ap.add_argument('--image-encoder', default='inception', choices=['inception', 'standin'],
+                    help='CNN_ENCODER inside the G step: the Inception-v3 trunk (PyTorch-ROCm/MIOpen, '
+                         'third-party arithmetic) or the light stand-in used by the parity fixtures')
+    ap.add_argument('--graph', type=int, default=1, help='replay the step from a captured hipGraph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    return ap.parse_args()
+
+
+def build(args, dev):
+    from miscc.config import cfg, cfg_from_file
+    cfg_from_file(os.path.join(ROOT, 'sba-gan_amd', 'cfg', 'bird_style.yml'))
+    cfg.TREE.BRANCH_NUM = args.branch
+    cfg.TRAIN.BATCH_SIZE = args.batch
+    cfg.TRAIN.NET_G = ''
+    import model
+    import model_bert
+    from miscc.utils import weights_init
+    from sbagan import ops
+    from sbagan.trainer import GANStep
+    ops.set_compute_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
+    netG = {'model': model.G_NET, 'bert': model_bert.G_NET, 'mix': model_bert.G_NET_MIX}[args.variant]()
+    netsD = [model.D_NET64(), model.D_NET128(), model.D_NET256()][:args.branch]
+    torch.manual_seed(100)
+    netG.apply(weights_init)
+    for d in netsD:
+        d.apply(weights_init)
+    netG.to(dev).train()
+    for d in netsD:
+        d.to(dev).train()
+    netG.set_return_attention(False)        # unused in training (trainer.py:262)
+    if args.image_encoder == 'inception':
+        enc_mod = model.CNN_ENCODER(cfg.TEXT.EMBEDDING_DIM).to(dev).eval()
+        for p in enc_mod.parameters():
+            p.requires_grad = False
+        enc_mod = enc_mod.to(memory_format=torch.channels_last)
+        amp = args.dtype == 'bf16'
+
+        def enc(x):
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
+                f, c = enc_mod(x)
+            return f.float(), c.float()
+    else:
+        from oracle import fill
+        enc = fill.StandInImageEncoder(cfg.TEXT.EMBEDDING_DIM, device=dev)
+    step = GANStep(netG, netsD, enc, args.batch, distributed=(args.gpus > 1))
+    return step
+
+
+def measure_dominant_kernel(args, dev):
+    """Roofline of the dominant kernel: the implicit-GEMM conv of the last generator upBlock
+    (nearest x2 + conv3x3 64->64 at 256x256, B images), timed with events on the launch stream."""
+    from sbagan import ops
+    dt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    B, C, S = args.batch, 64, 64 * 2 ** (args.branch - 1)
+    if args.branch == 1:
+        B, C, S = args.batch, 128, 64      # h_net1.upsample4: 128 -> 64 at 32 -> 64 px
+    x = torch.randn((B, C, S // 2, S // 2), device=dev).to(dt).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter((torch.randn((64, C, 3, 3), device=dev) / 24).contiguous(memory_format=torch.channels_last))
+    pw = ops.PackedWeight(w)
+    for _ in range(3):
+        ops.conv_forward(x, pw, '3x3up')
+    n = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        ops.conv_forward(x, pw, '3x3up', want_stats=False)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    flops = 2.0 * 9 * C * 64 * S * S * B
+    achieved = flops / (ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[args.dtype]
+    return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': round(achieved / peak, 4), 'traffic': None,
+            'kernel': 'igemm_kernel<%s,256,64,64,64> upBlock conv3x3 %d->64 @%dpx B=%d' % (args.dtype, C, S, B),
+            'kernel_ms': round(ms, 4), 'algorithmic_gflop_per_launch': round(flops / 1e9, 2)}
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement of the reference step, fp32) on the host cores: a bounded
+    sample of the same workload (3-stage, bird_style dims, B=4), 2 steps."""
+    from oracle import fill
+    from oracle import sbagan_oracle as O
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import FULL, SMOOTH, d_shapes, g_shapes, make_inputs
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 4
+    x = make_inputs(FULL, B, 18, branch=args.branch, lmax=18, tag=500)
+    PG = fill.fill_state_dict(g_shapes(FULL, args.branch, 'model'))
+    PDs = [fill.fill_state_dict(d_shapes(FULL, i), salt=i) for i in range(args.branch)]
+    st = O.OracleState(PG, PDs)
+    enc = fill.StandInImageEncoder(256)
+    t0 = time.time()
+    nsteps = 2
+    for s in range(nsteps):
+        O.train_step(st, x['imgs'], x['sent'], x['words'], x['mask'], x['cap_lens'], x['class_ids'],
+                     fill.unit((B, 100), 550 + s), fill.unit((B, 100), 560 + s), enc, SMOOTH)
+    dt = time.time() - t0
+    return {'value': round(B * nsteps / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '%d steps of the %d-stage step at B=%d (bird_style dims, fp32, stand-in image encoder), '
+                      'torch CPU threads=%d' % (nsteps, args.branch, B, cores)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus > 1 or world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', local)
+    from sbagan.synth import synthetic_batch
+    step = build(args, dev)
+    b = synthetic_batch(args.batch, branch_num=args.branch, device=dev, seed=100 + rank)
+    noise_shape = (2, args.batch, 100) if args.variant == 'mix' else (args.batch, 100)
+    noise = torch.empty(noise_shape, device=dev)
+    torch.manual_seed(100 + rank)
+
+    def one_step():
+        noise.normal_(0, 1)
+        return step.step(b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'], b['class_ids'],
+                         noise)
+
+    graph = None
+    mode = 'eager'
+    n_eager = max(args.warmup, 3) if args.graph else args.warmup
+    for _ in range(n_eager):
+        out = one_step()
+    torch.cuda.synchronize()
+    if args.graph and world == 1:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                one_step()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                out = one_step()
+            torch.cuda.synchronize()
+            for _ in range(2):
+                graph.replay()
+            torch.cuda.synchronize()
+            mode = 'hipgraph'
+        except Exception as e:      # capture is an optimisation, never a requirement
+            sys.stderr.write('graph capture failed (%s: %s); timing eager launches\n' % (type(e).__name__, e))
+            graph = None
+            torch.cuda.synchronize()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if graph is not None:
+            graph.replay()
+        else:
+            out = one_step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    finite = all(bool(torch.isfinite(v).all()) for v in out.values() if torch.is_tensor(v))
+    ips = world * args.batch * args.steps / dt
+    res = {
+        'metric': 'images/sec (G+D step) at %dpx' % (64 * 2 ** (args.branch - 1)),
+        'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': 'bird_style.yml %d-stage G+D step (64..%dpx), B=%d per GPU, G_NET variant=%s, '
+                               'image_encoder=%s' % (args.branch, 64 * 2 ** (args.branch - 1), args.batch,
+                                                     args.variant, args.image_encoder),
+                   'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'launch': mode,
+                   'losses_finite': finite},
+        'step_tflops': round(GFLOP_PER_IMG[args.branch] * ips / 1e3, 2),
+        'step_mfma_frac': round(GFLOP_PER_IMG[args.branch] * ips / 1e3 / world / PEAK_TFLOPS[args.dtype], 4),
+    }
+    if rank == 0:
+        if not args.no_roofline:
+            res['roofline'] = measure_dominant_kernel(args, dev)
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(args)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
