@@ -63,8 +63,11 @@ const char* sba_version(void);
 /* y[pixel][co] = sum_t sum_ci x[gather(pixel,t)][ci] * w[co][t][ci]  (+ addend[pixel][co]).
  * stats != NULL: also accumulates per-channel sum(y), sum(y^2) of the f32 accumulators into
  * stats[0..Cout) and stats[Cout..2Cout) (caller zeroes it) -- the BatchNorm batch statistics. */
+/* workspace (may be NULL): scratch for split-K of small-M / long-K layers, >= 4*M*Cout bytes to be
+ * used; the library zeroes what it uses.  Stream-ordered reuse of one buffer is safe. */
 int sba_conv_igemm(int dtype, const void* x, const void* w, void* y, const void* addend,
-                   float* stats, const sba_conv_geom* g, void* stream);
+                   float* stats, const sba_conv_geom* g, void* workspace, int64_t workspace_bytes,
+                   void* stream);
 /* dw[co][t][ci] += sum_pixel dy[pixel][co] * x[gather(pixel,t)][ci]   (f32 accumulate/output).
  * ksplit > 1 splits the pixel range over that many workgroups (atomic accumulation). */
 int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* dw, const sba_conv_geom* g,

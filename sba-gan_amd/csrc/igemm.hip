@@ -71,13 +71,14 @@ template <> struct Mma<float> {
 // LDS: double-buffered A[BM] and B[BN] rows of 80 B (64 data + 16 pad: the
 // pad makes the 16-lane ds_read_b128 groups hit 16 distinct 4-bank slots).
 // ---------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int KS>
 __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                     T* __restrict__ y, const T* __restrict__ addend,
                                                     float* __restrict__ stats, const sba_conv_geom g,
-                                                    const int M) {
+                                                    const int M, float* __restrict__ ws,
+                                                    const int slabs_per_split) {
     constexpr int ROWB = 80;
-    constexpr int KS = 64 / (int)sizeof(T);      // channels per slab
+    constexpr int KS_CH = 64 / (int)sizeof(T);   // channels per slab
     constexpr int CH = 16 / (int)sizeof(T);      // elements per 16-byte chunk
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
@@ -86,9 +87,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ x, con
     static_assert(BM % 64 == 0 && BN % 64 == 0, "tile");
     constexpr int TILE_BYTES = (BM + BN) * ROWB;
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES + BM * 4 + BN * 8];
-    int* rowoff = reinterpret_cast<int*>(lds + 2 * TILE_BYTES);
-    float* s_stat = reinterpret_cast<float*>(lds + 2 * TILE_BYTES + BM * 4);
+    // KS slabs are staged per barrier (KS > 1 for the small tiles, whose MFMA work per slab is short)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * KS * TILE_BYTES + BM * 4 + BN * 8];
+    int* rowoff = reinterpret_cast<int*>(lds + 2 * KS * TILE_BYTES);
+    float* s_stat = reinterpret_cast<float*>(lds + 2 * KS * TILE_BYTES + BM * 4);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ x, con
     }
     for (int c = tid; c < 2 * BN; c += 256) s_stat[c] = 0.f;
 
-    const int cpt = g.Cin / KS;               // slabs per tap
+    const int cpt = g.Cin / KS_CH;            // slabs per tap
     const int nsteps = g.ntaps * cpt;
     // tap offsets packed 4 bits each (offset + 8) so that the per-step lookup is
     // scalar shifts instead of a dynamically indexed kernarg array
@@ -137,40 +139,52 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ x, con
         txb |= (uint64_t)((g.tx[t] + 8) & 15) << (4 * t);
     }
 
-    uint4 ra[AI], rb[BI];
-    auto gload = [&](int step) {
-        const int tap = step / cpt;
-        const int c0 = (step - tap * cpt) * KS + chunk * CH;
-        const int ty = (int)((tyb >> (4 * tap)) & 15) - 8, tx = (int)((txb >> (4 * tap)) & 15) - 8;
+    // split-K: this block walks slabs [s_begin, s_end)
+    const int s_begin = blockIdx.z * slabs_per_split;
+    const int s_end = min(s_begin + slabs_per_split, nsteps);
+
+    uint4 ra[KS][AI], rb[KS][BI];
+    auto gload = [&](int stage) {
 #pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            int iy = a_iy0[i] + ty, ix = a_ix0[i] + tx;
-            const bool ok = (iy >= 0) & (iy < IHL) & (ix >= 0) & (ix < IWL);
-            if (g.ups) { iy >>= 1; ix >>= 1; }
-            ra[i] = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const T* p = x + ((int64_t)(a_nb[i] + iy * g.IW + ix) * g.Cin + c0);
-                ra[i] = *reinterpret_cast<const uint4*>(p);
+        for (int k = 0; k < KS; ++k) {
+            const int step = s_begin + stage * KS + k;
+            const bool live = step < s_end;
+            const int tap = live ? step / cpt : 0;
+            const int c0 = (live ? (step - tap * cpt) * KS_CH : 0) + chunk * CH;
+            const int ty = (int)((tyb >> (4 * tap)) & 15) - 8, tx = (int)((txb >> (4 * tap)) & 15) - 8;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                int iy = a_iy0[i] + ty, ix = a_ix0[i] + tx;
+                const bool ok = live & (iy >= 0) & (iy < IHL) & (ix >= 0) & (ix < IWL);
+                if (g.ups) { iy >>= 1; ix >>= 1; }
+                ra[k][i] = make_uint4(0, 0, 0, 0);
+                if (ok) {
+                    const T* p = x + ((int64_t)(a_nb[i] + iy * g.IW + ix) * g.Cin + c0);
+                    ra[k][i] = *reinterpret_cast<const uint4*>(p);
+                }
             }
-        }
 #pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            const int co = n_base + (tid >> 2) + 64 * i;
-            rb[i] = make_uint4(0, 0, 0, 0);
-            if (co < g.Cout) {
-                const T* p = w + (((int64_t)co * g.ntaps + tap) * g.Cin + c0);
-                rb[i] = *reinterpret_cast<const uint4*>(p);
+            for (int i = 0; i < BI; ++i) {
+                const int co = n_base + (tid >> 2) + 64 * i;
+                rb[k][i] = make_uint4(0, 0, 0, 0);
+                if (live && co < g.Cout) {
+                    const T* p = w + (((int64_t)co * g.ntaps + tap) * g.Cin + c0);
+                    rb[k][i] = *reinterpret_cast<const uint4*>(p);
+                }
             }
         }
     };
     auto lstore = [&](int buf) {
-        unsigned char* base = lds + buf * TILE_BYTES;
 #pragma unroll
-        for (int i = 0; i < AI; ++i)
-            *reinterpret_cast<uint4*>(base + ((tid >> 2) + 64 * i) * ROWB + chunk * 16) = ra[i];
+        for (int k = 0; k < KS; ++k) {
+            unsigned char* base = lds + (buf * KS + k) * TILE_BYTES;
 #pragma unroll
-        for (int i = 0; i < BI; ++i)
-            *reinterpret_cast<uint4*>(base + (BM + (tid >> 2) + 64 * i) * ROWB + chunk * 16) = rb[i];
+            for (int i = 0; i < AI; ++i)
+                *reinterpret_cast<uint4*>(base + ((tid >> 2) + 64 * i) * ROWB + chunk * 16) = ra[k][i];
+#pragma unroll
+            for (int i = 0; i < BI; ++i)
+                *reinterpret_cast<uint4*>(base + (BM + (tid >> 2) + 64 * i) * ROWB + chunk * 16) = rb[k][i];
+        }
     };
 
     f32x16_t acc[TM][TN];
@@ -181,16 +195,37 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ x, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const int nstages = (s_end - s_begin + KS - 1) / KS;
     gload(0);
     lstore(0);
     __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
+    for (int s = 0; s < nstages; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nsteps) gload(s + 1);
-        const unsigned char* base = lds + buf * TILE_BYTES;
-        Mma<T>::template slab<TM, TN, ROWB>(base + wm0 * ROWB, base + (BM + wn0) * ROWB, lane, acc);
-        if (s + 1 < nsteps) lstore(buf ^ 1);
+        if (s + 1 < nstages) gload(s + 1);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const unsigned char* base = lds + (buf * KS + k) * TILE_BYTES;
+            Mma<T>::template slab<TM, TN, ROWB>(base + wm0 * ROWB, base + (BM + wn0) * ROWB, lane, acc);
+        }
+        if (s + 1 < nstages) lstore(buf ^ 1);
         __syncthreads();
+    }
+
+    if (ws) {
+        // split-K partial: f32 atomics into ws[m][co]; y / addend / stats are done by splitk_finish_kernel
+        const int col_s = lane & 31, rsel_s = 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int co = n_base + wn0 + j * 32 + col_s;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m_base + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel_s;
+                    if (m < M && co < g.Cout) atomicAdd(&ws[(int64_t)m * g.Cout + co], acc[i][j][r]);
+                }
+        }
+        return;
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -404,6 +439,128 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
 }
 
 // ---------------------------------------------------------------------------
+// weight gradient, small-pixel-count regime (GEMM-like layers at 4x4 / 8x8 maps with
+// thousands of channels): every wave owns its own 64(co) x 64(ci) tile of one tap and walks
+// ALL pixels of the block's range, so there is no cross-wave reduction; the four waves of a
+// workgroup share the dy slice (same co tile) and differ in (tap, ci tile).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                          float* __restrict__ dw, const sba_conv_geom g,
+                                                          const int M, const int chunks_per_split,
+                                                          const int use_atomic) {
+    constexpr int ROWS = WgFrag<T>::ROWS;
+    constexpr int CH = 16 / (int)sizeof(T);
+    constexpr int CPR = 64 / CH;
+    constexpr int LPT = 16 * CPR / 64;               // 16-byte loads per lane for a wave-private slice
+    constexpr int APT = (16 * CPR + 255) / 256;      // 16-byte loads per thread for the shared dy slice
+    constexpr int SLICE = 16 * ROWS;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[5 * SLICE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int co0 = blockIdx.x * 64;
+    const int ci_tiles = (g.Cin + 63) / 64;
+    const int item = blockIdx.y * 4 + wid;
+    const bool active = item < g.ntaps * ci_tiles;
+    const int tap = active ? item / ci_tiles : 0;
+    const int ci0 = active ? (item - tap * ci_tiles) * 64 : 0;
+    int ty = 0, tx = 0;
+#pragma unroll
+    for (int t = 0; t < SBA_MAX_TAPS; ++t)
+        if (t == tap) { ty = g.ty[t]; tx = g.tx[t]; }
+    const int IHL = g.ups ? 2 * g.IH : g.IH, IWL = g.ups ? 2 * g.IW : g.IW;
+    const int sub = g.OHs * g.OWs;
+
+    unsigned char* sa = lds;
+    unsigned char* sb = lds + (1 + wid) * SLICE;
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int total_chunks = (M + 15) / 16;
+    const int chunk_lo = blockIdx.z * chunks_per_split;
+    const int chunk_hi = min(chunk_lo + chunks_per_split, total_chunks);
+
+    for (int ck = chunk_lo; ck < chunk_hi; ++ck) {
+        const int m0 = ck * 16;
+        uint4 va[APT], vb[LPT];
+#pragma unroll
+        for (int u = 0; u < APT; ++u) {
+            const int idx = tid + 256 * u;
+            va[u] = make_uint4(0, 0, 0, 0);
+            if (idx < 16 * CPR) {
+                const int pix = idx / CPR, cc = idx - pix * CPR;
+                const int m = m0 + pix, co = co0 + cc * CH;
+                if (m < M && co < g.Cout) {
+                    const int n = m / sub, rem = m - n * sub;
+                    const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
+                    const int64_t po = (int64_t)(n * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox;
+                    va[u] = *reinterpret_cast<const uint4*>(dy + po * g.Cout + co);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) {
+            const int idx = lane + 64 * u;
+            const int pix = idx / CPR, cc = idx - pix * CPR;
+            const int m = m0 + pix;
+            vb[u] = make_uint4(0, 0, 0, 0);
+            if (active && m < M) {
+                const int n = m / sub, rem = m - n * sub;
+                const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
+                int iy = oy * g.sy + ty, ix = ox * g.sx + tx;
+                const bool ok = (iy >= 0) & (iy < IHL) & (ix >= 0) & (ix < IWL);
+                if (g.ups) { iy >>= 1; ix >>= 1; }
+                const int ci = ci0 + cc * CH;
+                if (ok && ci < g.Cin) {
+                    const int64_t pi = (int64_t)(n * g.IH + iy) * g.IW + ix;
+                    vb[u] = *reinterpret_cast<const uint4*>(x + pi * g.Cin + ci);
+                }
+            }
+        }
+        __syncthreads();          // everyone is done reading the previous slices
+#pragma unroll
+        for (int u = 0; u < APT; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < 16 * CPR) {
+                const int pix = idx / CPR, cc = idx - pix * CPR;
+                *reinterpret_cast<uint4*>(sa + pix * ROWS + cc * 16) = va[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) {
+            const int idx = lane + 64 * u;
+            const int pix = idx / CPR, cc = idx - pix * CPR;
+            *reinterpret_cast<uint4*>(sb + pix * ROWS + cc * 16) = vb[u];
+        }
+        __syncthreads();
+        WgFrag<T>::mma(sa, sb, lane, acc);
+    }
+
+    if (!active) return;
+    const int col_l = lane & 31, rsel = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
+                const int ci = ci0 + j * 32 + col_l;
+                if (co < g.Cout && ci < g.Cin) {
+                    float* p = dw + ((int64_t)co * g.ntaps + tap) * g.Cin + ci;
+                    if (use_atomic) atomicAdd(p, acc[i][j][r]);
+                    else *p += acc[i][j][r];
+                }
+            }
+}
+
+// ---------------------------------------------------------------------------
 // weight packing and 2x2 sum pooling
 // ---------------------------------------------------------------------------
 template <typename T>
@@ -460,20 +617,81 @@ __global__ void pool2x2_kernel(const T* __restrict__ up, T* __restrict__ dx, int
     }
 }
 
+// split-K finish: y[pix(m)][co] = ws[m][co] (+ addend), per-channel stats; thread = 4 channels x 32 rows
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, T* __restrict__ y,
+                                                            const T* __restrict__ addend,
+                                                            float* __restrict__ stats, const sba_conv_geom g,
+                                                            const int M) {
+    const int cq = g.Cout / 4;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cq) return;
+    const int c = t * 4;
+    const int m0 = blockIdx.y * 32, m1 = min(m0 + 32, M);
+    const int sub = g.OHs * g.OWs;
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int m = m0; m < m1; ++m) {
+        const float4 v4 = *reinterpret_cast<const float4*>(ws + (int64_t)m * g.Cout + c);
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const int n = m / sub, rem = m - n * sub;
+        const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
+        const int64_t o = ((int64_t)(n * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox) * g.Cout + c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s0[k] += v[k];
+            s1[k] += v[k] * v[k];
+            if (addend) v[k] += to_f<T>(addend[o + k]);
+            y[o + k] = from_f<T>(v[k]);
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            atomicAdd(&stats[c + k], s0[k]);
+            atomicAdd(&stats[g.Cout + c + k], s1[k]);
+        }
+    }
+}
+
 template <typename T>
 int launch_igemm(const void* x, const void* w, void* y, const void* addend, float* stats,
-                 const sba_conv_geom& g, hipStream_t st) {
+                 const sba_conv_geom& g, void* workspace, int64_t ws_bytes, hipStream_t st) {
     const int M = g.N * g.OHs * g.OWs;
     const T* xp = (const T*)x; const T* wp = (const T*)w; T* yp = (T*)y; const T* ap = (const T*)addend;
+    const int nslabs = g.ntaps * (g.Cin / (64 / (int)sizeof(T)));
     if (g.Cout % 128 == 0 && M >= 4096) {
         dim3 grid(cdiv(M, 128), cdiv(g.Cout, 128));
-        hipLaunchKernelGGL((igemm_kernel<T, 128, 128, 64, 64>), grid, dim3(256), 0, st, xp, wp, yp, ap, stats, g, M);
+        hipLaunchKernelGGL((igemm_kernel<T, 128, 128, 64, 64, 1>), grid, dim3(256), 0, st, xp, wp, yp, ap, stats, g,
+                           M, (float*)nullptr, nslabs);
     } else if (M >= 8192) {
         dim3 grid(cdiv(M, 256), cdiv(g.Cout, 64));
-        hipLaunchKernelGGL((igemm_kernel<T, 256, 64, 64, 64>), grid, dim3(256), 0, st, xp, wp, yp, ap, stats, g, M);
+        hipLaunchKernelGGL((igemm_kernel<T, 256, 64, 64, 64, 1>), grid, dim3(256), 0, st, xp, wp, yp, ap, stats, g,
+                           M, (float*)nullptr, nslabs);
     } else {
-        dim3 grid(cdiv(M, 64), cdiv(g.Cout, 64));
-        hipLaunchKernelGGL((igemm_kernel<T, 64, 64, 32, 32>), grid, dim3(256), 0, st, xp, wp, yp, ap, stats, g, M);
+        // small-M (GEMM-like) layers: few output tiles and a long K -> split K over blockIdx.z
+        const int tiles = cdiv(M, 64) * cdiv(g.Cout, 64);
+        int split = 1;
+        if (workspace && tiles < 384 && nslabs >= 32 && g.Cout % 4 == 0 &&
+            (int64_t)M * g.Cout * 4 <= ws_bytes) {
+            split = cdiv(768, tiles);
+            if (split > nslabs / 8) split = nslabs / 8;
+            if (split > 32) split = 32;
+        }
+        if (split > 1) {
+            const int sps = cdiv(cdiv(nslabs, split), 4) * 4;      // multiple of the stage depth
+            split = cdiv(nslabs, sps);
+            if (hipMemsetAsync(workspace, 0, (size_t)M * g.Cout * 4, st) != hipSuccess) return SBA_E_LAUNCH;
+            dim3 grid(cdiv(M, 64), cdiv(g.Cout, 64), split);
+            hipLaunchKernelGGL((igemm_kernel<T, 64, 64, 32, 32, 4>), grid, dim3(256), 0, st, xp, wp, yp, ap, stats,
+                               g, M, (float*)workspace, sps);
+            dim3 fgrid(cdiv(g.Cout / 4, 256), cdiv(M, 32));
+            hipLaunchKernelGGL((splitk_finish_kernel<T>), fgrid, dim3(256), 0, st, (const float*)workspace, yp, ap,
+                               stats, g, M);
+        } else {
+            dim3 grid(cdiv(M, 64), cdiv(g.Cout, 64));
+            hipLaunchKernelGGL((igemm_kernel<T, 64, 64, 32, 32, 4>), grid, dim3(256), 0, st, xp, wp, yp, ap, stats,
+                               g, M, (float*)nullptr, nslabs);
+        }
     }
     return SBA_CHECK_LAUNCH();
 }
@@ -499,9 +717,12 @@ bool geom_ok(const sba_conv_geom* g, int dtype) {
 }  // namespace
 
 extern "C" int sba_conv_igemm(int dtype, const void* x, const void* w, void* y, const void* addend,
-                              float* stats, const sba_conv_geom* g, void* stream) {
+                              float* stats, const sba_conv_geom* g, void* workspace, int64_t workspace_bytes,
+                              void* stream) {
     if (!x || !w || !y || !geom_ok(g, dtype)) return SBA_E_ARG;
-    SBA_DISPATCH(dtype, return launch_igemm<T>(x, w, y, addend, stats, *g, (hipStream_t)stream));
+    if (((uintptr_t)workspace & 15) != 0) return SBA_E_ARG;
+    SBA_DISPATCH(dtype, return launch_igemm<T>(x, w, y, addend, stats, *g, workspace, workspace_bytes,
+                                               (hipStream_t)stream));
     return SBA_E_ARG;
 }
 
@@ -510,12 +731,27 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
     if (!x || !dy || !dw || !geom_ok(g, dtype)) return SBA_E_ARG;
     if (g->Cin % 8 != 0 || g->Cout % 8 != 0) return SBA_E_ARG;
     const int M = g->N * g->OHs * g->OWs;
-    const int total_chunks = cdiv(M, 64);
     if (ksplit < 1) ksplit = 1;
+    const int co_tiles = cdiv(g->Cout, 64), items = cdiv(g->Cin, 64) * g->ntaps;
+    if (M <= 2048 && co_tiles * items >= 256) {
+        // GEMM-like layer: one tile per wave, all pixels (ksplit re-derived for this decomposition)
+        const int total_chunks = cdiv(M, 16);
+        const int wgs = co_tiles * cdiv(items, 4);
+        int split = wgs >= 512 ? 1 : cdiv(1024, wgs);
+        if (split > total_chunks / 4) split = total_chunks / 4 > 0 ? total_chunks / 4 : 1;
+        const int cps = cdiv(total_chunks, split);
+        split = cdiv(total_chunks, cps);
+        dim3 grid(co_tiles, cdiv(items, 4), split);
+        if (grid.y > 65535 || grid.z > 65535) return SBA_E_ARG;
+        SBA_DISPATCH(dtype, hipLaunchKernelGGL((wgrad_small_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
+                                               (const T*)x, (const T*)dy, dw, *g, M, cps, split > 1 ? 1 : 0));
+        return SBA_CHECK_LAUNCH();
+    }
+    const int total_chunks = cdiv(M, 64);
     if (ksplit > total_chunks) ksplit = total_chunks;
     const int cps = cdiv(total_chunks, ksplit);
     ksplit = cdiv(total_chunks, cps);
-    dim3 grid(cdiv(g->Cout, 64), cdiv(g->Cin, 64) * g->ntaps, ksplit);
+    dim3 grid(co_tiles, items, ksplit);
     if (grid.y > 65535 || grid.z > 65535) return SBA_E_ARG;
     SBA_DISPATCH(dtype, hipLaunchKernelGGL((wgrad_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
                                            (const T*)x, (const T*)dy, dw, *g, M, cps, ksplit > 1 ? 1 : 0));

@@ -41,6 +41,16 @@ def weights_changed():
     _WEIGHT_EPOCH[0] += 1
 
 
+_EPOCH_CELL = {}             # id(param) -> [counter] shared by all parameters of one network
+
+
+def register_epoch(params, cell):
+    """Give a group of parameters (one network) its own change counter, so that an optimizer step
+    on one network does not invalidate the packed weights of the others."""
+    for p in params:
+        _EPOCH_CELL[id(p)] = cell
+
+
 def _dt(t):
     if t.dtype == torch.float32:
         return _lib.SBA_F32
@@ -153,7 +163,8 @@ class PackedWeight(object):
         self._kf = self._kd = None
 
     def _key(self, dtype):
-        return (self.param._version, _WEIGHT_EPOCH[0], dtype, self.param.data_ptr())
+        cell = _EPOCH_CELL.get(id(self.param))
+        return (self.param._version, _WEIGHT_EPOCH[0], cell[0] if cell else 0, dtype, self.param.data_ptr())
 
     def _master(self):
         p = self.param.detach()
@@ -188,6 +199,24 @@ class PackedWeight(object):
         return self._dgrad
 
 
+_WORKSPACE = {}
+WORKSPACE_BYTES = 64 << 20
+
+
+def workspace(device):
+    """Per-device scratch for split-K partial sums (reused by stream-ordered launches)."""
+    ws = _WORKSPACE.get(device)
+    if ws is None:
+        ws = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        _WORKSPACE[device] = ws
+    return ws
+
+
+def _igemm(dt, x, w, y, addend, stats, g, device):
+    ws = workspace(device)
+    call('sba_conv_igemm', dt, x, w, y, addend, stats, ctypes.byref(g), ws.data_ptr(), WORKSPACE_BYTES, _stream())
+
+
 # ----------------------------------------------------------------------------
 # raw (non-autograd) building blocks
 # ----------------------------------------------------------------------------
@@ -200,8 +229,7 @@ def conv_forward(x, pw, kind, want_stats=True, addend=None):
     y = empty_act(N, O, OH, OW, x)
     stats = torch.zeros(2 * O, dtype=torch.float32, device=x.device) if want_stats else None
     g = _geom((kind, N, H, W, Cin, O, None))
-    call('sba_conv_igemm', _dt(x), _p(x), _p(pw.fwd(x.dtype)), _p(y), _p(addend), _p(stats),
-         ctypes.byref(g), _stream())
+    _igemm(_dt(x), _p(x), _p(pw.fwd(x.dtype)), _p(y), _p(addend), _p(stats), g, x.device)
     return y, stats
 
 
@@ -215,10 +243,10 @@ def conv_dgrad(dy, pw, kind, in_hw, addend=None):
         g = _geom(('3x3', N, OH, OW, O, I, None))
         if kind == '3x3':
             dx = empty_act(N, I, H, W, dy)
-            call('sba_conv_igemm', _dt(dy), _p(dy), _p(wd), _p(dx), _p(addend), None, ctypes.byref(g), _stream())
+            _igemm(_dt(dy), _p(dy), _p(wd), _p(dx), _p(addend), None, g, dy.device)
             return dx
         dup = empty_act(N, I, OH, OW, dy)
-        call('sba_conv_igemm', _dt(dy), _p(dy), _p(wd), _p(dup), None, None, ctypes.byref(g), _stream())
+        _igemm(_dt(dy), _p(dy), _p(wd), _p(dup), None, None, g, dy.device)
         dx = empty_act(N, I, H, W, dy)
         call('sba_pool2x2_sum', _dt(dy), _p(dup), _p(dx), N, H, W, I, _stream())
         if addend is not None:
@@ -230,7 +258,7 @@ def conv_dgrad(dy, pw, kind, in_hw, addend=None):
         for cls in range(4):
             g = _geom(('4x4s2_dgrad', N, OH, OW, O, I, (cls // 2, cls % 2)))
             wptr = wd.data_ptr() + cls * I * 4 * O * esz
-            call('sba_conv_igemm', _dt(dy), _p(dy), wptr, _p(dx), _p(addend), None, ctypes.byref(g), _stream())
+            _igemm(_dt(dy), _p(dy), wptr, _p(dx), _p(addend), None, g, dy.device)
         return dx
     raise ValueError(kind)
 

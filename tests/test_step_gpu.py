@@ -126,12 +126,17 @@ def test_discriminator_loss(dev, dt, which):
     torch.cuda.synchronize()
     rt = 2e-4 if dt == torch.float32 else 3e-2
     assert abs(float(err) - float(ref)) <= rt * abs(float(ref)), (float(err), float(ref))
-    bad = []
+    bad, got, refs = [], [], []
     for n, p in net.named_parameters():
         r = rel_l2(p.grad, Q[n].grad)
-        if r > _l2tol(dt, 15 if dt == torch.float32 else 2.5):
+        got.append(p.grad.detach().float().cpu().flatten())
+        refs.append(Q[n].grad.detach().float().flatten())
+        # per tensor: tight in f32; loose in bf16 (near-cancelling sums such as BN beta gradients)
+        if r > (3e-3 if dt == torch.float32 else 0.35):
             bad.append((n, r))
     assert not bad, bad
+    allr = rel_l2(torch.cat(got), torch.cat(refs))
+    assert allr <= (1e-3 if dt == torch.float32 else 5e-2), allr
 
 
 def _build_step(dev, B, variant='model'):
