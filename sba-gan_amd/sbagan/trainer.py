@@ -101,6 +101,38 @@ def sort_by_caption_length(captions_lens):
     return torch.sort(captions_lens, 0, True)
 
 
+class GradExchange(object):
+    """Data-parallel gradient exchange (new functionality; the reference is single-GPU, SURVEY.md
+    8e): ONE sum all-reduce per network over its flat f32 gradient buffer, issued on a side
+    stream so that it overlaps the next network's forward/backward; the 1/world mean is folded
+    into the fused Adam (grad_scale).  Backend = torch.distributed: "nccl" is RCCL over xGMI on
+    ROCm; "gloo" on CPU tensors is used by the world_size-2 tests."""
+
+    def __init__(self, device, enabled=True):
+        self.enabled = bool(enabled) and dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.enabled else 1
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device) if (self.enabled and self.device.type == 'cuda') else None
+
+    def start(self, flat_grad):
+        if not self.enabled:
+            return None
+        if self.stream is None:
+            return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=True)
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        return self.stream
+
+    def wait(self, handle):
+        if handle is None:
+            return
+        if isinstance(handle, torch.cuda.Stream):
+            torch.cuda.current_stream().wait_stream(handle)
+        else:
+            handle.wait()
+
+
 class GANStep(object):
     """One G+D update.  `netsD` is a list (D_NET64[, D_NET128[, D_NET256]]); `image_encoder` maps
     the last fake image to (region features B x nef x 17 x 17, global code B x nef)."""
@@ -115,30 +147,15 @@ class GANStep(object):
         self.optG = FusedAdam(self.flatG, cfg.TRAIN.GENERATOR_LR if lr_g is None else lr_g)
         self.optD = [FusedAdam(f, cfg.TRAIN.DISCRIMINATOR_LR if lr_d is None else lr_d) for f in self.flatD]
         self.real_labels, self.fake_labels, self.match_labels = prepare_labels(batch_size, dev)
-        self.distributed = distributed and dist.is_available() and dist.is_initialized()
-        self.world = dist.get_world_size() if self.distributed else 1
-        self.comm_stream = torch.cuda.Stream(device=dev) if (self.distributed and dev.type == 'cuda') else None
+        self.exchange = GradExchange(dev, enabled=distributed)
+        self.distributed, self.world = self.exchange.enabled, self.exchange.world
         self._d_params = [p for d in netsD for p in d.parameters()]
 
-    # -- data-parallel gradient exchange: one all-reduce per network on a side stream so that it
-    #    overlaps the next network's forward/backward
     def _allreduce_start(self, flat):
-        if not self.distributed:
-            return None
-        if self.comm_stream is None:
-            return dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, async_op=True)
-        self.comm_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.comm_stream):
-            dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM)
-        return self.comm_stream
+        return self.exchange.start(flat.grad)
 
     def _allreduce_wait(self, h):
-        if h is None:
-            return
-        if isinstance(h, torch.cuda.Stream):
-            torch.cuda.current_stream().wait_stream(h)
-        else:
-            h.wait()
+        self.exchange.wait(h)
 
     def step(self, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, eps=None):
         """Returns a dict of DEVICE scalars (errD0.., errG_total, kl_loss, g_loss*, w_loss, s_loss)."""

@@ -1,0 +1,178 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports exactly what
+include/sbagan_hip.h declares, the config loader mirrors the reference's semantics, the
+module tree has the reference's state_dict surface, integer caption work is bit-exact, the
+product path refuses to run without a GPU, and the data-parallel exchange is correct on two
+gloo ranks."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_decls():
+    txt = open(os.path.join(ROOT, 'include', 'sbagan_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    decls = {}
+    for m in re.finditer(r'\bint\s+(sba_\w+)\s*\(([^;]*?)\)\s*;', txt, flags=re.S):
+        args = [a for a in m.group(2).split(',') if a.strip()]
+        decls[m.group(1)] = len(args)
+    return decls
+
+
+def test_library_exports_every_declared_symbol():
+    from sbagan import _lib
+    decls = _header_decls()
+    assert len(decls) >= 40
+    assert set(decls) == set(_lib.SIGNATURES), set(decls) ^ set(_lib.SIGNATURES)
+    for name, nargs in decls.items():
+        assert hasattr(_lib.lib, name), name
+        assert len(_lib.SIGNATURES[name]) == nargs, (name, nargs, len(_lib.SIGNATURES[name]))
+    assert 'gfx950' in _lib.version()
+
+
+def test_no_cpu_fallback():
+    """the product path fails loudly without a device; nothing under sba-gan_amd imports the oracle"""
+    from sbagan import ops
+    with pytest.raises(RuntimeError):
+        ops.LinearFn.apply(torch.zeros(2, 3), torch.zeros(4, 3), None)
+    pkg = os.path.join(ROOT, 'sba-gan_amd')
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith('.py'):
+                src = open(os.path.join(dp, f)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src, os.path.join(dp, f)
+
+
+def test_config_semantics(tmp_path):
+    from miscc.config import cfg, cfg_from_file, reset_cfg
+    reset_cfg()
+    assert cfg.GAN.GF_DIM == 128 and cfg.TRAIN.SMOOTH.GAMMA1 == 5.0 and cfg.TEXT.WORDS_NUM == 20
+    cfg_from_file(os.path.join(ROOT, 'sba-gan_amd', 'cfg', 'bird_style.yml'))
+    assert (cfg.GAN.GF_DIM, cfg.GAN.DF_DIM, cfg.TRAIN.BATCH_SIZE, cfg.TREE.BRANCH_NUM) == (32, 64, 20, 3)
+    assert cfg.TRAIN.SMOOTH.LAMBDA == 5.0 and cfg.TRAIN.SMOOTH.GAMMA1 == 4.0 and cfg['GAN']['R_NUM'] == 2
+    bad = tmp_path / 'bad.yml'
+    bad.write_text('NOT_A_KEY: 1\n')
+    with pytest.raises(KeyError):
+        cfg_from_file(str(bad))
+    bad.write_text('GAN:\n    GF_DIM: "thirty-two"\n')
+    with pytest.raises(ValueError):
+        cfg_from_file(str(bad))
+    for name in ('bird_attn2', 'bird_attnDCGAN2', 'coco_attn2', 'eval_bird', 'eval_bird_attnDCGAN2', 'eval_coco',
+                 'DAMSM/bird', 'DAMSM/coco'):
+        reset_cfg()
+        cfg_from_file(os.path.join(ROOT, 'sba-gan_amd', 'cfg', name + '.yml'))
+    reset_cfg()
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/AttnGAN2/code/cfg'), reason='reference not mounted')
+def test_reference_yml_files_load_unchanged():
+    from miscc.config import cfg, cfg_from_file, reset_cfg
+    base = '/root/reference/AttnGAN2/code/cfg'
+    n = 0
+    for dp, _, fs in os.walk(base):
+        for f in fs:
+            if f.endswith('.yml'):
+                reset_cfg()
+                cfg_from_file(os.path.join(dp, f))
+                n += 1
+    assert n == 9
+    reset_cfg()
+
+
+def test_state_dict_surface_matches_reference():
+    from helpers import FULL, d_shapes, g_shapes
+    from miscc.config import cfg, reset_cfg
+    reset_cfg()
+    cfg.GAN.GF_DIM, cfg.GAN.DF_DIM, cfg.TREE.BRANCH_NUM = 32, 64, 3
+    import model
+    import model_bert
+    for net, exp in ((model.G_NET(), g_shapes(FULL, 3, 'model')), (model_bert.G_NET(), g_shapes(FULL, 3, 'bert')),
+                     (model_bert.G_NET_MIX(), g_shapes(FULL, 3, 'bert')), (model.D_NET64(), d_shapes(FULL, 0)),
+                     (model.D_NET128(), d_shapes(FULL, 1)), (model.D_NET256(), d_shapes(FULL, 2))):
+        sd = net.state_dict()
+        assert set(sd) == set(exp)
+        for k, v in sd.items():
+            assert tuple(v.shape) == tuple(exp[k]), k
+    assert len(model.G_NET().state_dict()) == 107 and len(model.D_NET256().state_dict()) == 53
+    # weights_init + checkpoint round trip keep the packed (channels_last) storage
+    from miscc.utils import copy_G_params, weights_init
+    g = model.G_NET()
+    g.apply(weights_init)
+    w = g.h_net2.upsample[1].weight
+    assert w.is_contiguous(memory_format=torch.channels_last)
+    flat = w.detach().permute(0, 2, 3, 1).reshape(w.size(0), -1)
+    assert torch.allclose(flat @ flat.t(), torch.eye(w.size(0)), atol=1e-4)      # orthogonal rows
+    g2 = model.G_NET()
+    g2.load_state_dict(g.state_dict())
+    assert g2.h_net2.upsample[1].weight.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(g2.h_net2.upsample[1].weight, w)
+    assert len(copy_G_params(g)) == 62           # SURVEY: 62 G parameter tensors
+    rnn = model.RNN_ENCODER(50, nhidden=256)
+    words, sent = rnn(torch.randint(1, 50, (3, 7)), torch.tensor([7, 5, 2]), rnn.init_hidden(3))
+    assert words.shape == (3, 256, 7) and sent.shape == (3, 256)
+
+
+def test_caption_integer_work_bit_exact():
+    from oracle import fill
+    from oracle import sbagan_oracle as O
+    from miscc.losses import class_mask
+    from sbagan.trainer import build_mask, sort_by_caption_length
+    caps, lens = fill.synthetic_captions(7, 20, 18, tag=3)
+    assert torch.equal(build_mask(caps, 18), O.build_mask(caps, 18))
+    assert build_mask(caps, 25).shape == (7, 20)
+    perm = torch.tensor([3, 1, 6, 0, 2, 5, 4])
+    a, b = sort_by_caption_length(lens[perm]), O.sort_by_caption_length(lens[perm])
+    assert torch.equal(a[0], b[0])
+    ids = np.array([4, 1, 4, 2, 1, 1, 9])
+    m = class_mask(ids, 7, 'cpu')
+    assert m.dtype == torch.uint8 and np.array_equal(m.numpy().astype(bool), O.class_mask(ids, 7).numpy())
+    assert class_mask(None, 7, 'cpu') is None
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'sba-gan_amd'))
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sbagan.trainer import FlatParams, GradExchange
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(13, 7), torch.nn.Conv2d(4, 6, 3))
+    net[1].weight.data = net[1].weight.data.contiguous(memory_format=torch.channels_last)
+    flat = FlatParams(net)
+    ex = GradExchange('cpu')
+    assert ex.enabled and ex.world == world
+    # each rank's "local gradient": deterministic function of (rank, parameter index)
+    for i, p in enumerate(net.parameters()):
+        p.grad += (rank + 1) * (i + 1) * torch.ones_like(p)
+    h = ex.start(flat.grad)
+    ex.wait(h)
+    ok = True
+    for i, p in enumerate(net.parameters()):
+        expect = sum((r + 1) * (i + 1) for r in range(world))
+        ok &= bool(torch.allclose(p.grad, torch.full_like(p, float(expect))))
+    # mean gradient = what the fused Adam consumes with grad_scale = 1/world
+    mean = flat.grad / ex.world
+    ok &= bool(torch.allclose(mean[:13 * 7], torch.full((13 * 7,), (world + 1) / 2.0)))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_exchange_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29400 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
