@@ -63,8 +63,9 @@ const char* sba_version(void);
 /* y[pixel][co] = sum_t sum_ci x[gather(pixel,t)][ci] * w[co][t][ci]  (+ addend[pixel][co]).
  * stats != NULL: also accumulates per-channel sum(y), sum(y^2) of the f32 accumulators into
  * stats[0..Cout) and stats[Cout..2Cout) (caller zeroes it) -- the BatchNorm batch statistics. */
-/* workspace (may be NULL): scratch for split-K of small-M / long-K layers, >= 4*M*Cout bytes to be
- * used; the library zeroes what it uses.  Stream-ordered reuse of one buffer is safe. */
+/* workspace (may be NULL): scratch for split-K of small-M / long-K layers, used when it holds
+ * >= 4*M*Cout bytes.  It must be ZERO-FILLED when first handed in; every call leaves it zero-filled
+ * again, so stream-ordered reuse of one buffer needs no further memsets. */
 int sba_conv_igemm(int dtype, const void* x, const void* w, void* y, const void* addend,
                    float* stats, const sba_conv_geom* g, void* workspace, int64_t workspace_bytes,
                    void* stream);

@@ -561,6 +561,136 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+// weight gradient, large-map 3x3 stride-1 convs (optionally over a nearest-x2 upsampled input)
+// with OW % 64 == 0: the generator's 64..256 px layers, where ~all wgrad FLOPs are.
+// A workgroup owns one 64(co) x 64(ci) tile for ALL nine taps: per 64-pixel segment of an output
+// row it stages the dy tile once and, per kernel row kh, ONE input row with a 1-pixel halo
+// (66 x 64 channels); the three kw taps are the same LDS rows read at a +kw row offset, so each
+// input pixel is fetched once per kh instead of once per tap.  Wave kh (3 waves) accumulates its
+// three taps (192 accumulator registers) over the workgroup's whole pixel range, then adds them
+// to dw with f32 atomics.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(192) void wgrad_rows_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                         float* __restrict__ dw, const sba_conv_geom g,
+                                                         const int total_segs, const int segs_per_wg) {
+    constexpr int ROWS = WgFrag<T>::ROWS;
+    constexpr int CH = 16 / (int)sizeof(T);
+    constexpr int CPR = 64 / CH;                       // 16-byte chunks per 64-channel pixel row
+    constexpr int XR = 66;                             // 64 pixels + halo
+    constexpr int XROWS_ALLOC = 80;                    // rows reserved per x tile (>= 64 + 2 + 15 read slack)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(64 + 3 * XROWS_ALLOC) * ROWS];
+
+    const int tid = threadIdx.x, lane = tid & 63, kh = tid >> 6;
+    const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
+    const int IHL = g.ups ? 2 * g.IH : g.IH, IWL = g.ups ? 2 * g.IW : g.IW;
+    const int segs_per_row = g.OW / 64;
+    unsigned char* sa = lds;
+    unsigned char* sx = lds + (64 + kh * XROWS_ALLOC) * ROWS;
+
+    // rows 66..79 of the x tile are only ever read by discarded k positions? no: every read row
+    // index is < 16*3 + 2 + 16 = 66, so the slack rows are never touched; zero them once anyway
+    for (int i = lane; i < (XROWS_ALLOC - XR) * ROWS / 16; i += 64)
+        *reinterpret_cast<uint4*>(sx + XR * ROWS + i * 16) = make_uint4(0, 0, 0, 0);
+
+    f32x16_t acc[3][2][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+
+    const int seg_lo = blockIdx.z * segs_per_wg;
+    const int seg_hi = min(seg_lo + segs_per_wg, total_segs);
+    for (int seg = seg_lo; seg < seg_hi; ++seg) {
+        const int n = seg / (g.OH * segs_per_row);
+        const int rem = seg - n * g.OH * segs_per_row;
+        const int oy = rem / segs_per_row, ox0 = (rem - oy * segs_per_row) * 64;
+        // ---- global loads into registers
+        constexpr int A_PT = (64 * CPR + 191) / 192;
+        uint4 va[A_PT];
+#pragma unroll
+        for (int u = 0; u < A_PT; ++u) {
+            const int idx = tid + 192 * u;
+            va[u] = make_uint4(0, 0, 0, 0);
+            if (idx < 64 * CPR) {
+                const int pix = idx / CPR, cc = idx - pix * CPR;
+                const int co = co0 + cc * CH;
+                if (co < g.Cout) {
+                    const int64_t po = ((int64_t)(n * g.OH + oy) * g.OW + ox0 + pix);
+                    va[u] = *reinterpret_cast<const uint4*>(dy + po * g.Cout + co);
+                }
+            }
+        }
+        constexpr int X_PT = (XR * CPR + 63) / 64;
+        uint4 vx[X_PT];
+        int iy = oy + kh - 1;
+        const bool row_ok = (iy >= 0) & (iy < IHL);
+        if (g.ups) iy >>= 1;
+#pragma unroll
+        for (int u = 0; u < X_PT; ++u) {
+            const int idx = lane + 64 * u;
+            vx[u] = make_uint4(0, 0, 0, 0);
+            if (idx < XR * CPR) {
+                const int j = idx / CPR, cc = idx - j * CPR;
+                int ix = ox0 - 1 + j;
+                const bool ok = row_ok & (ix >= 0) & (ix < IWL);
+                if (g.ups) ix >>= 1;
+                const int ci = ci0 + cc * CH;
+                if (ok && ci < g.Cin) {
+                    const int64_t pi = (int64_t)(n * g.IH + iy) * g.IW + ix;
+                    vx[u] = *reinterpret_cast<const uint4*>(x + pi * g.Cin + ci);
+                }
+            }
+        }
+        __syncthreads();        // previous segment's tiles fully consumed
+#pragma unroll
+        for (int u = 0; u < A_PT; ++u) {
+            const int idx = tid + 192 * u;
+            if (idx < 64 * CPR) {
+                const int pix = idx / CPR, cc = idx - pix * CPR;
+                *reinterpret_cast<uint4*>(sa + pix * ROWS + cc * 16) = va[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < X_PT; ++u) {
+            const int idx = lane + 64 * u;
+            if (idx < XR * CPR) {
+                const int j = idx / CPR, cc = idx - j * CPR;
+                *reinterpret_cast<uint4*>(sx + j * ROWS + cc * 16) = vx[u];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+                WgFrag<T>::mma(sa + 16 * ks * ROWS, sx + (16 * ks + kw) * ROWS, lane, acc[kw]);
+        }
+    }
+
+    const int col_l = lane & 31, rsel = 4 * (lane >> 5);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int tap = kh * 3 + kw;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
+                    const int ci = ci0 + j * 32 + col_l;
+                    if (co < g.Cout && ci < g.Cin)
+                        atomicAdd(dw + ((int64_t)co * 9 + tap) * g.Cin + ci, acc[kw][i][j][r]);
+                }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // weight packing and 2x2 sum pooling
 // ---------------------------------------------------------------------------
 template <typename T>
@@ -617,9 +747,9 @@ __global__ void pool2x2_kernel(const T* __restrict__ up, T* __restrict__ dx, int
     }
 }
 
-// split-K finish: y[pix(m)][co] = ws[m][co] (+ addend), per-channel stats; thread = 4 channels x 32 rows
+// split-K finish: y[pix(m)][co] = ws[m][co] (+ addend), per-channel stats; thread = 4 channels x 8 rows
 template <typename T>
-__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, T* __restrict__ y,
+__global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ ws, T* __restrict__ y,
                                                             const T* __restrict__ addend,
                                                             float* __restrict__ stats, const sba_conv_geom g,
                                                             const int M) {
@@ -627,11 +757,13 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= cq) return;
     const int c = t * 4;
-    const int m0 = blockIdx.y * 32, m1 = min(m0 + 32, M);
+    const int m0 = blockIdx.y * 8, m1 = min(m0 + 8, M);
     const int sub = g.OHs * g.OWs;
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
     for (int m = m0; m < m1; ++m) {
-        const float4 v4 = *reinterpret_cast<const float4*>(ws + (int64_t)m * g.Cout + c);
+        float4* wp = reinterpret_cast<float4*>(ws + (int64_t)m * g.Cout + c);
+        const float4 v4 = *wp;
+        *wp = make_float4(0.f, 0.f, 0.f, 0.f);      // leave the workspace zero-filled for its next user
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
         const int n = m / sub, rem = m - n * sub;
         const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
@@ -680,12 +812,11 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
         if (split > 1) {
             const int sps = cdiv(cdiv(nslabs, split), 4) * 4;      // multiple of the stage depth
             split = cdiv(nslabs, sps);
-            if (hipMemsetAsync(workspace, 0, (size_t)M * g.Cout * 4, st) != hipSuccess) return SBA_E_LAUNCH;
             dim3 grid(cdiv(M, 64), cdiv(g.Cout, 64), split);
             hipLaunchKernelGGL((igemm_kernel<T, 64, 64, 32, 32, 4>), grid, dim3(256), 0, st, xp, wp, yp, ap, stats,
                                g, M, (float*)workspace, sps);
-            dim3 fgrid(cdiv(g.Cout / 4, 256), cdiv(M, 32));
-            hipLaunchKernelGGL((splitk_finish_kernel<T>), fgrid, dim3(256), 0, st, (const float*)workspace, yp, ap,
+            dim3 fgrid(cdiv(g.Cout / 4, 256), cdiv(M, 8));
+            hipLaunchKernelGGL((splitk_finish_kernel<T>), fgrid, dim3(256), 0, st, (float*)workspace, yp, ap,
                                stats, g, M);
         } else {
             dim3 grid(cdiv(M, 64), cdiv(g.Cout, 64));
@@ -745,6 +876,23 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
         if (grid.y > 65535 || grid.z > 65535) return SBA_E_ARG;
         SBA_DISPATCH(dtype, hipLaunchKernelGGL((wgrad_small_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
                                                (const T*)x, (const T*)dy, dw, *g, M, cps, split > 1 ? 1 : 0));
+        return SBA_CHECK_LAUNCH();
+    }
+    // generator-style 3x3 stride-1 conv on a wide map: all nine taps per workgroup from halo tiles
+    bool rows_ok = g->ntaps == 9 && g->sy == 1 && g->sx == 1 && g->osy == 1 && g->osx == 1 && g->ooy == 0 &&
+                   g->oox == 0 && g->OHs == g->OH && g->OWs == g->OW && g->OW % 64 == 0 && M >= 32768;
+    for (int t = 0; t < 9 && rows_ok; ++t) rows_ok = g->ty[t] == t / 3 - 1 && g->tx[t] == t % 3 - 1;
+    if (rows_ok) {
+        const int total_segs = g->N * g->OH * (g->OW / 64);
+        const int ci_t = cdiv(g->Cin, 64);
+        int nz = cdiv(512, co_tiles * ci_t);
+        if (nz > total_segs) nz = total_segs;
+        const int spw = cdiv(total_segs, nz);
+        nz = cdiv(total_segs, spw);
+        dim3 grid(co_tiles, ci_t, nz);
+        if (grid.z > 65535) return SBA_E_ARG;
+        SBA_DISPATCH(dtype, hipLaunchKernelGGL((wgrad_rows_kernel<T>), grid, dim3(192), 0, (hipStream_t)stream,
+                                               (const T*)x, (const T*)dy, dw, *g, total_segs, spw));
         return SBA_CHECK_LAUNCH();
     }
     const int total_chunks = cdiv(M, 64);

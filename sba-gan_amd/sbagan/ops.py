@@ -199,6 +199,46 @@ class PackedWeight(object):
         return self._dgrad
 
 
+class ZeroArena(object):
+    """Bump allocator over one pre-zeroed f32 buffer for the many small accumulators of a step
+    (BN statistics, backward reductions): ONE memset per step instead of one fill kernel per layer.
+    Only active between begin() and end() (GANStep.step); otherwise zeros_f32 falls back to
+    torch.zeros, so stand-alone module calls stay safe."""
+
+    def __init__(self):
+        self.buf, self.off, self.active = None, 0, False
+
+    def begin(self, device, nfloats=4 << 20):
+        if self.buf is None or self.buf.device != device or self.buf.numel() < nfloats:
+            self.buf = torch.empty(nfloats, dtype=torch.float32, device=device)
+        self.buf.zero_()
+        self.off, self.active = 0, True
+
+    def end(self):
+        self.active = False
+
+    def take(self, n, device):
+        n4 = (n + 3) // 4 * 4
+        if not self.active or self.buf.device != device or self.off + n4 > self.buf.numel():
+            return None
+        t = self.buf[self.off:self.off + n]
+        self.off += n4
+        return t
+
+
+ARENA = ZeroArena()
+
+
+def zeros_f32(shape, device):
+    n = 1
+    for d in (shape if isinstance(shape, (tuple, list)) else (shape,)):
+        n *= d
+    t = ARENA.take(n, device)
+    if t is None:
+        return torch.zeros(shape, dtype=torch.float32, device=device)
+    return t.view(shape)
+
+
 _WORKSPACE = {}
 WORKSPACE_BYTES = 64 << 20
 
@@ -207,7 +247,7 @@ def workspace(device):
     """Per-device scratch for split-K partial sums (reused by stream-ordered launches)."""
     ws = _WORKSPACE.get(device)
     if ws is None:
-        ws = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        ws = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device=device)   # contract: zero-filled
         _WORKSPACE[device] = ws
     return ws
 
@@ -227,7 +267,7 @@ def conv_forward(x, pw, kind, want_stats=True, addend=None):
     O = pw.param.shape[0]
     OH, OW = _conv_out_hw(kind, H, W)
     y = empty_act(N, O, OH, OW, x)
-    stats = torch.zeros(2 * O, dtype=torch.float32, device=x.device) if want_stats else None
+    stats = zeros_f32(2 * O, x.device) if want_stats else None
     g = _geom((kind, N, H, W, Cin, O, None))
     _igemm(_dt(x), _p(x), _p(pw.fwd(x.dtype)), _p(y), _p(addend), _p(stats), g, x.device)
     return y, stats
@@ -319,7 +359,7 @@ def bn_act_backward(y, dout, st, bn, act, need_param_grad=True):
     Co = C // 2 if act == ACT_GLU else C
     rows = N * H * W
     a = st.aux
-    red = torch.zeros(2 * C, dtype=torch.float32, device=y.device)
+    red = zeros_f32(2 * C, y.device)
     call('sba_bn_act_bwd_reduce', _dt(y), _p(y), _p(dout), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(red),
          rows, C, act, Co, 0, _stream())
     dy = torch.empty_like(y)
@@ -550,10 +590,10 @@ class AttnAdainCatFn(torch.autograd.Function):
         cdf, L = words.shape[1], words.shape[2]
         dev = h.device
         dh = torch.empty_like(h)
-        dsrc = torch.zeros((N, C, L), dtype=torch.float32, device=dev)
+        dsrc = zeros_f32((N, C, L), dev)
         call('sba_word_attn_bwd', _dt(h), _p(h), _p(src), _p(ctx.m8), _p(dout), _p(dh), _p(dsrc), N, HW, C, L,
              ctx.mask_mode, 2 * C, C, 0, _stream())
-        red = torch.zeros((N, C, 2), dtype=torch.float32, device=dev)
+        red = zeros_f32((N, C, 2), dev)
         call('sba_adain_bwd_reduce', _dt(h), _p(h), _p(dout), _p(mr[0]), _p(mr[1]), _p(red), N, HW, C, 2 * C, 0,
              _stream())
         dstyle = torch.empty_like(style)

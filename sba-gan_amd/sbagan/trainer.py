@@ -161,6 +161,7 @@ class GANStep(object):
         """Returns a dict of DEVICE scalars (errD0.., errG_total, kl_loss, g_loss*, w_loss, s_loss)."""
         netG, netsD = self.netG, self.netsD
         out = {}
+        ops.ARENA.begin(self.device)          # one memset for all per-layer accumulators of the step
         netG.ca_net.eps = eps
         fake_imgs, _, mu, logvar = netG(noise, sent_emb, words_embs, mask)
 
@@ -193,6 +194,7 @@ class GANStep(object):
         out['kl_loss'] = kl.detach()
         out.update(logs)
         self.fake_imgs = [f.detach() for f in fake_imgs]
+        ops.ARENA.end()
         return out
 
     def _finish_d(self, i, handle):

@@ -76,6 +76,9 @@ CONV_CASES = [
     ('4x4s2', 2, 512, 256, 8, 8),     # M = 32, K = 8192: split-K path + small-M wgrad
     ('3x3', 4, 256, 512, 4, 4),       # M = 64, K = 2304: split-K with a ragged last split
     ('3x3up', 2, 512, 512, 4, 4),     # generator stage-1 shape
+    ('3x3', 2, 64, 64, 128, 128),     # M = 32768, OW % 64 == 0: all-taps halo-tile wgrad
+    ('3x3up', 2, 64, 128, 64, 64),    # same with the fused nearest x2 (output 128 x 128)
+    ('3x3', 1, 128, 64, 128, 256),    # two ci tiles, non-square map
 ]
 
 
