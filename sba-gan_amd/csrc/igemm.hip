@@ -5,9 +5,29 @@
 //
 // Replaces cuDNN under nn.Conv2d forward/backward in the reference
 // (model.py:32-35 conv3x3, :552 downBlock conv4x4 s2, :41 fused nearest x2).
+#include <math.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
+
+// Division of a pixel index (< 2^21) by a launch-constant: one 64-bit multiply instead of the
+// ~30-instruction integer division sequence (the weight-gradient kernels decode (n, oy, ox) for
+// every staged pixel, which made address generation their bottleneck).
+struct FastDiv {
+    uint64_t magic;     // ceil(2^42 / d), 0 = use the plain division
+    uint32_t d;
+};
+static inline FastDiv make_fastdiv(uint32_t d, int64_t max_n) {
+    FastDiv f;
+    f.d = d;
+    f.magic = (max_n < (1 << 21) && d > 0) ? (((uint64_t)1 << 42) + d - 1) / d : 0;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+    return f.magic ? (uint32_t)(((uint64_t)n * f.magic) >> 42) : n / f.d;
+}
 
 // ---------------------------------------------------------------------------
 // MFMA over one 64-byte K slab held in LDS as rows of ROWB bytes
@@ -72,7 +92,7 @@ template <> struct Mma<float> {
 // pad makes the 16-lane ds_read_b128 groups hit 16 distinct 4-bank slots).
 // ---------------------------------------------------------------------------
 template <typename T, int BM, int BN, int WM, int WN, int KS>
-__global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ x, const T* __restrict__ w,
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                     T* __restrict__ y, const T* __restrict__ addend,
                                                     float* __restrict__ stats, const sba_conv_geom g,
                                                     const int M, float* __restrict__ ws,
@@ -82,9 +102,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ x, con
     constexpr int CH = 16 / (int)sizeof(T);      // elements per 16-byte chunk
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    constexpr int AI = BM / 64, BI = BN / 64;    // 16-byte loads per thread per slab
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves");
-    static_assert(BM % 64 == 0 && BN % 64 == 0, "tile");
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;   // threads: one wave per WM x WN sub-tile
+    constexpr int RP = NT / 4;                       // tile rows staged per pass (4 threads x 16 B per row)
+    constexpr int AI = (BM + RP - 1) / RP, BI = (BN + RP - 1) / RP;    // 16-byte loads per thread per slab
+    static_assert(BM % WM == 0 && BN % WN == 0 && WM % 32 == 0 && WN % 32 == 0, "tile");
     constexpr int TILE_BYTES = (BM + BN) * ROWB;
 
     // KS slabs are staged per barrier (KS > 1 for the small tiles, whose MFMA work per slab is short)
@@ -103,8 +124,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ x, con
     int a_iy0[AI], a_ix0[AI], a_nb[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const int m = m_base + (tid >> 2) + 64 * i;
-        if (m < M) {
+        const int m = m_base + (tid >> 2) + RP * i;
+        if (m < M && (tid >> 2) + RP * i < BM) {
             const int n = m / sub, rem = m - n * sub;
             const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
             a_iy0[i] = oy * g.sy;
@@ -116,7 +137,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ x, con
             a_nb[i] = 0;
         }
     }
-    for (int r = tid; r < BM; r += 256) {
+    for (int r = tid; r < BM; r += NT) {
         const int m = m_base + r;
         int off = -1;
         if (m < M) {
@@ -126,7 +147,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ x, con
         }
         rowoff[r] = off;
     }
-    for (int c = tid; c < 2 * BN; c += 256) s_stat[c] = 0.f;
+    for (int c = tid; c < 2 * BN; c += NT) s_stat[c] = 0.f;
 
     const int cpt = g.Cin / KS_CH;            // slabs per tap
     const int nsteps = g.ntaps * cpt;
@@ -165,9 +186,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ x, con
             }
 #pragma unroll
             for (int i = 0; i < BI; ++i) {
-                const int co = n_base + (tid >> 2) + 64 * i;
+                const int co = n_base + (tid >> 2) + RP * i;
                 rb[k][i] = make_uint4(0, 0, 0, 0);
-                if (live && co < g.Cout) {
+                if (live && co < g.Cout && (tid >> 2) + RP * i < BN) {
                     const T* p = w + (((int64_t)co * g.ntaps + tap) * g.Cin + c0);
                     rb[k][i] = *reinterpret_cast<const uint4*>(p);
                 }
@@ -180,10 +201,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ x, con
             unsigned char* base = lds + (buf * KS + k) * TILE_BYTES;
 #pragma unroll
             for (int i = 0; i < AI; ++i)
-                *reinterpret_cast<uint4*>(base + ((tid >> 2) + 64 * i) * ROWB + chunk * 16) = ra[k][i];
+                if ((tid >> 2) + RP * i < BM)
+                    *reinterpret_cast<uint4*>(base + ((tid >> 2) + RP * i) * ROWB + chunk * 16) = ra[k][i];
 #pragma unroll
             for (int i = 0; i < BI; ++i)
-                *reinterpret_cast<uint4*>(base + (BM + (tid >> 2) + 64 * i) * ROWB + chunk * 16) = rb[k][i];
+                if ((tid >> 2) + RP * i < BN)
+                    *reinterpret_cast<uint4*>(base + (BM + (tid >> 2) + RP * i) * ROWB + chunk * 16) = rb[k][i];
         }
     };
 
@@ -261,7 +284,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const T* __restrict__ x, con
     }
     if (stats) {
         __syncthreads();
-        for (int c = tid; c < BN; c += 256) {
+        for (int c = tid; c < BN; c += NT) {
             const int co = n_base + c;
             if (co < g.Cout) {
                 atomicAdd(&stats[co], s_stat[c]);
@@ -337,7 +360,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                     float* __restrict__ dw, const sba_conv_geom g,
                                                     const int M, const int chunks_per_split,
-                                                    const int use_atomic) {
+                                                    const int use_atomic, const FastDiv dsub, const FastDiv dow) {
     constexpr int ROWS = WgFrag<T>::ROWS;
     constexpr int CH = 16 / (int)sizeof(T);          // elements per 16-byte chunk
     constexpr int CPR = 64 / CH;                     // chunks per 64-channel pixel row
@@ -372,9 +395,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
     const int total_chunks = (M + 63) / 64;
     const int chunk_hi = min(chunk_lo + chunks_per_split, total_chunks);
 
-    for (int ck = chunk_lo; ck < chunk_hi; ++ck) {
+    uint4 va[LPT], vb[LPT];
+    auto gload = [&](int ck) {
         const int m0 = ck * 64 + wid * 16;          // this wave's 16 pixels
-        uint4 va[LPT], vb[LPT];
 #pragma unroll
         for (int u = 0; u < LPT; ++u) {
             const int idx = lane + 64 * u;
@@ -383,8 +406,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
             va[u] = make_uint4(0, 0, 0, 0);
             vb[u] = make_uint4(0, 0, 0, 0);
             if (m < M) {
-                const int n = m / sub, rem = m - n * sub;
-                const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
+                const int n = (int)fdiv(m, dsub), rem = m - n * sub;
+                const int oy = (int)fdiv(rem, dow), ox = rem - oy * g.OWs;
                 const int co = co0 + cc * CH;
                 if (co < g.Cout) {
                     const int64_t po = (int64_t)(n * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox;
@@ -400,6 +423,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
                 }
             }
         }
+    };
+    if (chunk_lo < chunk_hi) gload(chunk_lo);
+    for (int ck = chunk_lo; ck < chunk_hi; ++ck) {
         __syncthreads();    // previous slice fully consumed by this wave's MFMA reads
 #pragma unroll
         for (int u = 0; u < LPT; ++u) {
@@ -409,6 +435,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
             *reinterpret_cast<uint4*>(sb + pix * ROWS + cc * 16) = vb[u];
         }
         __syncthreads();
+        if (ck + 1 < chunk_hi) gload(ck + 1);     // next chunk's loads fly under this chunk's MFMAs
         WgFrag<T>::mma(sa, sb, lane, acc);
     }
 
@@ -448,7 +475,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           float* __restrict__ dw, const sba_conv_geom g,
                                                           const int M, const int chunks_per_split,
-                                                          const int use_atomic) {
+                                                          const int use_atomic, const FastDiv dsub,
+                                                          const FastDiv dow) {
     constexpr int ROWS = WgFrag<T>::ROWS;
     constexpr int CH = 16 / (int)sizeof(T);
     constexpr int CPR = 64 / CH;
@@ -486,9 +514,9 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ 
     const int chunk_lo = blockIdx.z * chunks_per_split;
     const int chunk_hi = min(chunk_lo + chunks_per_split, total_chunks);
 
-    for (int ck = chunk_lo; ck < chunk_hi; ++ck) {
+    uint4 va[APT], vb[LPT];
+    auto gload = [&](int ck) {
         const int m0 = ck * 16;
-        uint4 va[APT], vb[LPT];
 #pragma unroll
         for (int u = 0; u < APT; ++u) {
             const int idx = tid + 256 * u;
@@ -497,8 +525,8 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ 
                 const int pix = idx / CPR, cc = idx - pix * CPR;
                 const int m = m0 + pix, co = co0 + cc * CH;
                 if (m < M && co < g.Cout) {
-                    const int n = m / sub, rem = m - n * sub;
-                    const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
+                    const int n = (int)fdiv(m, dsub), rem = m - n * sub;
+                    const int oy = (int)fdiv(rem, dow), ox = rem - oy * g.OWs;
                     const int64_t po = (int64_t)(n * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox;
                     va[u] = *reinterpret_cast<const uint4*>(dy + po * g.Cout + co);
                 }
@@ -511,8 +539,8 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ 
             const int m = m0 + pix;
             vb[u] = make_uint4(0, 0, 0, 0);
             if (active && m < M) {
-                const int n = m / sub, rem = m - n * sub;
-                const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
+                const int n = (int)fdiv(m, dsub), rem = m - n * sub;
+                const int oy = (int)fdiv(rem, dow), ox = rem - oy * g.OWs;
                 int iy = oy * g.sy + ty, ix = ox * g.sx + tx;
                 const bool ok = (iy >= 0) & (iy < IHL) & (ix >= 0) & (ix < IWL);
                 if (g.ups) { iy >>= 1; ix >>= 1; }
@@ -523,6 +551,9 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ 
                 }
             }
         }
+    };
+    if (chunk_lo < chunk_hi) gload(chunk_lo);
+    for (int ck = chunk_lo; ck < chunk_hi; ++ck) {
         __syncthreads();          // everyone is done reading the previous slices
 #pragma unroll
         for (int u = 0; u < APT; ++u) {
@@ -539,6 +570,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ 
             *reinterpret_cast<uint4*>(sb + pix * ROWS + cc * 16) = vb[u];
         }
         __syncthreads();
+        if (ck + 1 < chunk_hi) gload(ck + 1);
         WgFrag<T>::mma(sa, sb, lane, acc);
     }
 
@@ -605,13 +637,13 @@ __global__ __launch_bounds__(192) void wgrad_rows_kernel(const T* __restrict__ x
 
     const int seg_lo = blockIdx.z * segs_per_wg;
     const int seg_hi = min(seg_lo + segs_per_wg, total_segs);
-    for (int seg = seg_lo; seg < seg_hi; ++seg) {
+    constexpr int A_PT = (64 * CPR + 191) / 192;
+    constexpr int X_PT = (XR * CPR + 63) / 64;
+    uint4 va[A_PT], vx[X_PT];
+    auto gload = [&](int seg) {
         const int n = seg / (g.OH * segs_per_row);
         const int rem = seg - n * g.OH * segs_per_row;
         const int oy = rem / segs_per_row, ox0 = (rem - oy * segs_per_row) * 64;
-        // ---- global loads into registers
-        constexpr int A_PT = (64 * CPR + 191) / 192;
-        uint4 va[A_PT];
 #pragma unroll
         for (int u = 0; u < A_PT; ++u) {
             const int idx = tid + 192 * u;
@@ -625,8 +657,6 @@ __global__ __launch_bounds__(192) void wgrad_rows_kernel(const T* __restrict__ x
                 }
             }
         }
-        constexpr int X_PT = (XR * CPR + 63) / 64;
-        uint4 vx[X_PT];
         int iy = oy + kh - 1;
         const bool row_ok = (iy >= 0) & (iy < IHL);
         if (g.ups) iy >>= 1;
@@ -646,6 +676,9 @@ __global__ __launch_bounds__(192) void wgrad_rows_kernel(const T* __restrict__ x
                 }
             }
         }
+    };
+    if (seg_lo < seg_hi) gload(seg_lo);
+    for (int seg = seg_lo; seg < seg_hi; ++seg) {
         __syncthreads();        // previous segment's tiles fully consumed
 #pragma unroll
         for (int u = 0; u < A_PT; ++u) {
@@ -664,6 +697,7 @@ __global__ __launch_bounds__(192) void wgrad_rows_kernel(const T* __restrict__ x
             }
         }
         __syncthreads();
+        if (seg + 1 < seg_hi) gload(seg + 1);     // prefetch the next segment under the 48 MFMAs below
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -785,44 +819,85 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ 
     }
 }
 
+// ---- tile configurations and their selection --------------------------------------------
+struct IgemmCfg { int bm, bn, ks, occ; float eff; bool split; };
+// A: big square tile, B: wide-M tile for Cout = 64, C: mid tile, D: small tile (+split-K),
+// E: skinny GEMM tile for the 4x4 / 8x8 maps with thousands of channels (+split-K)
+static const IgemmCfg kCfg[5] = {
+    {128, 128, 1, 3, 1.00f, false}, {256, 64, 1, 3, 1.00f, false}, {128, 64, 2, 2, 0.80f, false},
+    {64, 64, 2, 3, 0.50f, true},    {320, 128, 2, 1, 0.90f, true}};
+
+template <typename T, int BM, int BN, int WM, int WN, int KS>
+static void launch_cfg(const T* xp, const T* wp, T* yp, const T* ap, float* stats, const sba_conv_geom& g, int M,
+                       int nslabs, int split, float* ws, hipStream_t st) {
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    int sps = nslabs;
+    if (split > 1) {
+        sps = cdiv(cdiv(nslabs, split), KS) * KS;
+        split = cdiv(nslabs, sps);
+    }
+    dim3 grid(cdiv(M, BM), cdiv(g.Cout, BN), split);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KS>), grid, dim3(NT), 0, st, xp, wp, yp, ap, stats, g, M,
+                       split > 1 ? ws : (float*)nullptr, sps);
+    if (split > 1) {
+        dim3 fgrid(cdiv(g.Cout / 4, 256), cdiv(M, 8));
+        hipLaunchKernelGGL((splitk_finish_kernel<T>), fgrid, dim3(256), 0, st, ws, yp, ap, stats, g, M);
+    }
+}
+
+static int forced_cfg() {
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("SBA_IGEMM_CFG");       // tuning aid only: A..E
+        v = (e && e[0] >= 'A' && e[0] <= 'E') ? e[0] - 'A' : -1;
+    }
+    return v;
+}
+
 template <typename T>
 int launch_igemm(const void* x, const void* w, void* y, const void* addend, float* stats,
                  const sba_conv_geom& g, void* workspace, int64_t ws_bytes, hipStream_t st) {
     const int M = g.N * g.OHs * g.OWs;
     const T* xp = (const T*)x; const T* wp = (const T*)w; T* yp = (T*)y; const T* ap = (const T*)addend;
     const int nslabs = g.ntaps * (g.Cin / (64 / (int)sizeof(T)));
-    if (g.Cout % 128 == 0 && M >= 4096) {
-        dim3 grid(cdiv(M, 128), cdiv(g.Cout, 128));
-        hipLaunchKernelGGL((igemm_kernel<T, 128, 128, 64, 64, 1>), grid, dim3(256), 0, st, xp, wp, yp, ap, stats, g,
-                           M, (float*)nullptr, nslabs);
-    } else if (M >= 8192) {
-        dim3 grid(cdiv(M, 256), cdiv(g.Cout, 64));
-        hipLaunchKernelGGL((igemm_kernel<T, 256, 64, 64, 64, 1>), grid, dim3(256), 0, st, xp, wp, yp, ap, stats, g,
-                           M, (float*)nullptr, nslabs);
+    const bool can_split = workspace && g.Cout % 4 == 0 && (int64_t)M * g.Cout * 4 <= ws_bytes && nslabs >= 16;
+    // Rule table calibrated with tools/bench_conv.py on the B=20 layer shapes (profiles/r01_conv_tiles.txt):
+    //  - GEMM-like maps (M <= 2048): small tile D with split-K;
+    //  - Cout multiple of 128: A when it yields >= 320 workgroups, E (320x128, 10 waves) when it yields
+    //    thousands, otherwise the mid tile C;
+    //  - narrow Cout (64): B when >= 256 workgroups, otherwise C.
+    int best, best_split = 1;
+    const int wgA = (g.Cout % 128 == 0) ? cdiv(M, 128) * (g.Cout / 128) : 0;
+    if (M <= 2048) {
+        best = (g.Cout >= 1024 && (nslabs >= 512 || (M >= 1280 && nslabs >= 256))) ? 4 : 3;
+    } else if (g.Cout == 128 && M >= 40000) {
+        best = 4;
+    } else if (wgA >= 320) {
+        best = 0;
+    } else if (g.Cout <= 64 && cdiv(M, 256) >= 256) {
+        best = 1;
     } else {
-        // small-M (GEMM-like) layers: few output tiles and a long K -> split K over blockIdx.z
-        const int tiles = cdiv(M, 64) * cdiv(g.Cout, 64);
-        int split = 1;
-        if (workspace && tiles < 384 && nslabs >= 32 && g.Cout % 4 == 0 &&
-            (int64_t)M * g.Cout * 4 <= ws_bytes) {
-            split = cdiv(768, tiles);
+        best = 2;
+    }
+    if (forced_cfg() >= 0) best = forced_cfg();
+    {
+        const IgemmCfg& k = kCfg[best];
+        const int tiles = cdiv(M, k.bm) * cdiv(g.Cout, k.bn);
+        const int slots = 256 * k.occ;
+        if (k.split && can_split && tiles < slots) {
+            int split = cdiv(slots, tiles);
             if (split > nslabs / 8) split = nslabs / 8;
             if (split > 32) split = 32;
+            if (split > 1) best_split = split;
         }
-        if (split > 1) {
-            const int sps = cdiv(cdiv(nslabs, split), 4) * 4;      // multiple of the stage depth
-            split = cdiv(nslabs, sps);
-            dim3 grid(cdiv(M, 64), cdiv(g.Cout, 64), split);
-            hipLaunchKernelGGL((igemm_kernel<T, 64, 64, 32, 32, 4>), grid, dim3(256), 0, st, xp, wp, yp, ap, stats,
-                               g, M, (float*)workspace, sps);
-            dim3 fgrid(cdiv(g.Cout / 4, 256), cdiv(M, 8));
-            hipLaunchKernelGGL((splitk_finish_kernel<T>), fgrid, dim3(256), 0, st, (float*)workspace, yp, ap,
-                               stats, g, M);
-        } else {
-            dim3 grid(cdiv(M, 64), cdiv(g.Cout, 64));
-            hipLaunchKernelGGL((igemm_kernel<T, 64, 64, 32, 32, 4>), grid, dim3(256), 0, st, xp, wp, yp, ap, stats,
-                               g, M, (float*)nullptr, nslabs);
-        }
+    }
+    float* ws = (float*)workspace;
+    switch (best) {
+        case 0: launch_cfg<T, 128, 128, 64, 64, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st); break;
+        case 1: launch_cfg<T, 256, 64, 64, 64, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st); break;
+        case 2: launch_cfg<T, 128, 64, 32, 64, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st); break;
+        case 3: launch_cfg<T, 64, 64, 32, 32, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st); break;
+        default: launch_cfg<T, 320, 128, 64, 64, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st); break;
     }
     return SBA_CHECK_LAUNCH();
 }
@@ -864,6 +939,8 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
     const int M = g->N * g->OHs * g->OWs;
     if (ksplit < 1) ksplit = 1;
     const int co_tiles = cdiv(g->Cout, 64), items = cdiv(g->Cin, 64) * g->ntaps;
+    const FastDiv dsub = make_fastdiv((uint32_t)(g->OHs * g->OWs), (int64_t)M + 64);
+    const FastDiv dow = make_fastdiv((uint32_t)g->OWs, (int64_t)M + 64);
     if (M <= 2048 && co_tiles * items >= 256) {
         // GEMM-like layer: one tile per wave, all pixels (ksplit re-derived for this decomposition)
         const int total_chunks = cdiv(M, 16);
@@ -875,7 +952,8 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
         dim3 grid(co_tiles, cdiv(items, 4), split);
         if (grid.y > 65535 || grid.z > 65535) return SBA_E_ARG;
         SBA_DISPATCH(dtype, hipLaunchKernelGGL((wgrad_small_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
-                                               (const T*)x, (const T*)dy, dw, *g, M, cps, split > 1 ? 1 : 0));
+                                               (const T*)x, (const T*)dy, dw, *g, M, cps, split > 1 ? 1 : 0, dsub,
+                                               dow));
         return SBA_CHECK_LAUNCH();
     }
     // generator-style 3x3 stride-1 conv on a wide map: all nine taps per workgroup from halo tiles
@@ -885,8 +963,11 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
     if (rows_ok) {
         const int total_segs = g->N * g->OH * (g->OW / 64);
         const int ci_t = cdiv(g->Cin, 64);
-        int nz = cdiv(512, co_tiles * ci_t);
-        if (nz > total_segs) nz = total_segs;
+        // every pixel split adds a full copy of the tile's 9 x 64 x 64 outputs to the f32 atomics
+        // (~1.3 TB/s chip-wide), so use few, fat workgroups: ~1 per CU and >= 16 segments each
+        int nz = cdiv(256, co_tiles * ci_t);
+        if (nz > total_segs / 16) nz = total_segs / 16;
+        if (nz < 1) nz = 1;
         const int spw = cdiv(total_segs, nz);
         nz = cdiv(total_segs, spw);
         dim3 grid(co_tiles, ci_t, nz);
@@ -902,7 +983,8 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
     dim3 grid(co_tiles, items, ksplit);
     if (grid.y > 65535 || grid.z > 65535) return SBA_E_ARG;
     SBA_DISPATCH(dtype, hipLaunchKernelGGL((wgrad_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
-                                           (const T*)x, (const T*)dy, dw, *g, M, cps, ksplit > 1 ? 1 : 0));
+                                           (const T*)x, (const T*)dy, dw, *g, M, cps, ksplit > 1 ? 1 : 0, dsub,
+                                           dow));
     return SBA_CHECK_LAUNCH();
 }
 

@@ -305,8 +305,8 @@ def conv_dgrad(dy, pw, kind, in_hw, addend=None):
 
 def _ksplit(tiles, M):
     chunks = (M + 63) // 64
-    want = max(1, (1536 + tiles - 1) // tiles)
-    return max(1, min(want, chunks))
+    want = max(1, (640 + tiles - 1) // tiles)       # ~2.5 workgroups per CU ...
+    return max(1, min(want, chunks // 4 if chunks >= 8 else 1))   # ... each with >= 4 pixel chunks
 
 
 def conv_wgrad(x, dy, param, kind):
