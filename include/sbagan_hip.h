@@ -90,6 +90,9 @@ int sba_bn_finalize(const float* stats, const float* gamma, const float* beta, f
                     float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
                     float* mean, float* rstd, int C, int64_t count, float eps, float momentum,
                     void* stream);
+/* stats[0..C) += sum(y), stats[C..2C) += sum(y^2) over `rows` NHWC rows (caller zeroes): used when one
+ * conv launch covers several BatchNorm batches (real | fake), so the conv epilogue cannot split them. */
+int sba_bn_stats(int dtype, const void* y, float* stats, int64_t rows, int C, void* stream);
 /* out = act(y*scale+shift) (+ residual).  GLU halves the channel count.  out may have a larger
  * channel stride (out_cstride) and offset (out_coff) so that it can be written into a concat. */
 int sba_bn_act_fwd(int dtype, const void* y, const float* scale, const float* shift,

@@ -60,12 +60,19 @@ __global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) s[t] = 0.f;
     if (tid < R) {
-        for (int c = 0; c < nef; ++c) {
-            const float fv = fj[(int64_t)c * R + tid];
-            const float* qr = &L.q[c * Lw];
+        // 8 independent loads in flight per thread (a dependent load -> FMA chain made this
+        // phase pure latency)
+        for (int c0 = 0; c0 < nef; c0 += 8) {
+            float fv8[8];
 #pragma unroll
-            for (int t = 0; t < TMAX; ++t)
-                if (t < Lw) s[t] += fv * qr[t];
+            for (int k = 0; k < 8; ++k) fv8[k] = fj[(int64_t)(c0 + k) * R + tid];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float* qr = &L.q[(c0 + k) * Lw];
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t)
+                    if (t < Lw) s[t] += fv8[k] * qr[t];
+            }
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -200,12 +207,17 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) dA[t] = 0.f;
     if (tid < R) {
-        for (int c = 0; c < nef; ++c) {
-            const float fv = fj[(int64_t)c * R + tid];
-            const float* wr = &L.w[c * Lw];
+        for (int c0 = 0; c0 < nef; c0 += 8) {
+            float fv8[8];
 #pragma unroll
-            for (int t = 0; t < TMAX; ++t)
-                if (t < Lw) dA[t] += fv * wr[t];
+            for (int k = 0; k < 8; ++k) fv8[k] = fj[(int64_t)(c0 + k) * R + tid];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float* wr = &L.w[(c0 + k) * Lw];
+#pragma unroll
+                for (int t = 0; t < TMAX; ++t)
+                    if (t < Lw) dA[t] += fv8[k] * wr[t];
+            }
         }
 #pragma unroll
         for (int t = 0; t < TMAX; ++t)

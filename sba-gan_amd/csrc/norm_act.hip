@@ -35,6 +35,38 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float*
     }
 }
 
+// ---- batch statistics of an NHWC tensor (used when the conv epilogue cannot provide them:
+//      grouped passes, where one conv launch covers several BatchNorm batches) ----
+template <typename T>
+__global__ void bn_stats_kernel(const T* __restrict__ y, float* __restrict__ stats, int64_t rows, int C) {
+    constexpr int V = Vec16<T>::N;
+    const int cv = C / V;
+    extern __shared__ float s_acc[];                        // [2*C]
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.f;
+    __syncthreads();
+    const int tpr = cv < (int)blockDim.x ? cv : (int)blockDim.x;
+    const int rpi = blockDim.x / tpr;
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
+    for (int cvi = tc; cvi < cv; cvi += tpr) {
+        const int c = cvi * V;
+        float s0[V], s1[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) s0[k] = s1[k] = 0.f;
+        for (int64_t row = (int64_t)blockIdx.x * rpi + tr; row < rows; row += (int64_t)gridDim.x * rpi) {
+            Vec16<T> a = ld16(y + row * C + c);
+#pragma unroll
+            for (int k = 0; k < V; ++k) { const float v = a.get(k); s0[k] += v; s1[k] += v * v; }
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            atomicAdd(&s_acc[c + k], s0[k]);
+            atomicAdd(&s_acc[C + c + k], s1[k]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&stats[i], s_acc[i]);
+}
+
 // ---- forward: out = act(y*scale+shift) (+residual) ----
 template <typename T, int ACT>
 __global__ void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
@@ -429,6 +461,19 @@ extern "C" int sba_bn_finalize(const float* stats, const float* gamma, const flo
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, gamma,
                        beta, running_mean, running_var, nbt, scale, shift, mean, rstd, C, (float)count, eps,
                        momentum);
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_bn_stats(int dtype, const void* y, float* stats, int64_t rows, int C, void* stream) {
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    if (!y || !stats || rows <= 0 || C <= 0 || C % V || !pow2(C / V) || C > 4096) return SBA_E_ARG;
+    const int cv = C / V;
+    const int rpi = cv < 256 ? 256 / cv : 1;
+    int blocks = cdiv(rows, (int64_t)rpi * 8);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(blocks), dim3(256), 2 * (size_t)C * sizeof(float),
+                                           (hipStream_t)stream, (const T*)y, stats, rows, C));
     return SBA_CHECK_LAUNCH();
 }
 

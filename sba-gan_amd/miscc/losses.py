@@ -27,6 +27,7 @@ def cosine_similarity(x1, x2, dim=1, eps=1e-8):
 
 
 _MASK_CACHE = {}
+BATCH_REAL_FAKE = True
 
 
 def class_mask(class_ids, batch_size, device):
@@ -74,8 +75,15 @@ def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size)
 def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake_labels):
     """losses.py:136-161: two separate trunk passes (real, fake.detach()), five heads,
     errD = (real + cond_real)/2 + (fake + cond_fake + cond_wrong)/3."""
-    real_features = netD(real_imgs)
-    fake_features = netD(fake_imgs.detach())
+    if BATCH_REAL_FAKE and real_imgs.shape == fake_imgs.shape:
+        # one trunk pass over [real | fake] with per-half BatchNorm batches: same results and module
+        # state as the reference's two calls, half the launches and weight reads
+        n = real_imgs.size(0)
+        feats = netD(torch.cat((real_imgs, fake_imgs.detach()), 0), groups=2)
+        real_features, fake_features = feats[:n], feats[n:]
+    else:
+        real_features = netD(real_imgs)
+        fake_features = netD(fake_imgs.detach())
     cond_real = netD.COND_DNET(real_features, conditions)
     cond_fake = netD.COND_DNET(fake_features, conditions)
     batch_size = real_features.size(0)

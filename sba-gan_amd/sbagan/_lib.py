@@ -42,6 +42,7 @@ SIGNATURES = {
     'sba_pack_weight': [I, P, P, I, I, I, I, I, P],
     'sba_pool2x2_sum': [I, P, P, I, I, I, I, P],
     'sba_bn_finalize': [P, P, P, P, P, P, P, P, P, P, I, L, F, F, P],
+    'sba_bn_stats': [I, P, P, L, I, P],
     'sba_bn_act_fwd': [I, P, P, P, P, P, L, I, I, I, I, P],
     'sba_bn_act_bwd_reduce': [I, P, P, P, P, P, P, P, L, I, I, I, I, P],
     'sba_bn_act_bwd_apply': [I, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P],

@@ -73,9 +73,10 @@ class _ConvBNAct(nn.Sequential):
             self.__dict__['_l'] = l
         return l
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, groups=1):
         l = self._layer()
-        return ops.ConvBNActFn.apply(x, l.conv.weight, l.bn.weight, l.bn.bias, l, self.kind, self.act, residual)
+        return ops.ConvBNActFn.apply(x, l.conv.weight, l.bn.weight, l.bn.bias, l, self.kind, self.act, residual,
+                                     groups)
 
 
 class _UpBlock(_ConvBNAct):
@@ -398,10 +399,11 @@ class _EncodeBy16(nn.Sequential):
             self.__dict__['_ls'] = [_Layer(self[2], self[3]), _Layer(self[5], self[6]), _Layer(self[8], self[9])]
         return self.__dict__['_ls']
 
-    def forward(self, x):
+    def forward(self, x, groups=1):
         h = ops.DStemFn.apply(x, self[0].weight)
         for l in self._layers():
-            h = ops.ConvBNActFn.apply(h, l.conv.weight, l.bn.weight, l.bn.bias, l, '4x4s2', ACT_LRELU, None)
+            h = ops.ConvBNActFn.apply(h, l.conv.weight, l.bn.weight, l.bn.bias, l, '4x4s2', ACT_LRELU, None,
+                                      groups)
         return h
 
 
@@ -448,8 +450,10 @@ class D_NET64(_DBase):
         self.img_code_s16 = encode_image_by_16times(ndf)
         self._heads(b_jcu)
 
-    def forward(self, x_var):
-        return self.img_code_s16(x_var)
+    def forward(self, x_var, groups=1):
+        """groups > 1: x_var holds that many independent batches back to back (e.g. real | fake);
+        BatchNorm treats each as its own batch, exactly like separate calls (see ops.ConvBNActFn)."""
+        return self.img_code_s16(x_var, groups)
 
 
 class D_NET128(_DBase):
@@ -463,10 +467,10 @@ class D_NET128(_DBase):
         self.img_code_s32_1 = Block3x3_leakRelu(ndf * 16, ndf * 8)
         self._heads(b_jcu)
 
-    def forward(self, x_var):
-        x = self.img_code_s16(x_var)
-        x = self.img_code_s32(x)
-        return self.img_code_s32_1(x)
+    def forward(self, x_var, groups=1):
+        x = self.img_code_s16(x_var, groups)
+        x = self.img_code_s32(x, groups=groups)
+        return self.img_code_s32_1(x, groups=groups)
 
 
 class D_NET256(_DBase):
@@ -482,12 +486,12 @@ class D_NET256(_DBase):
         self.img_code_s64_2 = Block3x3_leakRelu(ndf * 16, ndf * 8)
         self._heads(b_jcu)
 
-    def forward(self, x_var):
-        x = self.img_code_s16(x_var)
-        x = self.img_code_s32(x)
-        x = self.img_code_s64(x)
-        x = self.img_code_s64_1(x)
-        return self.img_code_s64_2(x)
+    def forward(self, x_var, groups=1):
+        x = self.img_code_s16(x_var, groups)
+        x = self.img_code_s32(x, groups=groups)
+        x = self.img_code_s64(x, groups=groups)
+        x = self.img_code_s64_1(x, groups=groups)
+        return self.img_code_s64_2(x, groups=groups)
 
 
 # ----------------------------------------------------------------------------

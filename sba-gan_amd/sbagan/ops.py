@@ -345,16 +345,17 @@ def bn_prepare(stats, bn, rows, training):
     return st
 
 
-def bn_act_forward(y, st, act, residual=None):
+def bn_act_forward(y, st, act, residual=None, out=None):
     N, C, H, W = y.shape
     Co = C // 2 if act == ACT_GLU else C
-    out = empty_act(N, Co, H, W, y)
+    if out is None:
+        out = empty_act(N, Co, H, W, y)
     call('sba_bn_act_fwd', _dt(y), _p(y), _p(st.aux[0]), _p(st.aux[1]), _p(residual), _p(out), N * H * W, C,
          act, Co, 0, _stream())
     return out
 
 
-def bn_act_backward(y, dout, st, bn, act, need_param_grad=True):
+def bn_act_backward(y, dout, st, bn, act, need_param_grad=True, dy=None):
     N, C, H, W = y.shape
     Co = C // 2 if act == ACT_GLU else C
     rows = N * H * W
@@ -362,13 +363,22 @@ def bn_act_backward(y, dout, st, bn, act, need_param_grad=True):
     red = zeros_f32(2 * C, y.device)
     call('sba_bn_act_bwd_reduce', _dt(y), _p(y), _p(dout), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(red),
          rows, C, act, Co, 0, _stream())
-    dy = torch.empty_like(y)
+    if dy is None:
+        dy = torch.empty_like(y)
     dg = db = None
     if need_param_grad:
         dg, db = param_grad(bn.weight), param_grad(bn.bias)
     call('sba_bn_act_bwd_apply', _dt(y), _p(y), _p(dout), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]),
          _p(bn.weight), _p(red), _p(dy), _p(dg), _p(db), rows, C, act, Co, 0, _stream())
     return dy
+
+
+def bn_stats(y):
+    """per-channel (sum, sumsq) of an NHWC tensor by a separate pass (grouped batches)."""
+    N, C, H, W = y.shape
+    stats = zeros_f32(2 * C, y.device)
+    call('sba_bn_stats', _dt(y), _p(y), _p(stats), N * H * W, C, _stream())
+    return stats
 
 
 # ----------------------------------------------------------------------------
@@ -383,16 +393,34 @@ def _c(t):
 
 class ConvBNActFn(torch.autograd.Function):
     """conv (3x3 / nearest-x2 + 3x3 / 4x4 s2) -> BatchNorm(train) -> GLU | LeakyReLU | none (+ residual).
-    upBlock model.py:39-45, Block3x3_leakRelu :540-546, downBlock :550-556, ResBlock halves :60-65."""
+    upBlock model.py:39-45, Block3x3_leakRelu :540-546, downBlock :550-556, ResBlock halves :60-65.
+
+    groups > 1: the batch holds `groups` independent BatchNorm batches back to back (the
+    discriminator's real | fake passes, losses.py:139-140): ONE conv / dgrad / wgrad launch over
+    the whole batch, BatchNorm statistics, running-stat updates and normalisation per group in
+    order -- bit-for-bit the same module state as calling the block once per group."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, layer, kind, act, residual):
+    def forward(ctx, x, weight, gamma, beta, layer, kind, act, residual, groups=1):
         x = as_act(x)
-        y, stats = conv_forward(x, layer.pw, kind)
-        N, C, H, W = y.shape
-        st = bn_prepare(stats, layer.bn, N * H * W, layer.bn.training)
-        out = bn_act_forward(y, st, act, residual)
-        ctx.layer, ctx.kind, ctx.act, ctx.st = layer, kind, act, st
+        if groups == 1:
+            y, stats = conv_forward(x, layer.pw, kind)
+            N, C, H, W = y.shape
+            sts = [bn_prepare(stats, layer.bn, N * H * W, layer.bn.training)]
+            out = bn_act_forward(y, sts[0], act, residual)
+        else:
+            assert residual is None and x.shape[0] % groups == 0
+            y, _ = conv_forward(x, layer.pw, kind, want_stats=False)
+            N, C, H, W = y.shape
+            ng = N // groups
+            out = empty_act(N, C // 2 if act == ACT_GLU else C, H, W, y)
+            sts = []
+            for g in range(groups):
+                yg = y[g * ng:(g + 1) * ng]
+                st = bn_prepare(bn_stats(yg), layer.bn, ng * H * W, layer.bn.training)
+                bn_act_forward(yg, st, act, out=out[g * ng:(g + 1) * ng])
+                sts.append(st)
+        ctx.layer, ctx.kind, ctx.act, ctx.sts, ctx.groups = layer, kind, act, sts, groups
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, y)
         return out
@@ -400,16 +428,23 @@ class ConvBNActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x, y = ctx.saved_tensors
-        layer, kind, act = ctx.layer, ctx.kind, ctx.act
+        layer, kind, act, groups = ctx.layer, ctx.kind, ctx.act, ctx.groups
         dout = _c(dout)
-        dy = bn_act_backward(y, dout, ctx.st, layer.bn, act, ctx.needs_input_grad[2])
+        if groups == 1:
+            dy = bn_act_backward(y, dout, ctx.sts[0], layer.bn, act, ctx.needs_input_grad[2])
+        else:
+            dy = torch.empty_like(y)
+            ng = y.shape[0] // groups
+            for g in range(groups):
+                sl = slice(g * ng, (g + 1) * ng)
+                bn_act_backward(y[sl], dout[sl], ctx.sts[g], layer.bn, act, ctx.needs_input_grad[2], dy=dy[sl])
         if ctx.needs_input_grad[1]:
             conv_wgrad(x, dy, layer.conv.weight, kind)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad(dy, layer.pw, kind, x.shape[2:])
         dres = dout if (ctx.has_res and ctx.needs_input_grad[7]) else None
-        return dx, None, None, None, None, None, None, dres
+        return dx, None, None, None, None, None, None, dres, None
 
 
 class ResBlockFn(torch.autograd.Function):

@@ -440,3 +440,43 @@ def test_errors_are_loud(dev):
         ops.conv_forward(x, ops.PackedWeight(w), '3x3')
     with pytest.raises(RuntimeError):      # CPU tensors never silently fall back
         ops.LinearFn.apply(torch.zeros(2, 3), torch.zeros(4, 3), None)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_grouped_real_fake_pass_equals_two_calls(dev, dt):
+    """netD(cat(real, fake), groups=2) == (netD(real), netD(fake)): features, BatchNorm buffers
+    (running stats updated twice, in order) and parameter gradients."""
+    import copy
+    from sbagan import nets, ops
+    from miscc.config import cfg
+    ops.set_compute_dtype(dt)
+    cfg.GAN.DF_DIM = 64
+    d1 = nets.D_NET128()
+    P = fill.fill_state_dict({k: tuple(v.shape) for k, v in d1.state_dict().items()})
+    d1.load_state_dict(P)
+    d2 = copy.deepcopy(d1)
+    d1.to(dev).train(); d2.to(dev).train()
+    B = 3
+    real, fake = fill.uniform((B, 3, 128, 128), 1).to(dev), fill.uniform((B, 3, 128, 128), 2).to(dev)
+    g = fill.unit((2 * B, 512, 4, 4), 3).to(dev).to(dt).contiguous(memory_format=torch.channels_last)
+    f1 = d1(torch.cat((real, fake), 0), groups=2)
+    f1.backward(g)
+    fr, ff = d2(real), d2(fake)
+    (fr * g[:B].float()).sum().backward()
+    (ff * g[B:].float()).sum().backward()
+    torch.cuda.synchronize()
+    # (the grouped pass takes its BN statistics from the stored activations, the single pass from the
+    # f32 accumulators of the conv epilogue: equal up to rounding)
+    close(f1[:B], fr, dt, 'real half', scale=0.2 if dt == torch.float32 else 0.6)
+    close(f1[B:], ff, dt, 'fake half', scale=0.2 if dt == torch.float32 else 0.6)
+    for (n, a), (_, b) in zip(d1.named_buffers(), d2.named_buffers()):
+        if n.endswith('num_batches_tracked'):
+            assert int(a) == int(b) == (2 if 'img_code' in n else 0), n
+        else:
+            close(a, b, torch.float32, n, scale=10 if dt == torch.float32 else 300)
+    for (n, a), (_, b) in zip(d1.named_parameters(), d2.named_parameters()):
+        if b.grad is None:
+            assert a.grad is None
+            continue
+        r = rel_l2(a.grad, b.grad)
+        assert r < (2e-4 if dt == torch.float32 else 3e-2), (n, r)
