@@ -99,7 +99,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
                                                     const int slabs_per_split) {
     constexpr int ROWB = 80;
     constexpr int KS_CH = 64 / (int)sizeof(T);   // channels per slab
-    constexpr int CH = 16 / (int)sizeof(T);      // elements per 16-byte chunk
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int NT = (BM / WM) * (BN / WN) * 64;   // threads: one wave per WM x WN sub-tile
@@ -164,35 +163,68 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
     const int s_begin = blockIdx.z * slabs_per_split;
     const int s_end = min(s_begin + slabs_per_split, nsteps);
 
+    // Address generation is hoisted out of the per-slab path: slabs are consumed in order, so the
+    // (tap, channel-slab) position is tracked incrementally (no division), the per-row gather
+    // offsets are recomputed only when the tap changes, and everything is 32-bit byte offsets
+    // (tensors are < 4 GiB, checked on the host).
+    // Loads are BRANCH-FREE buffer loads: an out-of-image tap, a row beyond M or a slab beyond this
+    // split's range gets the offset 0xFFFFFFFF, which the buffer bounds check turns into zeros.
+    int g_tap = s_begin / cpt, g_c = s_begin - g_tap * cpt, g_step = s_begin;
+    int cur_tap = -1;
+    constexpr uint32_t OOB = 0xFFFFFFFFu;
+    uint32_t a_off[AI];           // byte offset of (n, iy, ix, channel 0) for the current tap, or OOB
+#pragma unroll
+    for (int i = 0; i < AI; ++i) a_off[i] = OOB;
+    uint32_t w_off[BI];           // byte offset of (co, slab, chunk); K is contiguous per co
+    const uint32_t krow_bytes = (uint32_t)g.ntaps * (uint32_t)g.Cin * (uint32_t)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int r = (tid >> 2) + RP * i;
+        const int co = n_base + r;
+        const bool ok = (co < g.Cout) && (r < BN);
+        w_off[i] = ok ? (uint32_t)co * krow_bytes + (uint32_t)s_begin * 64u + (uint32_t)chunk * 16u : OOB;
+    }
+    const uint32_t x_bytes = (uint32_t)((int64_t)g.N * g.IH * g.IW * g.Cin * (int64_t)sizeof(T));
+    const uint32_t w_bytes = (uint32_t)g.Cout * krow_bytes;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, w_bytes, 0x00020000);
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
     uint4 ra[KS][AI], rb[KS][BI];
-    auto gload = [&](int stage) {
+    auto gload = [&](int /*stage*/) {
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-            const int step = s_begin + stage * KS + k;
-            const bool live = step < s_end;
-            const int tap = live ? step / cpt : 0;
-            const int c0 = (live ? (step - tap * cpt) * KS_CH : 0) + chunk * CH;
-            const int ty = (int)((tyb >> (4 * tap)) & 15) - 8, tx = (int)((txb >> (4 * tap)) & 15) - 8;
+            const bool live = g_step < s_end;
+            if (g_tap != cur_tap) {                     // (uniform) new tap: refresh the gather offsets
+                cur_tap = g_tap;
+                const int tsel = g_tap < SBA_MAX_TAPS ? g_tap : 0;
+                const int ty = (int)((tyb >> (4 * tsel)) & 15) - 8, tx = (int)((txb >> (4 * tsel)) & 15) - 8;
+#pragma unroll
+                for (int i = 0; i < AI; ++i) {
+                    int iy = a_iy0[i] + ty, ix = a_ix0[i] + tx;
+                    const bool ok = (iy >= 0) & (iy < IHL) & (ix >= 0) & (ix < IWL);
+                    if (g.ups) { iy >>= 1; ix >>= 1; }
+                    const uint32_t o = (uint32_t)(a_nb[i] + iy * g.IW + ix) * (uint32_t)(g.Cin * (int)sizeof(T)) +
+                                       (uint32_t)chunk * 16u;
+                    a_off[i] = ok ? o : OOB;
+                }
+            }
+            const uint32_t cbytes = (uint32_t)g_c * 64u;
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
-                int iy = a_iy0[i] + ty, ix = a_ix0[i] + tx;
-                const bool ok = live & (iy >= 0) & (iy < IHL) & (ix >= 0) & (ix < IWL);
-                if (g.ups) { iy >>= 1; ix >>= 1; }
-                ra[k][i] = make_uint4(0, 0, 0, 0);
-                if (ok) {
-                    const T* p = x + ((int64_t)(a_nb[i] + iy * g.IW + ix) * g.Cin + c0);
-                    ra[k][i] = *reinterpret_cast<const uint4*>(p);
-                }
+                const uint32_t o = (live && a_off[i] != OOB) ? a_off[i] + cbytes : OOB;
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xr, o, 0, 0);
+                ra[k][i] = make_uint4(v[0], v[1], v[2], v[3]);
             }
 #pragma unroll
             for (int i = 0; i < BI; ++i) {
-                const int co = n_base + (tid >> 2) + RP * i;
-                rb[k][i] = make_uint4(0, 0, 0, 0);
-                if (live && co < g.Cout && (tid >> 2) + RP * i < BN) {
-                    const T* p = w + (((int64_t)co * g.ntaps + tap) * g.Cin + c0);
-                    rb[k][i] = *reinterpret_cast<const uint4*>(p);
-                }
+                const uint32_t o = (live && w_off[i] != OOB) ? w_off[i] : OOB;
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wr, o, 0, 0);
+                rb[k][i] = make_uint4(v[0], v[1], v[2], v[3]);
+                if (w_off[i] != OOB) w_off[i] += 64u;
             }
+            ++g_step;
+            if (++g_c == cpt) { g_c = 0; ++g_tap; }
         }
     };
     auto lstore = [&](int buf) {
@@ -253,6 +285,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col_l = lane & 31, rsel = 4 * (lane >> 5);
+    constexpr bool kStageOut = sizeof(T) == 2;       // bf16: transpose through LDS -> 16-byte row stores
+    constexpr int OROW = BN * 2 + 16;                // staged output row: BN bf16 + 16 B pad
+    static_assert(!kStageOut || BM * OROW <= 2 * KS * TILE_BYTES, "output tile fits in the staging buffers");
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int co = n_base + wn0 + j * 32 + col_l;
@@ -262,14 +297,19 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
-                const int pix = rowoff[row];
                 float v = acc[i][j][r];
                 csum += v;
                 csq += v * v;
-                if (pix >= 0 && co < g.Cout) {
-                    const int64_t o = (int64_t)pix * g.Cout + co;
-                    if (addend) v += to_f<T>(addend[o]);
-                    y[o] = from_f<T>(v);
+                if (kStageOut) {
+                    // (the main loop's last barrier has passed: the staging buffers are free)
+                    *reinterpret_cast<T*>(lds + row * OROW + (wn0 + j * 32 + col_l) * 2) = from_f<T>(v);
+                } else {
+                    const int pix = rowoff[row];
+                    if (pix >= 0 && co < g.Cout) {
+                        const int64_t o = (int64_t)pix * g.Cout + co;
+                        if (addend) v += to_f<T>(addend[o]);
+                        y[o] = from_f<T>(v);
+                    }
                 }
             }
         }
@@ -282,8 +322,36 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
             }
         }
     }
+    if (kStageOut || stats) __syncthreads();
+    if (kStageOut) {
+        constexpr int CPRO = BN / 8;                 // 16-byte chunks per output row
+        for (int idx = tid; idx < BM * CPRO; idx += NT) {
+            const int row = idx / CPRO, cc = idx - row * CPRO;
+            const int pix = rowoff[row];
+            const int co = n_base + cc * 8;
+            if (pix < 0 || co >= g.Cout) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(lds + row * OROW + cc * 16);
+            const int64_t o = (int64_t)pix * g.Cout + co;
+            if (co + 8 <= g.Cout) {
+                if (addend) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(addend + o);
+                    const bf16_t* ap = reinterpret_cast<const bf16_t*>(&a);
+                    bf16_t* vp = reinterpret_cast<bf16_t*>(&v);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) vp[k] = f2bf(bf2f(vp[k]) + bf2f(ap[k]));
+                }
+                *reinterpret_cast<uint4*>(y + o) = v;
+            } else {                                  // ragged Cout tail: scalar
+                const bf16_t* vp = reinterpret_cast<const bf16_t*>(&v);
+                for (int k = 0; k < 8 && co + k < g.Cout; ++k) {
+                    float f = bf2f(vp[k]);
+                    if (addend) f += to_f<T>(addend[o + k]);
+                    y[o + k] = from_f<T>(f);
+                }
+            }
+        }
+    }
     if (stats) {
-        __syncthreads();
         for (int c = tid; c < BN; c += NT) {
             const int co = n_base + c;
             if (co < g.Cout) {
@@ -915,6 +983,9 @@ bool geom_ok(const sba_conv_geom* g, int dtype) {
     if ((g->OHs - 1) * g->osy + g->ooy >= g->OH || (g->OWs - 1) * g->osx + g->oox >= g->OW) return false;
     if (g->ooy < 0 || g->oox < 0) return false;
     if ((int64_t)g->N * g->OHs * g->OWs > 0x7fffffff) return false;
+    const int64_t esz = dtype == SBA_BF16 ? 2 : 4;
+    if ((int64_t)g->N * g->IH * g->IW * g->Cin * esz >= ((int64_t)1 << 32)) return false;    // 32-bit byte offsets
+    if ((int64_t)g->Cout * g->ntaps * g->Cin * esz >= ((int64_t)1 << 32)) return false;
     if ((int64_t)g->N * g->IH * g->IW > 0x7fffffff / 2 || (int64_t)g->N * g->OH * g->OW > 0x7fffffff / 2)
         return false;
     return true;
