@@ -43,6 +43,7 @@ def parse():
                     help='CNN_ENCODER inside the G step: the Inception-v3 trunk (PyTorch-ROCm/MIOpen, '
                          'third-party arithmetic) or the light stand-in used by the parity fixtures')
     ap.add_argument('--graph', type=int, default=1, help='replay the step from a captured hipGraph')
+    ap.add_argument('--phases', action='store_true', help='also print per-phase times of an eager step (stderr)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     return ap.parse_args()
@@ -170,6 +171,16 @@ def main():
         return step.step(b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'], b['class_ids'],
                          noise)
 
+    if args.phases:
+        for _ in range(3):
+            one_step()
+        step.phase_events = []
+        one_step()
+        torch.cuda.synchronize()
+        ev = step.phase_events
+        step.phase_events = None
+        sys.stderr.write('phases (eager, ms): ' + ', '.join(
+            '%s %.2f' % (ev[i + 1][0], ev[i][1].elapsed_time(ev[i + 1][1])) for i in range(len(ev) - 1)) + '\n')
     graph = None
     mode = 'eager'
     n_eager = max(args.warmup, 3) if args.graph else args.warmup
@@ -181,11 +192,11 @@ def main():
             graph = torch.cuda.CUDAGraph()
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
+            with torch.cuda.stream(s):          # warm the capture stream (per-stream workspaces exist)
                 one_step()
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=s):
                 out = one_step()
             torch.cuda.synchronize()
             for _ in range(2):

@@ -97,33 +97,54 @@ def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake
 
 
 def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sent_emb, match_labels,
-                   cap_lens, class_ids):
+                   cap_lens, class_ids, streams=None):
     """losses.py:164-206.  Returns (errG_total, logs) where logs is a dict of device scalars
-    {'g_loss0', ..., 'w_loss', 's_loss'} (format with .item() outside the step)."""
+    {'g_loss0', ..., 'w_loss', 's_loss'} (format with .item() outside the step).
+
+    streams (optional, len(netsD) + 1 HIP streams): the per-discriminator terms and the
+    encoder + DAMSM term are independent branches (forward and backward), so each may run on its
+    own stream; autograd replays every branch's backward on the stream of its forward."""
+    import contextlib
     numDs = len(netsD)
     batch_size = real_labels.size(0)
     logs = {}
+    main = torch.cuda.current_stream() if streams else None
+
+    def branch(k):
+        if not streams:
+            return contextlib.nullcontext()
+        streams[k].wait_stream(main)
+        return torch.cuda.stream(streams[k])
+
+    terms = []
+    for i in range(numDs):
+        with branch(i):
+            features = netsD[i](fake_imgs[i])
+            cond_logits = netsD[i].COND_DNET(features, sent_emb)
+            if netsD[i].UNCOND_DNET is not None:
+                logits = netsD[i].UNCOND_DNET(features)
+                g_loss = ops.BCEMultiFn.apply((1., 1.), (1., 1.), logits, cond_logits)
+            else:
+                g_loss = ops.BCEMultiFn.apply((1.,), (1.,), cond_logits)
+        terms.append(g_loss)
+        logs['g_loss%d' % i] = g_loss.detach()
+    # ranking loss on the last scale (losses.py:187-204)
+    with branch(numDs):
+        region_features, cnn_code = image_encoder(fake_imgs[numDs - 1])
+        w_loss0, w_loss1, _ = words_loss(region_features, words_embs, match_labels, cap_lens, class_ids,
+                                         batch_size)
+        w_loss = (w_loss0 + w_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+        s_loss0, s_loss1 = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size)
+        s_loss = (s_loss0 + s_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+    if streams:
+        for st in streams[:numDs + 1]:
+            main.wait_stream(st)
     errG_total = 0
     for i in range(numDs):
-        features = netsD[i](fake_imgs[i])
-        cond_logits = netsD[i].COND_DNET(features, sent_emb)
-        if netsD[i].UNCOND_DNET is not None:
-            logits = netsD[i].UNCOND_DNET(features)
-            g_loss = ops.BCEMultiFn.apply((1., 1.), (1., 1.), logits, cond_logits)
-        else:
-            g_loss = ops.BCEMultiFn.apply((1.,), (1.,), cond_logits)
-        errG_total = errG_total + g_loss
-        logs['g_loss%d' % i] = g_loss.detach()
-        if i == (numDs - 1):
-            region_features, cnn_code = image_encoder(fake_imgs[i])
-            w_loss0, w_loss1, _ = words_loss(region_features, words_embs, match_labels, cap_lens,
-                                             class_ids, batch_size)
-            w_loss = (w_loss0 + w_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
-            s_loss0, s_loss1 = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size)
-            s_loss = (s_loss0 + s_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
-            errG_total = errG_total + w_loss + s_loss
-            logs['w_loss'] = w_loss.detach()
-            logs['s_loss'] = s_loss.detach()
+        errG_total = errG_total + terms[i]          # same summation order as the reference
+    errG_total = errG_total + w_loss + s_loss
+    logs['w_loss'] = w_loss.detach()
+    logs['s_loss'] = s_loss.detach()
     return errG_total, logs
 
 

@@ -244,11 +244,15 @@ WORKSPACE_BYTES = 64 << 20
 
 
 def workspace(device):
-    """Per-device scratch for split-K partial sums (reused by stream-ordered launches)."""
-    ws = _WORKSPACE.get(device)
+    """Per-(device, stream) scratch for split-K partial sums: launches on one stream reuse it in
+    stream order; concurrent streams must not share it."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACE.get(key)
     if ws is None:
-        ws = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device=device)   # contract: zero-filled
-        _WORKSPACE[device] = ws
+        with torch.cuda.stream(torch.cuda.default_stream(device)):
+            ws = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device=device)   # contract: zero-filled
+        torch.cuda.current_stream(device).wait_stream(torch.cuda.default_stream(device))
+        _WORKSPACE[key] = ws
     return ws
 
 

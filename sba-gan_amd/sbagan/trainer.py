@@ -161,35 +161,53 @@ class GANStep(object):
         """Returns a dict of DEVICE scalars (errD0.., errG_total, kl_loss, g_loss*, w_loss, s_loss)."""
         netG, netsD = self.netG, self.netsD
         out = {}
+        mark = self._mark
+        mark('start')
         ops.ARENA.begin(self.device)          # one memset for all per-layer accumulators of the step
         netG.ca_net.eps = eps
         fake_imgs, _, mu, logvar = netG(noise, sent_emb, words_embs, mask)
+        mark('g_forward')
 
-        pending = []
+        # The three discriminator updates are independent of each other (different networks, the
+        # same detached fakes): each runs on its own HIP stream so that the small launches of the
+        # 4x4 / 8x8 layers of one network fill CUs the others leave idle.  Under hipGraph capture
+        # the streams become parallel branches of the graph.
+        main = torch.cuda.current_stream()
+        streams = self._d_streams()[:len(netsD)] if self.concurrent_d else [main] * len(netsD)
         for i, netD in enumerate(netsD):
-            self.flatD[i].zero_grad()
-            errD = discriminator_loss(netD, imgs[i], fake_imgs[i], sent_emb, self.real_labels, self.fake_labels)
-            errD.backward()
-            out['errD%d' % i] = errD.detach()
-            h = self._allreduce_start(self.flatD[i])
-            if i > 0:       # finish the previous network while this one's gradients travel
-                self._finish_d(i - 1, pending.pop())
-            pending.append(h)
-        self._finish_d(len(netsD) - 1, pending.pop())
+            st = streams[i]
+            if st is not main:
+                st.wait_stream(main)
+            with torch.cuda.stream(st):
+                self.flatD[i].zero_grad()
+                errD = discriminator_loss(netD, imgs[i], fake_imgs[i], sent_emb, self.real_labels,
+                                          self.fake_labels)
+                errD.backward()
+                out['errD%d' % i] = errD.detach()
+                self._allreduce_wait(self._allreduce_start(self.flatD[i]))
+                self.optD[i].step(1.0 / self.world)
+        for st in streams:
+            if st is not main:
+                main.wait_stream(st)
+        mark('d_steps')
 
         for p in self._d_params:
             p.requires_grad_(False)
         self.flatG.zero_grad()
         errG_total, logs = generator_loss(netsD, self.image_encoder, fake_imgs, self.real_labels, words_embs,
-                                          sent_emb, self.match_labels, cap_lens, class_ids)
+                                          sent_emb, self.match_labels, cap_lens, class_ids,
+                                          streams=self._d_streams() if self.concurrent_d else None)
         kl = KL_loss(mu, logvar)
         errG_total = errG_total + kl
+        mark('g_loss_forward')
         errG_total.backward()
+        mark('g_backward')
         for p in self._d_params:
             p.requires_grad_(True)
         h = self._allreduce_start(self.flatG)
         self._allreduce_wait(h)
         self.optG.step(1.0 / self.world)
+        mark('g_adam')
         out['errG_total'] = errG_total.detach()
         out['kl_loss'] = kl.detach()
         out.update(logs)
@@ -197,9 +215,20 @@ class GANStep(object):
         ops.ARENA.end()
         return out
 
-    def _finish_d(self, i, handle):
-        self._allreduce_wait(handle)
-        self.optD[i].step(1.0 / self.world)
+    phase_events = None      # set to [] to record (name, cuda event) pairs per step (bench.py --phases)
+
+    def _mark(self, name):
+        if self.phase_events is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.phase_events.append((name, e))
+
+    concurrent_d = True
+
+    def _d_streams(self):
+        if getattr(self, '_streams', None) is None:
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(len(self.netsD) + 1)]
+        return self._streams
 
     def grad_norm(self, flat):
         return flat.grad.double().norm()
