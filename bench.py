@@ -39,9 +39,10 @@ def parse():
     ap.add_argument('--branch', type=int, default=3, help='TREE.BRANCH_NUM: 1/2/3 = 64/128/256 px')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--variant', default='model', choices=['model', 'bert', 'mix'])
-    ap.add_argument('--image-encoder', default='inception', choices=['inception', 'standin'],
-                    help='CNN_ENCODER inside the G step: the Inception-v3 trunk (PyTorch-ROCm/MIOpen, '
-                         'third-party arithmetic) or the light stand-in used by the parity fixtures')
+    ap.add_argument('--image-encoder', default='inception', choices=['inception', 'inception-miopen', 'standin'],
+                    help='CNN_ENCODER inside the G step: the Inception-v3 trunk on the HIP kernels '
+                         '(sbagan.inception_hip), the same module through PyTorch-ROCm/MIOpen, or the light '
+                         'stand-in used by the parity fixtures')
     ap.add_argument('--graph', type=int, default=1, help='replay the step from a captured hipGraph')
     ap.add_argument('--phases', action='store_true', help='also print per-phase times of an eager step (stderr)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -72,6 +73,11 @@ def build(args, dev):
         d.to(dev).train()
     netG.set_return_attention(False)        # unused in training (trainer.py:262)
     if args.image_encoder == 'inception':
+        from sbagan.inception_hip import InceptionHIP
+        torch.manual_seed(101)
+        enc_mod = model.CNN_ENCODER(cfg.TEXT.EMBEDDING_DIM).to(dev).eval()
+        enc = InceptionHIP(enc_mod)
+    elif args.image_encoder == 'inception-miopen':
         enc_mod = model.CNN_ENCODER(cfg.TEXT.EMBEDDING_DIM).to(dev).eval()
         for p in enc_mod.parameters():
             p.requires_grad = False

@@ -36,7 +36,7 @@ extern "C" {
 #define SBA_ACT_GLU 1       /* model.py:15-23 */
 #define SBA_ACT_LRELU 2     /* LeakyReLU(0.2), model.py:544 */
 
-#define SBA_MAX_TAPS 16
+#define SBA_MAX_TAPS 32
 
 /* Geometry of one implicit-GEMM convolution launch.  Output pixel (oy, ox) of
  * the OHs x OWs sub-grid reads input pixel (oy*sy + ty[t], ox*sx + tx[t]) for
@@ -55,6 +55,11 @@ typedef struct sba_conv_geom {
     int32_t ntaps;
     int8_t ty[SBA_MAX_TAPS];
     int8_t tx[SBA_MAX_TAPS];
+    /* channel strides / offsets (elements) of the input and output tensors, for reading from /
+     * writing into a channel slice of a wider NHWC tensor (Inception concats); 0 = dense
+     * (x_cstride = Cin, y_cstride = Cout).  Honoured by sba_conv_igemm only. */
+    int32_t x_cstride, x_coff, y_cstride, y_coff;
+    int32_t relu;               /* epilogue: y = max(acc + bias, 0) when set (with `bias`) */
 } sba_conv_geom;
 
 const char* sba_version(void);
@@ -69,6 +74,11 @@ const char* sba_version(void);
 int sba_conv_igemm(int dtype, const void* x, const void* w, void* y, const void* addend,
                    float* stats, const sba_conv_geom* g, void* workspace, int64_t workspace_bytes,
                    void* stream);
+/* same with a per-output-channel f32 bias (may be NULL) added before the optional ReLU of g->relu
+ * (frozen conv + folded BatchNorm(eval) + ReLU of the image encoder, model.py:170-199). */
+int sba_conv_igemm_bias(int dtype, const void* x, const void* w, void* y, const void* addend,
+                        float* stats, const float* bias, const sba_conv_geom* g, void* workspace,
+                        int64_t workspace_bytes, void* stream);
 /* dw[co][t][ci] += sum_pixel dy[pixel][co] * x[gather(pixel,t)][ci]   (f32 accumulate/output).
  * ksplit > 1 splits the pixel range over that many workgroups (atomic accumulation). */
 int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* dw, const sba_conv_geom* g,
@@ -195,6 +205,32 @@ int sba_cond_cat_fwd(int dtype, const void* h, const float* sent, void* out, int
                      void* stream);
 int sba_cond_cat_bwd(int dtype, const void* dout, void* dh, float* dsent, int B, int C, int E,
                      int accumulate, void* stream);
+
+/* ---- frozen image encoder pieces (CNN_ENCODER, model.py:162-267; forward + backward-data only) ---- */
+/* bilinear resize, align_corners=True (model.py:210), NCHW f32 [NC][S][S] -> [NC][D][D];
+ * backward != 0: `in` is d(out) [NC][D][D] and `out` receives d(in) [NC][S][S]. */
+int sba_resize_bilinear(const float* in, float* out, int NC, int S, int D, int backward, void* stream);
+/* Conv2d_1a_3x3: conv3x3 s2 p0 (3->C) + bias + ReLU, NCHW f32 image -> NHWC features. */
+int sba_enc_stem_fwd(int dtype, const float* img, const float* w, const float* bias, void* out, int N, int S, int C,
+                     void* stream);
+int sba_enc_stem_bwd(int dtype, const float* w, const void* out, const void* dout, float* dimg, int N, int S, int C,
+                     void* stream);
+/* F.max_pool2d(x, 3, 2) on NHWC channel slices (cs = channel stride, co = channel offset); the backward
+ * routes each window's gradient to its first maximum in scan order (torch's tie rule). */
+int sba_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, int xcs, int xco, int ycs,
+                         int yco, void* stream);
+int sba_maxpool3x3s2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C, int xcs,
+                         int xco, int dycs, int dyco, int dxcs, int dxco, int accumulate, void* stream);
+/* F.avg_pool2d(x, 3, 1, 1) (count_include_pad); self-adjoint, so it is also its own backward. */
+int sba_avgpool3x3(int dtype, const void* x, void* y, int N, int H, int W, int C, int xcs, int xco, int ycs, int yco,
+                   int accumulate, void* stream);
+/* dpre[rows][C] = (out > 0) ? dout : 0 on channel slices. */
+int sba_relu_bwd(int dtype, const void* out, const void* dout, void* dpre, int64_t rows, int C, int ocs, int oco,
+                 int dcs, int dco, void* stream);
+/* F.avg_pool2d over the whole HW map: x NHWC -> y [N][C] f32; backward != 0: x receives dy / HW. */
+int sba_global_avgpool(int dtype, void* x, float* y, int N, int HW, int C, int backward, void* stream);
+/* NHWC features <-> NCHW f32 (to_nhwc != 0: nchw -> nhwc). */
+int sba_layout_nhwc_nchw(int dtype, void* nhwc, float* nchw, int N, int HW, int C, int to_nhwc, void* stream);
 
 /* ---- losses ---- */
 /* loss[0] = sum_s weight[s] * mean BCE(prob_s, target[s]) over nseg segments given by

@@ -1,0 +1,409 @@
+// Non-GEMM pieces of the frozen image encoder (CNN_ENCODER, model.py:162-267: Inception-v3 trunk on a
+// 299 x 299 bilinear resize) for gfx950.  The convolutions themselves run on the implicit-GEMM
+// kernels of igemm.hip (BatchNorm(eval) folded into weights + bias, ReLU in the epilogue, concat by
+// writing channel slices); this file holds the resize, the 3-channel stem conv, the pools and the
+// ReLU-mask / layout helpers, forward and backward-data (the encoder's weights are frozen:
+// trainer.py:57-63).  All are HBM-bound streaming kernels.
+#include "common.h"
+
+namespace {
+
+// ---- bilinear resize, align_corners=True (model.py:210), NCHW f32 -> NCHW f32 ----
+__global__ void resize_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int NC, int S, int D) {
+    const int64_t total = (int64_t)NC * D * D;
+    const float sc = (float)(S - 1) / (float)(D - 1);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % D), y = (int)((i / D) % D);
+        const int64_t nc = i / ((int64_t)D * D);
+        const float fy = y * sc, fx = x * sc;
+        int y0 = (int)fy, x0 = (int)fx;
+        y0 = min(y0, S - 1); x0 = min(x0, S - 1);
+        const int y1 = min(y0 + 1, S - 1), x1 = min(x0 + 1, S - 1);
+        const float wy = fy - y0, wx = fx - x0;
+        const float* p = in + nc * S * S;
+        const float v = (1.f - wy) * ((1.f - wx) * p[y0 * S + x0] + wx * p[y0 * S + x1]) +
+                        wy * ((1.f - wx) * p[y1 * S + x0] + wx * p[y1 * S + x1]);
+        out[i] = v;
+    }
+}
+
+__global__ void resize_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int NC, int S, int D) {
+    const int64_t total = (int64_t)NC * D * D;
+    const float sc = (float)(S - 1) / (float)(D - 1);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % D), y = (int)((i / D) % D);
+        const int64_t nc = i / ((int64_t)D * D);
+        const float fy = y * sc, fx = x * sc;
+        int y0 = (int)fy, x0 = (int)fx;
+        y0 = min(y0, S - 1); x0 = min(x0, S - 1);
+        const int y1 = min(y0 + 1, S - 1), x1 = min(x0 + 1, S - 1);
+        const float wy = fy - y0, wx = fx - x0, g = dout[i];
+        float* p = din + nc * S * S;
+        atomicAdd(&p[y0 * S + x0], g * (1.f - wy) * (1.f - wx));
+        atomicAdd(&p[y0 * S + x1], g * (1.f - wy) * wx);
+        atomicAdd(&p[y1 * S + x0], g * wy * (1.f - wx));
+        atomicAdd(&p[y1 * S + x1], g * wy * wx);
+    }
+}
+
+// ---- stem: conv3x3 s2 p0 (3 -> C) + bias + ReLU, NCHW f32 in, NHWC T out ----
+// thread = (output pixel, V channels); weights [C][3][3][3] (channels_last OIHW) transposed to [27][C] in LDS
+template <typename T>
+__global__ __launch_bounds__(256) void enc_stem_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, T* __restrict__ out,
+                                                           int N, int S, int O, int C) {
+    constexpr int V = Vec16<T>::N;
+    extern __shared__ float s_w[];       // [27][C]
+    for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) {
+        const int co = i / 27, k = i - co * 27;
+        s_w[k * C + co] = w[i];
+    }
+    __syncthreads();
+    const int cv = C / V;
+    const int64_t total = (int64_t)N * O * O * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V;
+        const int64_t p = i / cv;
+        const int ox = (int)(p % O), oy = (int)((p / O) % O), n = (int)(p / ((int64_t)O * O));
+        float acc[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = bias[c + k];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float v = img[(((int64_t)n * 3 + ci) * S + 2 * oy + kh) * S + 2 * ox + kw];
+                    const float* wr = &s_w[((kh * 3 + kw) * 3 + ci) * C + c];
+#pragma unroll
+                    for (int k = 0; k < V; ++k) acc[k] += v * wr[k];
+                }
+        Vec16<T> o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) o.set(k, fmaxf(acc[k], 0.f));
+        st16(out + p * C + c, o);
+    }
+}
+
+// dimg[n][ci][iy][ix] = sum over output pixels (<= 2 x 2) reading it and all co of dout*(out>0)*w
+template <typename T>
+__global__ __launch_bounds__(256) void enc_stem_bwd_kernel(const float* __restrict__ w, const T* __restrict__ out,
+                                                           const T* __restrict__ dout, float* __restrict__ dimg,
+                                                           int N, int S, int O, int C) {
+    constexpr int V = Vec16<T>::N;
+    extern __shared__ float s_w[];       // [27][C]
+    for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) {
+        const int co = i / 27, k = i - co * 27;
+        s_w[k * C + co] = w[i];
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)N * S * S;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const int ix = (int)(p % S), iy = (int)((p / S) % S), n = (int)(p / ((int64_t)S * S));
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int kh = iy & 1; kh < 3; kh += 2) {
+            const int oy = (iy - kh) >> 1;
+            if (iy - kh < 0 || oy >= O) continue;
+            for (int kw = ix & 1; kw < 3; kw += 2) {
+                const int ox = (ix - kw) >> 1;
+                if (ix - kw < 0 || ox >= O) continue;
+                const int64_t q = (((int64_t)n * O + oy) * O + ox) * C;
+                for (int cv = 0; cv < C / V; ++cv) {
+                    Vec16<T> ov = ld16(out + q + cv * V), dv = ld16(dout + q + cv * V);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        const float dp = ov.get(k) > 0.f ? dv.get(k) : 0.f;
+                        const int co = cv * V + k;
+#pragma unroll
+                        for (int ci = 0; ci < 3; ++ci) acc[ci] += dp * s_w[((kh * 3 + kw) * 3 + ci) * C + co];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) dimg[(((int64_t)n * 3 + ci) * S + iy) * S + ix] = acc[ci];
+    }
+}
+
+// ---- max pool 3x3 stride 2 (no padding), NHWC with channel strides ----
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int xcs,
+                                   int xco, int ycs, int yco) {
+    constexpr int V = Vec16<T>::N;
+    const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1, cv = C / V;
+    const int64_t total = (int64_t)N * OH * OW * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V;
+        const int64_t p = i / cv;
+        const int ox = (int)(p % OW), oy = (int)((p / OW) % OH), n = (int)(p / ((int64_t)OW * OH));
+        float m[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) m[k] = -INFINITY;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                Vec16<T> v = ld16(x + (((int64_t)n * H + 2 * oy + kh) * W + 2 * ox + kw) * xcs + xco + c);
+#pragma unroll
+                for (int k = 0; k < V; ++k) m[k] = fmaxf(m[k], v.get(k));
+            }
+        Vec16<T> o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) o.set(k, m[k]);
+        st16(y + p * ycs + yco + c, o);
+    }
+}
+
+// dx[p] (+)= sum over the windows containing p whose FIRST maximum (scan order kh, kw: torch's tie rule)
+// is p, of dy[window]
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int N, int H,
+                                   int W, int C, int xcs, int xco, int dycs, int dyco, int dxcs, int dxco,
+                                   int accumulate) {
+    constexpr int V = Vec16<T>::N;
+    const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1, cv = C / V;
+    const int64_t total = (int64_t)N * H * W * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V;
+        const int64_t p = i / cv;
+        const int ix = (int)(p % W), iy = (int)((p / W) % H), n = (int)(p / ((int64_t)W * H));
+        float g[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) g[k] = 0.f;
+        for (int oy = max(0, (iy - 1) >> 1); oy <= min(OH - 1, iy >> 1); ++oy) {
+            if (iy - 2 * oy > 2) continue;
+            for (int ox = max(0, (ix - 1) >> 1); ox <= min(OW - 1, ix >> 1); ++ox) {
+                if (ix - 2 * ox > 2) continue;
+                const int mypos = (iy - 2 * oy) * 3 + (ix - 2 * ox);
+                float m[V];
+                int arg[V];
+#pragma unroll
+                for (int k = 0; k < V; ++k) { m[k] = -INFINITY; arg[k] = -1; }
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        Vec16<T> v = ld16(x + (((int64_t)n * H + 2 * oy + kh) * W + 2 * ox + kw) * xcs + xco + c);
+#pragma unroll
+                        for (int k = 0; k < V; ++k) {
+                            const float f = v.get(k);
+                            if (f > m[k]) { m[k] = f; arg[k] = kh * 3 + kw; }
+                        }
+                    }
+                Vec16<T> d = ld16(dy + (((int64_t)n * OH + oy) * OW + ox) * dycs + dyco + c);
+#pragma unroll
+                for (int k = 0; k < V; ++k)
+                    if (arg[k] == mypos) g[k] += d.get(k);
+            }
+        }
+        T* op = dx + p * dxcs + dxco + c;
+        Vec16<T> o;
+        if (accumulate) o = ld16(op);
+#pragma unroll
+        for (int k = 0; k < V; ++k) o.set(k, g[k] + (accumulate ? o.get(k) : 0.f));
+        st16(op, o);
+    }
+}
+
+// ---- avg pool 3x3 stride 1 pad 1, count_include_pad (divide by 9); its backward is the same operator ----
+template <typename T>
+__global__ void avgpool3_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int xcs,
+                                int xco, int ycs, int yco, int accumulate) {
+    constexpr int V = Vec16<T>::N;
+    const int cv = C / V;
+    const int64_t total = (int64_t)N * H * W * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V;
+        const int64_t p = i / cv;
+        const int ix = (int)(p % W), iy = (int)((p / W) % H), n = (int)(p / ((int64_t)W * H));
+        float s[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) s[k] = 0.f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = iy + dy, xx = ix + dx;
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                Vec16<T> v = ld16(x + (((int64_t)n * H + yy) * W + xx) * xcs + xco + c);
+#pragma unroll
+                for (int k = 0; k < V; ++k) s[k] += v.get(k);
+            }
+        T* op = y + p * ycs + yco + c;
+        Vec16<T> o;
+        if (accumulate) o = ld16(op);
+#pragma unroll
+        for (int k = 0; k < V; ++k) o.set(k, s[k] * (1.f / 9.f) + (accumulate ? o.get(k) : 0.f));
+        st16(op, o);
+    }
+}
+
+// ---- dpre = (out > 0) ? dout : 0 on a channel slice ----
+template <typename T>
+__global__ void relu_bwd_kernel(const T* __restrict__ out, const T* __restrict__ dout, T* __restrict__ dpre,
+                                int64_t rows, int C, int ocs, int oco, int dcs, int dco) {
+    constexpr int V = Vec16<T>::N;
+    const int cv = C / V;
+    const int64_t total = rows * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V;
+        const int64_t r = i / cv;
+        Vec16<T> o = ld16(out + r * ocs + oco + c), d = ld16(dout + r * dcs + dco + c), q;
+#pragma unroll
+        for (int k = 0; k < V; ++k) q.set(k, o.get(k) > 0.f ? d.get(k) : 0.f);
+        st16(dpre + r * C + c, q);
+    }
+}
+
+// ---- global average pool over HW (NHWC T -> [N][C] f32) and its backward ----
+template <typename T>
+__global__ void gap_fwd_kernel(const T* __restrict__ x, float* __restrict__ y, int N, int HW, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += to_f<T>(x[((int64_t)n * HW + p) * C + c]);
+    y[i] = s / HW;
+}
+template <typename T>
+__global__ void gap_bwd_kernel(const float* __restrict__ dy, T* __restrict__ dx, int N, int HW, int C) {
+    const int64_t total = (int64_t)N * HW * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int n = (int)(i / ((int64_t)HW * C));
+        dx[i] = from_f<T>(dy[n * C + c] / HW);
+    }
+}
+
+// ---- NHWC T <-> NCHW f32 (region features handed to the DAMSM loss) ----
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int N, int HW, int C) {
+    const int64_t total = (int64_t)N * HW * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW), c = (int)((i / HW) % C), n = (int)(i / ((int64_t)HW * C));
+        y[i] = to_f<T>(x[((int64_t)n * HW + p) * C + c]);
+    }
+}
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int HW, int C) {
+    const int64_t total = (int64_t)N * HW * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), p = (int)((i / C) % HW), n = (int)(i / ((int64_t)HW * C));
+        y[i] = from_f<T>(x[((int64_t)n * C + c) * HW + p]);
+    }
+}
+
+inline int grid_for(int64_t items, int cap = 8192) {
+    int64_t b = (items + 255) / 256;
+    if (b < 1) b = 1;
+    return (int)(b > cap ? cap : b);
+}
+inline bool slice_ok(int dtype, int C, int cs, int co) {
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    return C > 0 && C % V == 0 && cs >= C + co && co >= 0 && cs % V == 0 && co % V == 0;
+}
+
+}  // namespace
+
+extern "C" int sba_resize_bilinear(const float* in, float* out, int NC, int S, int D, int backward, void* stream) {
+    if (!in || !out || NC <= 0 || S < 2 || D < 2) return SBA_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (!backward) {
+        hipLaunchKernelGGL(resize_fwd_kernel, dim3(grid_for((int64_t)NC * D * D)), dim3(256), 0, st, in, out, NC, S, D);
+    } else {     // in = d(out) [NC][D][D], out = d(in) [NC][S][S]
+        if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)NC * S * S, st) != hipSuccess) return SBA_E_LAUNCH;
+        hipLaunchKernelGGL(resize_bwd_kernel, dim3(grid_for((int64_t)NC * D * D)), dim3(256), 0, st, in, out, NC, S, D);
+    }
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_enc_stem_fwd(int dtype, const float* img, const float* w, const float* bias, void* out, int N,
+                                int S, int C, void* stream) {
+    if (!img || !w || !bias || !out || N <= 0 || S < 3 || C <= 0 || C % 8 || C > 256) return SBA_E_ARG;
+    const int O = (S - 3) / 2 + 1, V = dtype == SBA_BF16 ? 8 : 4;
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((enc_stem_fwd_kernel<T>), dim3(grid_for((int64_t)N * O * O * (C / V), 4096)),
+                                           dim3(256), sizeof(float) * 27 * C, (hipStream_t)stream, img, w, bias,
+                                           (T*)out, N, S, O, C));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_enc_stem_bwd(int dtype, const float* w, const void* out, const void* dout, float* dimg, int N,
+                                int S, int C, void* stream) {
+    if (!w || !out || !dout || !dimg || N <= 0 || S < 3 || C <= 0 || C % 8 || C > 256) return SBA_E_ARG;
+    const int O = (S - 3) / 2 + 1;
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((enc_stem_bwd_kernel<T>), dim3(grid_for((int64_t)N * S * S, 4096)), dim3(256),
+                                           sizeof(float) * 27 * C, (hipStream_t)stream, w, (const T*)out,
+                                           (const T*)dout, dimg, N, S, O, C));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, int xcs, int xco,
+                                    int ycs, int yco, void* stream) {
+    if (!x || !y || N <= 0 || H < 3 || W < 3 || !slice_ok(dtype, C, xcs, xco) || !slice_ok(dtype, C, ycs, yco))
+        return SBA_E_ARG;
+    const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1, V = dtype == SBA_BF16 ? 8 : 4;
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for((int64_t)N * OH * OW * (C / V))),
+                                           dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, N, H, W, C, xcs, xco,
+                                           ycs, yco));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_maxpool3x3s2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C,
+                                    int xcs, int xco, int dycs, int dyco, int dxcs, int dxco, int accumulate,
+                                    void* stream) {
+    if (!x || !dy || !dx || N <= 0 || H < 3 || W < 3 || !slice_ok(dtype, C, xcs, xco) ||
+        !slice_ok(dtype, C, dycs, dyco) || !slice_ok(dtype, C, dxcs, dxco))
+        return SBA_E_ARG;
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for((int64_t)N * H * W * (C / V))),
+                                           dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, N, H,
+                                           W, C, xcs, xco, dycs, dyco, dxcs, dxco, accumulate));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_avgpool3x3(int dtype, const void* x, void* y, int N, int H, int W, int C, int xcs, int xco,
+                              int ycs, int yco, int accumulate, void* stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || !slice_ok(dtype, C, xcs, xco) || !slice_ok(dtype, C, ycs, yco))
+        return SBA_E_ARG;
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((avgpool3_kernel<T>), dim3(grid_for((int64_t)N * H * W * (C / V))), dim3(256),
+                                           0, (hipStream_t)stream, (const T*)x, (T*)y, N, H, W, C, xcs, xco, ycs, yco,
+                                           accumulate));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_relu_bwd(int dtype, const void* out, const void* dout, void* dpre, int64_t rows, int C, int ocs,
+                            int oco, int dcs, int dco, void* stream) {
+    if (!out || !dout || !dpre || rows <= 0 || !slice_ok(dtype, C, ocs, oco) || !slice_ok(dtype, C, dcs, dco))
+        return SBA_E_ARG;
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((relu_bwd_kernel<T>), dim3(grid_for(rows * (C / V))), dim3(256), 0,
+                                           (hipStream_t)stream, (const T*)out, (const T*)dout, (T*)dpre, rows, C, ocs,
+                                           oco, dcs, dco));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_global_avgpool(int dtype, void* x, float* y, int N, int HW, int C, int backward, void* stream) {
+    if (!x || !y || N <= 0 || HW <= 0 || C <= 0) return SBA_E_ARG;
+    if (!backward) {
+        SBA_DISPATCH(dtype, hipLaunchKernelGGL((gap_fwd_kernel<T>), dim3(cdiv((int64_t)N * C, 256)), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)x, y, N, HW, C));
+    } else {     // x = dx (output, T), y = dy (input, f32)
+        SBA_DISPATCH(dtype, hipLaunchKernelGGL((gap_bwd_kernel<T>), dim3(grid_for((int64_t)N * HW * C)), dim3(256), 0,
+                                               (hipStream_t)stream, (const float*)y, (T*)x, N, HW, C));
+    }
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_layout_nhwc_nchw(int dtype, void* nhwc, float* nchw, int N, int HW, int C, int to_nhwc, void* stream) {
+    if (!nhwc || !nchw || N <= 0 || HW <= 0 || C <= 0) return SBA_E_ARG;
+    if (!to_nhwc) {
+        SBA_DISPATCH(dtype, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(grid_for((int64_t)N * HW * C)), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)nhwc, nchw, N, HW, C));
+    } else {
+        SBA_DISPATCH(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for((int64_t)N * HW * C)), dim3(256), 0,
+                                               (hipStream_t)stream, (const float*)nchw, (T*)nhwc, N, HW, C));
+    }
+    return SBA_CHECK_LAUNCH();
+}

@@ -96,7 +96,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
                                                     T* __restrict__ y, const T* __restrict__ addend,
                                                     float* __restrict__ stats, const sba_conv_geom g,
                                                     const int M, float* __restrict__ ws,
-                                                    const int slabs_per_split) {
+                                                    const int slabs_per_split, const float* __restrict__ bias) {
     constexpr int ROWB = 80;
     constexpr int KS_CH = 64 / (int)sizeof(T);   // channels per slab
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -152,12 +152,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
     const int nsteps = g.ntaps * cpt;
     // tap offsets packed 4 bits each (offset + 8) so that the per-step lookup is
     // scalar shifts instead of a dynamically indexed kernarg array
-    uint64_t tyb = 0, txb = 0;
+    uint64_t tyb[2] = {0, 0}, txb[2] = {0, 0};
 #pragma unroll
     for (int t = 0; t < SBA_MAX_TAPS; ++t) {
-        tyb |= (uint64_t)((g.ty[t] + 8) & 15) << (4 * t);
-        txb |= (uint64_t)((g.tx[t] + 8) & 15) << (4 * t);
+        tyb[t >> 4] |= (uint64_t)((g.ty[t] + 8) & 15) << (4 * (t & 15));
+        txb[t >> 4] |= (uint64_t)((g.tx[t] + 8) & 15) << (4 * (t & 15));
     }
+    const int xcs = g.x_cstride ? g.x_cstride : g.Cin;       // input pixel stride (channels)
+    const int ycs = g.y_cstride ? g.y_cstride : g.Cout;      // output pixel stride (channels)
 
     // split-K: this block walks slabs [s_begin, s_end)
     const int s_begin = blockIdx.z * slabs_per_split;
@@ -184,7 +186,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
         const bool ok = (co < g.Cout) && (r < BN);
         w_off[i] = ok ? (uint32_t)co * krow_bytes + (uint32_t)s_begin * 64u + (uint32_t)chunk * 16u : OOB;
     }
-    const uint32_t x_bytes = (uint32_t)((int64_t)g.N * g.IH * g.IW * g.Cin * (int64_t)sizeof(T));
+    const uint32_t x_bytes = (uint32_t)((int64_t)g.N * g.IH * g.IW * xcs * (int64_t)sizeof(T));
     const uint32_t w_bytes = (uint32_t)g.Cout * krow_bytes;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, w_bytes, 0x00020000);
@@ -198,14 +200,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
             if (g_tap != cur_tap) {                     // (uniform) new tap: refresh the gather offsets
                 cur_tap = g_tap;
                 const int tsel = g_tap < SBA_MAX_TAPS ? g_tap : 0;
-                const int ty = (int)((tyb >> (4 * tsel)) & 15) - 8, tx = (int)((txb >> (4 * tsel)) & 15) - 8;
+                const uint64_t tyw = tsel < 16 ? tyb[0] : tyb[1], txw = tsel < 16 ? txb[0] : txb[1];
+                const int ty = (int)((tyw >> (4 * (tsel & 15))) & 15) - 8;
+                const int tx = (int)((txw >> (4 * (tsel & 15))) & 15) - 8;
 #pragma unroll
                 for (int i = 0; i < AI; ++i) {
                     int iy = a_iy0[i] + ty, ix = a_ix0[i] + tx;
                     const bool ok = (iy >= 0) & (iy < IHL) & (ix >= 0) & (ix < IWL);
                     if (g.ups) { iy >>= 1; ix >>= 1; }
-                    const uint32_t o = (uint32_t)(a_nb[i] + iy * g.IW + ix) * (uint32_t)(g.Cin * (int)sizeof(T)) +
-                                       (uint32_t)chunk * 16u;
+                    const uint32_t o = (uint32_t)(a_nb[i] + iy * g.IW + ix) * (uint32_t)(xcs * (int)sizeof(T)) +
+                                       (uint32_t)(g.x_coff * (int)sizeof(T)) + (uint32_t)chunk * 16u;
                     a_off[i] = ok ? o : OOB;
                 }
             }
@@ -300,13 +304,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
                 float v = acc[i][j][r];
                 csum += v;
                 csq += v * v;
+                if (bias) v += bias[co < g.Cout ? co : 0];
+                if (g.relu) v = fmaxf(v, 0.f);
                 if (kStageOut) {
                     // (the main loop's last barrier has passed: the staging buffers are free)
                     *reinterpret_cast<T*>(lds + row * OROW + (wn0 + j * 32 + col_l) * 2) = from_f<T>(v);
                 } else {
                     const int pix = rowoff[row];
                     if (pix >= 0 && co < g.Cout) {
-                        const int64_t o = (int64_t)pix * g.Cout + co;
+                        const int64_t o = (int64_t)pix * ycs + g.y_coff + co;
                         if (addend) v += to_f<T>(addend[o]);
                         y[o] = from_f<T>(v);
                     }
@@ -331,7 +337,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
             const int co = n_base + cc * 8;
             if (pix < 0 || co >= g.Cout) continue;
             uint4 v = *reinterpret_cast<const uint4*>(lds + row * OROW + cc * 16);
-            const int64_t o = (int64_t)pix * g.Cout + co;
+            const int64_t o = (int64_t)pix * ycs + g.y_coff + co;
             if (co + 8 <= g.Cout) {
                 if (addend) {
                     const uint4 a = *reinterpret_cast<const uint4*>(addend + o);
@@ -828,6 +834,45 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
     }
 }
 
+// modes 1 / 2 as tiled transposes: for one (source tap -> destination tap) pair the job is
+// out[ci][co] = w[co][ci] with row strides of taps*Cin resp. dtaps*Cout; 32x32 tiles through LDS
+// keep both the global reads (along ci) and writes (along co) coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_tr_kernel(const float* __restrict__ w, T* __restrict__ out,
+                                                             int Cout, int KH, int KW, int Cin, int mode) {
+    __shared__ float tile[32][33];
+    const int z = blockIdx.z;
+    int src_tap, dst_tap, dtaps;
+    int64_t dst_base = 0;
+    if (mode == 1) {
+        const int kh = z / KW, kw = z - kh * KW;
+        dst_tap = z;
+        src_tap = (KH - 1 - kh) * KW + (KW - 1 - kw);
+        dtaps = KH * KW;
+    } else {
+        const int cls = z >> 2, tp = z & 3;
+        const int py = cls >> 1, px = cls & 1, j = tp >> 1, i2 = tp & 1;
+        src_tap = ((1 - py) + 2 * j) * 4 + (1 - px) + 2 * i2;
+        dst_tap = tp;
+        dtaps = 4;
+        dst_base = (int64_t)cls * Cin * 4 * Cout;
+    }
+    const int taps = KH * KW;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        tile[r][tx] = (co < Cout && ci < Cin) ? w[((int64_t)co * taps + src_tap) * Cin + ci] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < Cin && co < Cout) out[dst_base + ((int64_t)ci * dtaps + dst_tap) * Cout + co] = from_f<T>(tile[tx][r]);
+    }
+}
+
 template <typename T>
 __global__ void pool2x2_kernel(const T* __restrict__ up, T* __restrict__ dx, int N, int H, int W, int C) {
     constexpr int V = Vec16<T>::N;
@@ -854,7 +899,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ ws, T* __restrict__ y,
                                                             const T* __restrict__ addend,
                                                             float* __restrict__ stats, const sba_conv_geom g,
-                                                            const int M) {
+                                                            const int M, const float* __restrict__ bias) {
+    const int ycs = g.y_cstride ? g.y_cstride : g.Cout;
     const int cq = g.Cout / 4;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= cq) return;
@@ -869,11 +915,13 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ 
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
         const int n = m / sub, rem = m - n * sub;
         const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
-        const int64_t o = ((int64_t)(n * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox) * g.Cout + c;
+        const int64_t o = ((int64_t)(n * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox) * ycs + g.y_coff + c;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             s0[k] += v[k];
             s1[k] += v[k] * v[k];
+            if (bias) v[k] += bias[c + k];
+            if (g.relu) v[k] = fmaxf(v[k], 0.f);
             if (addend) v[k] += to_f<T>(addend[o + k]);
             y[o + k] = from_f<T>(v[k]);
         }
@@ -897,7 +945,7 @@ static const IgemmCfg kCfg[5] = {
 
 template <typename T, int BM, int BN, int WM, int WN, int KS>
 static void launch_cfg(const T* xp, const T* wp, T* yp, const T* ap, float* stats, const sba_conv_geom& g, int M,
-                       int nslabs, int split, float* ws, hipStream_t st) {
+                       int nslabs, int split, float* ws, hipStream_t st, const float* bias) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     int sps = nslabs;
     if (split > 1) {
@@ -906,10 +954,10 @@ static void launch_cfg(const T* xp, const T* wp, T* yp, const T* ap, float* stat
     }
     dim3 grid(cdiv(M, BM), cdiv(g.Cout, BN), split);
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KS>), grid, dim3(NT), 0, st, xp, wp, yp, ap, stats, g, M,
-                       split > 1 ? ws : (float*)nullptr, sps);
+                       split > 1 ? ws : (float*)nullptr, sps, bias);
     if (split > 1) {
         dim3 fgrid(cdiv(g.Cout / 4, 256), cdiv(M, 8));
-        hipLaunchKernelGGL((splitk_finish_kernel<T>), fgrid, dim3(256), 0, st, ws, yp, ap, stats, g, M);
+        hipLaunchKernelGGL((splitk_finish_kernel<T>), fgrid, dim3(256), 0, st, ws, yp, ap, stats, g, M, bias);
     }
 }
 
@@ -924,7 +972,8 @@ static int forced_cfg() {
 
 template <typename T>
 int launch_igemm(const void* x, const void* w, void* y, const void* addend, float* stats,
-                 const sba_conv_geom& g, void* workspace, int64_t ws_bytes, hipStream_t st) {
+                 const sba_conv_geom& g, void* workspace, int64_t ws_bytes, hipStream_t st,
+                 const float* bias = nullptr) {
     const int M = g.N * g.OHs * g.OWs;
     const T* xp = (const T*)x; const T* wp = (const T*)w; T* yp = (T*)y; const T* ap = (const T*)addend;
     const int nslabs = g.ntaps * (g.Cin / (64 / (int)sizeof(T)));
@@ -961,11 +1010,11 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
     }
     float* ws = (float*)workspace;
     switch (best) {
-        case 0: launch_cfg<T, 128, 128, 64, 64, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st); break;
-        case 1: launch_cfg<T, 256, 64, 64, 64, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st); break;
-        case 2: launch_cfg<T, 128, 64, 32, 64, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st); break;
-        case 3: launch_cfg<T, 64, 64, 32, 32, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st); break;
-        default: launch_cfg<T, 320, 128, 64, 64, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st); break;
+        case 0: launch_cfg<T, 128, 128, 64, 64, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
+        case 1: launch_cfg<T, 256, 64, 64, 64, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
+        case 2: launch_cfg<T, 128, 64, 32, 64, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
+        case 3: launch_cfg<T, 64, 64, 32, 32, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
+        default: launch_cfg<T, 320, 128, 64, 64, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
     }
     return SBA_CHECK_LAUNCH();
 }
@@ -984,7 +1033,11 @@ bool geom_ok(const sba_conv_geom* g, int dtype) {
     if (g->ooy < 0 || g->oox < 0) return false;
     if ((int64_t)g->N * g->OHs * g->OWs > 0x7fffffff) return false;
     const int64_t esz = dtype == SBA_BF16 ? 2 : 4;
-    if ((int64_t)g->N * g->IH * g->IW * g->Cin * esz >= ((int64_t)1 << 32)) return false;    // 32-bit byte offsets
+    const int vec = dtype == SBA_BF16 ? 8 : 4;
+    const int xcs = g->x_cstride ? g->x_cstride : g->Cin, ycs = g->y_cstride ? g->y_cstride : g->Cout;
+    if (xcs < g->Cin + g->x_coff || ycs < g->Cout + g->y_coff || g->x_coff < 0 || g->y_coff < 0) return false;
+    if (xcs % vec || g->x_coff % vec || ycs % vec || g->y_coff % vec) return false;
+    if ((int64_t)g->N * g->IH * g->IW * xcs * esz >= ((int64_t)1 << 32)) return false;    // 32-bit byte offsets
     if ((int64_t)g->Cout * g->ntaps * g->Cin * esz >= ((int64_t)1 << 32)) return false;
     if ((int64_t)g->N * g->IH * g->IW > 0x7fffffff / 2 || (int64_t)g->N * g->OH * g->OW > 0x7fffffff / 2)
         return false;
@@ -1003,10 +1056,21 @@ extern "C" int sba_conv_igemm(int dtype, const void* x, const void* w, void* y, 
     return SBA_E_ARG;
 }
 
+extern "C" int sba_conv_igemm_bias(int dtype, const void* x, const void* w, void* y, const void* addend,
+                                   float* stats, const float* bias, const sba_conv_geom* g, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+    if (!x || !w || !y || !geom_ok(g, dtype)) return SBA_E_ARG;
+    if (((uintptr_t)workspace & 15) != 0) return SBA_E_ARG;
+    SBA_DISPATCH(dtype, return launch_igemm<T>(x, w, y, addend, stats, *g, workspace, workspace_bytes,
+                                               (hipStream_t)stream, bias));
+    return SBA_E_ARG;
+}
+
 extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* dw, const sba_conv_geom* g,
                               int ksplit, void* stream) {
     if (!x || !dy || !dw || !geom_ok(g, dtype)) return SBA_E_ARG;
     if (g->Cin % 8 != 0 || g->Cout % 8 != 0) return SBA_E_ARG;
+    if (g->x_cstride || g->x_coff || g->y_cstride || g->y_coff || g->ntaps > 16) return SBA_E_ARG;
     const int M = g->N * g->OHs * g->OWs;
     if (ksplit < 1) ksplit = 1;
     const int co_tiles = cdiv(g->Cout, 64), items = cdiv(g->Cin, 64) * g->ntaps;
@@ -1063,6 +1127,13 @@ extern "C" int sba_pack_weight(int dtype, const float* w, void* out, int Cout, i
                                int mode, void* stream) {
     if (!w || !out || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || mode < 0 || mode > 2) return SBA_E_ARG;
     if (mode == 2 && (KH != 4 || KW != 4)) return SBA_E_ARG;
+    if (mode != 0) {
+        dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), mode == 1 ? KH * KW : 16);
+        if (grid.y > 65535) return SBA_E_ARG;
+        SBA_DISPATCH(dtype, hipLaunchKernelGGL((pack_weight_tr_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
+                                               w, (T*)out, Cout, KH, KW, Cin, mode));
+        return SBA_CHECK_LAUNCH();
+    }
     const int64_t n = (int64_t)Cout * KH * KW * Cin;
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     SBA_DISPATCH(dtype, hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(blocks), dim3(256), 0,

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libsbagan_hip.so')
 
 SBA_F32, SBA_BF16 = 0, 1
 ACT_NONE, ACT_GLU, ACT_LRELU = 0, 1, 2
-MAX_TAPS = 16
+MAX_TAPS = 32
 
 
 class ConvGeom(Structure):
@@ -24,7 +24,9 @@ class ConvGeom(Structure):
                 ('sy', c_int32), ('sx', c_int32),
                 ('osy', c_int32), ('osx', c_int32), ('ooy', c_int32), ('oox', c_int32),
                 ('ups', c_int32), ('ntaps', c_int32),
-                ('ty', c_int8 * MAX_TAPS), ('tx', c_int8 * MAX_TAPS)]
+                ('ty', c_int8 * MAX_TAPS), ('tx', c_int8 * MAX_TAPS),
+                ('x_cstride', c_int32), ('x_coff', c_int32), ('y_cstride', c_int32), ('y_coff', c_int32),
+                ('relu', c_int32)]
 
 
 if not os.path.exists(LIB_PATH):
@@ -38,6 +40,7 @@ G = POINTER(ConvGeom)
 # name -> argtypes; mirrors include/sbagan_hip.h one to one
 SIGNATURES = {
     'sba_conv_igemm': [I, P, P, P, P, P, G, P, L, P],
+    'sba_conv_igemm_bias': [I, P, P, P, P, P, P, G, P, L, P],
     'sba_conv_wgrad': [I, P, P, P, G, I, P],
     'sba_pack_weight': [I, P, P, I, I, I, I, I, P],
     'sba_pool2x2_sum': [I, P, P, I, I, I, I, P],
@@ -68,6 +71,15 @@ SIGNATURES = {
     'sba_logits_bwd': [I, P, P, P, P, P, P, P, I, I, I, P],
     'sba_cond_cat_fwd': [I, P, P, P, I, I, I, P],
     'sba_cond_cat_bwd': [I, P, P, P, I, I, I, I, P],
+    'sba_resize_bilinear': [P, P, I, I, I, I, P],
+    'sba_enc_stem_fwd': [I, P, P, P, P, I, I, I, P],
+    'sba_enc_stem_bwd': [I, P, P, P, P, I, I, I, P],
+    'sba_maxpool3x3s2_fwd': [I, P, P, I, I, I, I, I, I, I, I, P],
+    'sba_maxpool3x3s2_bwd': [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
+    'sba_avgpool3x3': [I, P, P, I, I, I, I, I, I, I, I, I, P],
+    'sba_relu_bwd': [I, P, P, P, L, I, I, I, I, I, P],
+    'sba_global_avgpool': [I, P, P, I, I, I, I, P],
+    'sba_layout_nhwc_nchw': [I, P, P, I, I, I, I, P],
     'sba_bce_multi': [P, P, P, P, I, P, P, P],
     'sba_kl_loss': [P, P, P, P, P, I, P],
     'sba_damsm_words_fwd': [P, P, P, P, P, P, P, I, I, I, I, F, F, P],

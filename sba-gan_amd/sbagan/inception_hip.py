@@ -1,0 +1,382 @@
+"""CNN_ENCODER (model.py:162-267) forward + backward-data on the HIP kernels.
+
+The encoder is frozen in GAN training (trainer.py:57-63) but sits inside every generator
+step (losses.py:190) and back-propagates to the fake image.  Here the Inception-v3 trunk runs on
+the implicit-GEMM kernel (sba_conv_igemm_bias): BatchNorm(eval, eps 1e-3) is folded into the
+packed weights + a bias, ReLU is the conv epilogue, the Inception concats are channel-slice
+writes, and the backward is ReLU-mask -> data-gradient conv with in-place accumulation into the
+block input's gradient.  Resize / stem / pools: csrc/encoder.hip.
+
+`InceptionHIP(enc)` wraps a sbagan.encoders.CNN_ENCODER (whose state_dict layout matches the
+reference's checkpoints) and is a drop-in callable: (B x 3 x S x S f32) ->
+(B x nef x 17 x 17 f32, B x nef f32).
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+from ._lib import ConvGeom, call
+
+BN_EPS = 1e-3
+
+
+def _pad32(c):
+    return (c + 31) // 32 * 32
+
+
+class _Act(object):
+    """NHWC activation: `t` is [N, H, W, Ct]; this view covers channels [coff, coff + C)."""
+
+    def __init__(self, t, coff=0, C=None):
+        self.t, self.coff = t, coff
+        self.C = t.shape[3] - coff if C is None else C
+        self.grad = None            # gradient w.r.t. the WHOLE tensor t (shared by all slices)
+        self.grad_ready = False
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+
+class _Conv(object):
+    """One BasicConv2d (conv, BN eval, ReLU) or a plain conv: folded + packed operands."""
+
+    def __init__(self, conv, bn, dtype, relu=True):
+        w = conv.weight.detach().float()
+        O, I, KH, KW = w.shape
+        dev = w.device
+        if bn is not None:
+            s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+            b = bn.bias.detach().float() - bn.running_mean.detach().float() * s
+            w = w * s.view(-1, 1, 1, 1)
+        else:
+            b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(O, device=dev)
+        self.O, self.I, self.KH, self.KW = O, I, KH, KW
+        self.Op, self.Ip = _pad32(O), _pad32(I)
+        self.stride = conv.stride[0]
+        self.ph, self.pw = conv.padding
+        self.relu = relu
+        taps = KH * KW
+        wp = torch.zeros((self.Op, taps, self.Ip), dtype=torch.float32, device=dev)
+        wp[:O, :, :I] = w.permute(0, 2, 3, 1).reshape(O, taps, I)
+        self.bias = torch.zeros(self.Op, dtype=torch.float32, device=dev)
+        self.bias[:O] = b
+        self.w_fwd = wp.to(dtype).contiguous()
+        wt = wp.permute(2, 1, 0).contiguous()                      # [Ip][tap][Op]
+        if self.stride == 1:
+            self.w_dgrad = [wt.to(dtype).contiguous()]
+            self.dtaps = [[(self.ph - t // KW, self.pw - t % KW) for t in range(taps)]]
+        else:       # stride 2 (3x3, pad 0): four parity classes of the input grid
+            self.w_dgrad, self.dtaps = [], []
+            for py in range(2):
+                for px in range(2):
+                    sel = [(kh, kw) for kh in range(KH) if (kh - py) % 2 == 0 for kw in range(KW) if (kw - px) % 2 == 0]
+                    idx = torch.tensor([kh * KW + kw for kh, kw in sel], device=dev)
+                    self.w_dgrad.append(wt[:, idx, :].to(dtype).contiguous())
+                    self.dtaps.append([((py - kh) // 2, (px - kw) // 2) for kh, kw in sel])
+
+
+def _geom(N, IH, IW, Cin, OH, OW, Cout, taps, sy=1, OHs=None, OWs=None, osy=1, ooy=0, oox=0, xcs=0, xco=0, ycs=0,
+          yco=0, relu=0):
+    g = ConvGeom()
+    g.N, g.IH, g.IW, g.Cin, g.OH, g.OW, g.Cout = N, IH, IW, Cin, OH, OW, Cout
+    g.OHs, g.OWs = OH if OHs is None else OHs, OW if OWs is None else OWs
+    g.sy = g.sx = sy
+    g.osy = g.osx = osy
+    g.ooy, g.oox = ooy, oox
+    g.ups = 0
+    g.ntaps = len(taps)
+    for t, (a, b) in enumerate(taps):
+        g.ty[t], g.tx[t] = a, b
+    g.x_cstride, g.x_coff, g.y_cstride, g.y_coff, g.relu = xcs, xco, ycs, yco, relu
+    return g
+
+
+class InceptionHIP(object):
+    def __init__(self, enc, dtype=None):
+        self.enc = enc
+        self.dtype = dtype or ops.compute_dtype()
+        self.nef = enc.nef
+        self._convs = {}
+        self._geoms = {}
+        dev = next(enc.parameters()).device
+        self.device = dev
+        for name, m in enc.named_modules():
+            if m.__class__.__name__ == 'BasicConv2d':
+                self._convs[name] = _Conv(m.conv, m.bn, self.dtype)
+        self._convs['emb_features'] = _Conv(enc.emb_features, None, self.dtype, relu=False)
+        lin = enc.emb_cnn_code
+
+        class _L(object):
+            pass
+        fake = _L()
+        fake.weight = lin.weight.detach().view(lin.out_features, lin.in_features, 1, 1)
+        fake.bias, fake.stride, fake.padding = lin.bias, (1, 1), (0, 0)
+        self._convs['emb_cnn_code'] = _Conv(fake, None, self.dtype, relu=False)
+        stem = enc.Conv2d_1a_3x3
+        s = stem.bn.weight.detach().float() / torch.sqrt(stem.bn.running_var.detach().float() + stem.bn.eps)
+        self.stem_w = (stem.conv.weight.detach().float() * s.view(-1, 1, 1, 1)).contiguous(
+            memory_format=torch.channels_last)
+        self.stem_b = (stem.bn.bias.detach().float() - stem.bn.running_mean.detach().float() * s).contiguous()
+
+    # ------------------------------------------------------------------ primitive ops
+    def _dt(self):
+        return _lib.SBA_BF16 if self.dtype == torch.bfloat16 else _lib.SBA_F32
+
+    def _new(self, N, H, W, C):
+        return torch.empty((N, H, W, C), dtype=self.dtype, device=self.device)
+
+    def _igemm(self, x_ptr, w, y_ptr, addend_ptr, bias, g):
+        ws = ops.workspace(self.device)
+        call('sba_conv_igemm_bias', self._dt(), x_ptr, w.data_ptr(), y_ptr, addend_ptr,
+             None, None if bias is None else bias.data_ptr(), ctypes.byref(g), ws.data_ptr(), ops.WORKSPACE_BYTES,
+             ops._stream())
+
+    def conv(self, name, x, out=None):
+        """y = relu(conv(x) + bias) written to `out` (an _Act slice) or a new tensor."""
+        L = self._convs[name]
+        N, H, W, Ct = x.shape
+        assert x.C == L.Ip, (name, x.C, L.Ip)
+        OH = (H + 2 * L.ph - L.KH) // L.stride + 1
+        OW = (W + 2 * L.pw - L.KW) // L.stride + 1
+        if out is None:
+            out = _Act(self._new(N, OH, OW, L.Op))
+        assert out.C == L.Op and out.shape[1] == OH and out.shape[2] == OW, (name, out.C, L.Op)
+        taps = [(t // L.KW - L.ph, t % L.KW - L.pw) for t in range(L.KH * L.KW)]
+        g = _geom(N, H, W, L.Ip, OH, OW, L.Op, taps, sy=L.stride, xcs=Ct, xco=x.coff, ycs=out.shape[3],
+                  yco=out.coff, relu=1 if L.relu else 0)
+        self._igemm(x.t.data_ptr(), L.w_fwd, out.t.data_ptr(), None, L.bias, g)
+        self.tape.append(('conv', L, x, out))
+        return out
+
+    def _grad_of(self, a):
+        """gradient buffer of the tensor behind activation `a`, and whether it already holds a value"""
+        if a.grad is None:
+            key = id(a.t)
+            holder = self._grads.get(key)
+            if holder is None:
+                holder = [torch.empty_like(a.t), False]
+                self._grads[key] = holder
+            a.grad = holder
+        return a.grad
+
+    def _conv_bwd(self, L, x, out):
+        gy = self._grad_of(out)
+        assert gy[1], 'gradient of a conv output was never produced'
+        N, OH, OW, Ct_o = out.shape
+        dt = self._dt()
+        dpre = self._new(N, OH, OW, L.Op)
+        if L.relu:
+            call('sba_relu_bwd', dt, out.t.data_ptr(), gy[0].data_ptr(), dpre.data_ptr(), N * OH * OW, L.Op, Ct_o,
+                 out.coff, Ct_o, out.coff, ops._stream())
+            dsrc, dcs, dco = dpre, L.Op, 0
+        else:
+            dsrc, dcs, dco = gy[0], Ct_o, out.coff
+        gx = self._grad_of(x)
+        _, H, W, Ct_x = x.shape
+        addend = gx[0].data_ptr() if gx[1] else None
+        if L.stride == 1:
+            g = _geom(N, OH, OW, L.Op, H, W, L.Ip, L.dtaps[0], xcs=dcs, xco=dco, ycs=Ct_x, yco=x.coff)
+            self._igemm(dsrc.data_ptr(), L.w_dgrad[0], gx[0].data_ptr(), addend, None, g)
+        else:
+            for cls in range(4):
+                py, px = cls // 2, cls % 2
+                OHs, OWs = (H - py + 1) // 2, (W - px + 1) // 2
+                if OHs <= 0 or OWs <= 0 or not L.dtaps[cls]:
+                    continue
+                g = _geom(N, OH, OW, L.Op, H, W, L.Ip, L.dtaps[cls], OHs=OHs, OWs=OWs, osy=2, ooy=py, oox=px,
+                          xcs=dcs, xco=dco, ycs=Ct_x, yco=x.coff)
+                self._igemm(dsrc.data_ptr(), L.w_dgrad[cls], gx[0].data_ptr(), addend, None, g)
+        gx[1] = True
+
+    def maxpool(self, x, out=None):
+        N, H, W, Ct = x.shape
+        OH, OW = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+        if out is None:
+            out = _Act(self._new(N, OH, OW, x.C))
+        call('sba_maxpool3x3s2_fwd', self._dt(), x.t.data_ptr(), out.t.data_ptr(), N, H, W, x.C, Ct, x.coff,
+             out.shape[3], out.coff, ops._stream())
+        self.tape.append(('maxpool', None, x, out))
+        return out
+
+    def _maxpool_bwd(self, x, out):
+        gy, gx = self._grad_of(out), self._grad_of(x)
+        N, H, W, Ct = x.shape
+        call('sba_maxpool3x3s2_bwd', self._dt(), x.t.data_ptr(), gy[0].data_ptr(), gx[0].data_ptr(), N, H, W, x.C, Ct,
+             x.coff, out.shape[3], out.coff, Ct, x.coff, 1 if gx[1] else 0, ops._stream())
+        gx[1] = True
+
+    def avgpool(self, x):
+        N, H, W, Ct = x.shape
+        out = _Act(self._new(N, H, W, x.C))
+        call('sba_avgpool3x3', self._dt(), x.t.data_ptr(), out.t.data_ptr(), N, H, W, x.C, Ct, x.coff, x.C, 0, 0,
+             ops._stream())
+        self.tape.append(('avgpool', None, x, out))
+        return out
+
+    def _avgpool_bwd(self, x, out):
+        gy, gx = self._grad_of(out), self._grad_of(x)
+        N, H, W, Ct = x.shape
+        call('sba_avgpool3x3', self._dt(), gy[0].data_ptr(), gx[0].data_ptr(), N, H, W, x.C, out.shape[3], out.coff,
+             Ct, x.coff, 1 if gx[1] else 0, ops._stream())
+        gx[1] = True
+
+    # ------------------------------------------------------------------ Inception blocks
+    def _A(self, p, x, pf):
+        N, H, W, _ = x.shape
+        cat = self._new(N, H, W, 64 + 64 + 96 + pf)
+        self.conv(p + '.branch1x1', x, _Act(cat, 0, 64))
+        self.conv(p + '.branch5x5_2', self.conv(p + '.branch5x5_1', x), _Act(cat, 64, 64))
+        t = self.conv(p + '.branch3x3dbl_2', self.conv(p + '.branch3x3dbl_1', x))
+        self.conv(p + '.branch3x3dbl_3', t, _Act(cat, 128, 96))
+        self.conv(p + '.branch_pool', self.avgpool(x), _Act(cat, 224, pf))
+        return _Act(cat)
+
+    def _B(self, p, x):
+        N, H, W, _ = x.shape
+        OH = (H - 3) // 2 + 1
+        cat = self._new(N, OH, OH, 384 + 96 + x.C)
+        self.conv(p + '.branch3x3', x, _Act(cat, 0, 384))
+        t = self.conv(p + '.branch3x3dbl_2', self.conv(p + '.branch3x3dbl_1', x))
+        self.conv(p + '.branch3x3dbl_3', t, _Act(cat, 384, 96))
+        self.maxpool(x, _Act(cat, 480, x.C))
+        return _Act(cat)
+
+    def _C(self, p, x):
+        N, H, W, _ = x.shape
+        cat = self._new(N, H, W, 768)
+        self.conv(p + '.branch1x1', x, _Act(cat, 0, 192))
+        t = self.conv(p + '.branch7x7_2', self.conv(p + '.branch7x7_1', x))
+        self.conv(p + '.branch7x7_3', t, _Act(cat, 192, 192))
+        t = self.conv(p + '.branch7x7dbl_1', x)
+        for k in (2, 3, 4):
+            t = self.conv(p + '.branch7x7dbl_%d' % k, t)
+        self.conv(p + '.branch7x7dbl_5', t, _Act(cat, 384, 192))
+        self.conv(p + '.branch_pool', self.avgpool(x), _Act(cat, 576, 192))
+        return _Act(cat)
+
+    def _D(self, p, x):
+        N, H, W, _ = x.shape
+        OH = (H - 3) // 2 + 1
+        cat = self._new(N, OH, OH, 320 + 192 + x.C)
+        self.conv(p + '.branch3x3_2', self.conv(p + '.branch3x3_1', x), _Act(cat, 0, 320))
+        t = self.conv(p + '.branch7x7x3_1', x)
+        for k in (2, 3):
+            t = self.conv(p + '.branch7x7x3_%d' % k, t)
+        self.conv(p + '.branch7x7x3_4', t, _Act(cat, 320, 192))
+        self.maxpool(x, _Act(cat, 512, x.C))
+        return _Act(cat)
+
+    def _E(self, p, x):
+        N, H, W, _ = x.shape
+        cat = self._new(N, H, W, 2048)
+        self.conv(p + '.branch1x1', x, _Act(cat, 0, 320))
+        t = self.conv(p + '.branch3x3_1', x)
+        self.conv(p + '.branch3x3_2a', t, _Act(cat, 320, 384))
+        self.conv(p + '.branch3x3_2b', t, _Act(cat, 704, 384))
+        t = self.conv(p + '.branch3x3dbl_2', self.conv(p + '.branch3x3dbl_1', x))
+        self.conv(p + '.branch3x3dbl_3a', t, _Act(cat, 1088, 384))
+        self.conv(p + '.branch3x3dbl_3b', t, _Act(cat, 1472, 384))
+        self.conv(p + '.branch_pool', self.avgpool(x), _Act(cat, 1856, 192))
+        return _Act(cat)
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward(self, img):
+        img = img.float().contiguous()
+        N, _, S, _ = img.shape
+        dt = self._dt()
+        self.tape, self._grads = [], {}
+        self.named = {}
+        st = ops._stream()
+        x299 = torch.empty((N, 3, 299, 299), dtype=torch.float32, device=self.device)
+        call('sba_resize_bilinear', img.data_ptr(), x299.data_ptr(), N * 3, S, 299, 0, st)
+        a0 = _Act(self._new(N, 149, 149, 32))
+        call('sba_enc_stem_fwd', dt, x299.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(),
+             a0.t.data_ptr(), N, 299, 32, st)
+        nm = self.named
+        nm['Conv2d_1a_3x3'] = a0
+        a = nm['Conv2d_2a_3x3'] = self.conv('Conv2d_2a_3x3', a0)
+        a = nm['Conv2d_2b_3x3'] = self.conv('Conv2d_2b_3x3', a)
+        a = nm['pool1'] = self.maxpool(a)
+        a = nm['Conv2d_3b_1x1'] = self.conv('Conv2d_3b_1x1', a)
+        a = nm['Conv2d_4a_3x3'] = self.conv('Conv2d_4a_3x3', a)
+        a = nm['pool2'] = self.maxpool(a)
+        a = nm['Mixed_5b'] = self._A('Mixed_5b', a, 32)
+        a = nm['Mixed_5c'] = self._A('Mixed_5c', a, 64)
+        a = nm['Mixed_5d'] = self._A('Mixed_5d', a, 64)
+        a = nm['Mixed_6a'] = self._B('Mixed_6a', a)
+        for nme in ('Mixed_6b', 'Mixed_6c', 'Mixed_6d', 'Mixed_6e'):
+            a = nm[nme] = self._C(nme, a)
+        feat_in = a
+        f = self.conv('emb_features', feat_in)                       # [N,17,17,nef_p]
+        a = nm['Mixed_7a'] = self._D('Mixed_7a', a)
+        a = nm['Mixed_7b'] = self._E('Mixed_7b', a)
+        a = nm['Mixed_7c'] = self._E('Mixed_7c', a)
+        pooled = torch.empty((N, 2048), dtype=torch.float32, device=self.device)
+        call('sba_global_avgpool', dt, a.t.data_ptr(), pooled.data_ptr(), N, 64, 2048, 0, st)
+        pooled_t = _Act(pooled.to(self.dtype).view(N, 1, 1, 2048))
+        code = self.conv('emb_cnn_code', pooled_t)                    # [N,1,1,nef_p]
+        nef = self.nef
+        features = torch.empty((N, f.C, 17, 17), dtype=torch.float32, device=self.device)
+        call('sba_layout_nhwc_nchw', dt, f.t.data_ptr(), features.data_ptr(), N, 289, f.C, 0, st)
+        self._saved = (img.shape, x299, a0, f, a, pooled_t, code)
+        return features[:, :nef], code.t.view(N, -1)[:, :nef].float()
+
+    def backward(self, dfeat, dcode):
+        (ishape, x299, a0, f, last, pooled_t, code) = self._saved
+        N = ishape[0]
+        dt, st = self._dt(), ops._stream()
+        # seed the two head gradients
+        gf = self._grad_of(f)
+        if dfeat is not None:
+            df = torch.zeros((N, f.C, 17, 17), dtype=torch.float32, device=self.device)
+            df[:, :self.nef] = dfeat
+            call('sba_layout_nhwc_nchw', dt, gf[0].data_ptr(), df.data_ptr(), N, 289, f.C, 1, st)
+        else:
+            gf[0].zero_()
+        gf[1] = True
+        gc = self._grad_of(code)
+        gc[0].zero_()
+        if dcode is not None:
+            gc[0].view(N, -1)[:, :self.nef] = dcode.to(self.dtype)
+        gc[1] = True
+        for kind, L, x, out in reversed(self.tape):
+            if kind == 'conv':
+                if x is pooled_t:
+                    self._conv_bwd(L, x, out)
+                    gp = self._grad_of(pooled_t)[0].view(N, 2048).float().contiguous()
+                    gl = self._grad_of(last)
+                    call('sba_global_avgpool', dt, gl[0].data_ptr(), gp.data_ptr(), N, 64, 2048, 1, st)
+                    gl[1] = True
+                else:
+                    self._conv_bwd(L, x, out)
+            elif kind == 'maxpool':
+                self._maxpool_bwd(x, out)
+            else:
+                self._avgpool_bwd(x, out)
+        g0 = self._grad_of(a0)
+        d299 = torch.empty_like(x299)
+        call('sba_enc_stem_bwd', dt, self.stem_w.data_ptr(), a0.t.data_ptr(), g0[0].data_ptr(), d299.data_ptr(), N,
+             299, 32, st)
+        dimg = torch.empty(ishape, dtype=torch.float32, device=self.device)
+        call('sba_resize_bilinear', d299.data_ptr(), dimg.data_ptr(), N * 3, ishape[2], 299, 1, st)
+        if not getattr(self, 'keep_debug', False):
+            self.tape, self._grads, self._saved, self.named = [], {}, None, {}
+        self.d299 = d299 if getattr(self, 'keep_debug', False) else None
+        return dimg
+
+    def __call__(self, img):
+        return _InceptionFn.apply(img, self)
+
+
+class _InceptionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, runner):
+        ctx.runner = runner
+        feats, code = runner.forward(img)
+        return feats.contiguous(), code.contiguous()
+
+    @staticmethod
+    def backward(ctx, dfeat, dcode):
+        return ctx.runner.backward(dfeat, dcode), None

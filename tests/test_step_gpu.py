@@ -245,3 +245,50 @@ def test_full_size_step_properties(dev):
     assert int(st.netsD[2].img_code_s16[3].num_batches_tracked) == 3
     assert int(st.netsD[2].COND_DNET.jointConv[1].num_batches_tracked) == 4     # real, fake, wrong + G step
     assert int(st.netG.h_net1.upsample1[2].num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_image_encoder_hip_vs_torch(dev, dt):
+    """CNN_ENCODER on the HIP kernels (sbagan.inception_hip) against the same module evaluated by
+    PyTorch on the CPU in fp32 (the reference's arithmetic here is torchvision's Inception-v3:
+    model.py:170-267): region features, global code, and the gradient w.r.t. the image."""
+    import model
+    from sbagan import ops
+    from sbagan.inception_hip import InceptionHIP
+    ops.set_compute_dtype(dt)
+    enc = model.CNN_ENCODER(256).eval()
+    sd = enc.state_dict()
+    P = fill.fill_state_dict({k: tuple(v.shape) for k, v in sd.items()}, gain=1.6)
+    for k in P:      # non-trivial running statistics so that the BN folding is exercised
+        if k.endswith('running_mean'):
+            P[k] = 0.1 * fill.uniform(tuple(P[k].shape), fill.tag_of(k))
+        elif k.endswith('running_var'):
+            P[k] = 1.0 + 0.3 * fill.uniform(tuple(P[k].shape), fill.tag_of(k) + 1)
+    enc.load_state_dict(P)
+    B = 2
+    img = fill.uniform((B, 3, 256, 256), 77)
+    xr = img.clone().requires_grad_(True)
+    fr, cr = enc(xr)
+    gfe, gco = fill.unit(tuple(fr.shape), 78), fill.unit(tuple(cr.shape), 79)
+    ((fr * gfe).sum() + (cr * gco).sum()).backward()
+    enc_g = enc.to(dev)
+    run = InceptionHIP(enc_g)
+    xa = img.to(dev).requires_grad_(True)
+    f, c = run(xa)
+    ((f * gfe.to(dev)).sum() + (c * gco.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    tol = 2e-3 if dt == torch.float32 else 6e-2
+    assert f.shape == fr.shape and c.shape == cr.shape
+    assert rel_l2(f, fr) <= tol, rel_l2(f, fr)
+    assert rel_l2(c, cr) <= tol, rel_l2(c, cr)
+    # ReLU masks: an activation whose pre-activation differs in the last bits flips its mask and
+    # changes one gradient element by O(1), so rel-L2 of the image gradient is ~sqrt(flipped
+    # fraction) per layer: ~1e-2 through 47 layers in f32 (measured per block by
+    # tools/debug_encoder.py: 3e-7 at Mixed_7c growing to 1.1e-2 at the stem), tens of percent in
+    # bf16 (any bf16 implementation).  f32 pins the algorithm; bf16 is checked for direction.
+    ga, gr = xa.grad.float().cpu().flatten(), xr.grad.flatten()
+    if dt == torch.float32:
+        assert rel_l2(ga, gr) <= 3e-2, rel_l2(ga, gr)
+    else:
+        cos = float(torch.dot(ga, gr) / (ga.norm() * gr.norm()))
+        assert cos >= 0.85 and rel_l2(ga, gr) <= 0.6, (cos, rel_l2(ga, gr))
