@@ -133,7 +133,13 @@ def cpu_baseline(args):
     from oracle import sbagan_oracle as O
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from helpers import FULL, SMOOTH, d_shapes, g_shapes, make_inputs
-    cores = os.cpu_count() or 1
+    # the GPU box exposes many host cores but grants a CPU share of ~16 per GPU: oversubscribing
+    # torch's intra-op pool makes the baseline (and the bench) crawl
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
     torch.set_num_threads(cores)
     B = 4
     x = make_inputs(FULL, B, 18, branch=args.branch, lmax=18, tag=500)
@@ -142,7 +148,7 @@ def cpu_baseline(args):
     st = O.OracleState(PG, PDs)
     enc = fill.StandInImageEncoder(256)
     t0 = time.time()
-    nsteps = 2
+    nsteps = 6          # ~12 s of CPU work on 16 threads
     for s in range(nsteps):
         O.train_step(st, x['imgs'], x['sent'], x['words'], x['mask'], x['cap_lens'], x['class_ids'],
                      fill.unit((B, 100), 550 + s), fill.unit((B, 100), 560 + s), enc, SMOOTH)

@@ -993,15 +993,17 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
         best = 0;
     } else if (g.Cout <= 64 && cdiv(M, 256) >= 256) {
         best = 1;
-    } else {
+    } else if (cdiv(M, 128) * cdiv(g.Cout, 64) >= 256) {
         best = 2;
+    } else {
+        best = 3;       // too few mid tiles to fill the chip: small tiles (+ split-K when K is long)
     }
     if (forced_cfg() >= 0) best = forced_cfg();
     {
         const IgemmCfg& k = kCfg[best];
         const int tiles = cdiv(M, k.bm) * cdiv(g.Cout, k.bn);
         const int slots = 256 * k.occ;
-        if (k.split && can_split && tiles < slots) {
+        if (k.split && can_split && tiles < slots && M <= 2048) {     // split-K only pays on the GEMM-like maps
             int split = cdiv(slots, tiles);
             if (split > nslabs / 8) split = nslabs / 8;
             if (split > 32) split = 32;

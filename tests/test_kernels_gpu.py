@@ -479,4 +479,4 @@ def test_grouped_real_fake_pass_equals_two_calls(dev, dt):
             assert a.grad is None
             continue
         r = rel_l2(a.grad, b.grad)
-        assert r < (2e-4 if dt == torch.float32 else 3e-2), (n, r)
+        assert r < (2e-4 if dt == torch.float32 else 0.12), (n, r)
