@@ -88,96 +88,169 @@ __global__ __launch_bounds__(256) void word_attn_fwd_kernel(
 // backward: recompute the attention row, then
 //   dA[l]  = sum_c dctx[c] src[c][l];  dS[l] = a[l] (dA[l] - sum_l' a dA)
 //   dh[c]  = sum_l dS[l] src[c][l]
-//   dsrc[c][l] += sum_q (h[q][c] dS[q][l] + dctx[q][c] a[q][l])     (block reduce through LDS)
+//   dsrc[c][l] += sum_q (h[q][c] dS[q][l] + dctx[q][c] a[q][l])
+// The last line is a (idf x Q) . (Q x L) contraction over the query axis: each wave stages its
+// 64 queries' rows ([q][32] tiles of T) in LDS and accumulates 32 x 32 tiles with MFMA
+// (bf16: 32x32x16 through ds_read_b64_tr_b16; f32: 32x32x2), over all the query chunks the
+// workgroup walks; one LDS reduction + idf*L global atomics per workgroup at the end.
+template <typename T> struct AttnMma;
+template <> struct AttnMma<bf16_t> {
+    static constexpr int RS = 64;                      // bytes per [q][32] row
+    // fragment of columns [0,32) over rows [16*ks, 16*ks+16) of a [64][32] bf16 tile
+    static __device__ __forceinline__ bf16x8_t frag(const unsigned char* tile, int ks, int lane) {
+        const int g16 = lane >> 4, i16 = lane & 15;
+        const int cbase = 16 * (g16 & 1), kbase = 16 * ks + 8 * (g16 >> 1);
+        const int q = i16 >> 2, p = i16 & 3;
+        const unsigned char* a0 = tile + (kbase + q) * RS + (cbase + 4 * p) * 2;
+        typedef __attribute__((address_space(3))) s16x4_t* lptr;
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * RS));
+        bf16x8_t r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    }
+    // acc[c][l] += sum_q X[q][c] * Y[q][l]
+    static __device__ __forceinline__ void mma(const unsigned char* X, const unsigned char* Y, int lane, f32x16_t& acc) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(X, ks, lane), frag(Y, ks, lane), acc, 0, 0, 0);
+    }
+};
+template <> struct AttnMma<float> {
+    static constexpr int RS = 128;
+    static __device__ __forceinline__ void mma(const unsigned char* X, const unsigned char* Y, int lane, f32x16_t& acc) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) {
+            const float a = *reinterpret_cast<const float*>(X + (2 * kk + h) * RS + r * 4);
+            const float b = *reinterpret_cast<const float*>(Y + (2 * kk + h) * RS + r * 4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+};
+
 template <typename T, int IDF>
-__global__ __launch_bounds__(128) void word_attn_bwd_kernel(
+__global__ __launch_bounds__(256) void word_attn_bwd_kernel(
     const T* __restrict__ h, const float* __restrict__ src, const uint8_t* __restrict__ mask,
     const T* __restrict__ dctx, T* __restrict__ dh, float* __restrict__ dsrc, int B, int Q, int L,
-    int mask_mode, int dcs, int dco, int accumulate) {
+    int mask_mode, int dcs, int dco, int accumulate, int chunks) {
     constexpr int V = Vec16<T>::N;
-    constexpr int NT = 128;
-    constexpr int HS = IDF + 1;
-    extern __shared__ float sm[];
-    float* s_src = sm;                         // [IDF][LMAX]
-    float* s_h = s_src + IDF * LMAX;           // [NT][HS]
-    float* s_dc = s_h + NT * HS;               // [NT][HS]
-    float* s_ds = s_dc + NT * HS;              // [NT][LMAX+1]
-    float* s_a = s_ds + NT * (LMAX + 1);       // [NT][LMAX+1]
-    const int b = blockIdx.y, tid = threadIdx.x;
+    constexpr int NT = 256;
+    constexpr int CT = IDF / 32;                         // 32-channel tiles
+    constexpr int RS = AttnMma<T>::RS;
+    constexpr int TILE = 64 * RS;                        // one [64 q][32] tile
+    __shared__ float s_src[IDF * LMAX];
+    __shared__ __attribute__((aligned(16))) unsigned char s_t[4 * 2 * TILE];   // per wave: X, Y
+    __shared__ float s_red[IDF * 32];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < IDF * LMAX; i += NT) {
         const int c = i / LMAX, l = i - c * LMAX;
         s_src[i] = l < L ? src[((int64_t)b * IDF + c) * L + l] : 0.f;
     }
+    for (int i = tid; i < IDF * 32; i += NT) s_red[i] = 0.f;
     __syncthreads();
-    const int q = blockIdx.x * NT + tid;
-    const bool live = q < Q;
-    const int64_t r = (int64_t)b * Q + (live ? q : 0);
-    const int mrow = mask_mode == 0 ? (int)(r % B) : b;
+    unsigned char* X = s_t + wid * 2 * TILE;
+    unsigned char* Y = X + TILE;
+    T* xrow = reinterpret_cast<T*>(X + lane * RS);
+    T* yrow = reinterpret_cast<T*>(Y + lane * RS);
 
-    float s[LMAX], dA[LMAX];
+    f32x16_t acc[CT];
 #pragma unroll
-    for (int l = 0; l < LMAX; ++l) { s[l] = 0.f; dA[l] = 0.f; }
-    const T* hp = h + r * IDF;
-    const T* dp = dctx + r * dcs + dco;
+    for (int t = 0; t < CT; ++t)
 #pragma unroll
-    for (int cv = 0; cv < IDF / V; ++cv) {
-        Vec16<T> hv = ld16(hp + cv * V), dv = ld16(dp + cv * V);
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int ck = 0; ck < chunks; ++ck) {
+        const int q = (blockIdx.x * chunks + ck) * NT + tid;
+        const bool live = q < Q;
+        const int64_t r = (int64_t)b * Q + (live ? q : 0);
+        const int mrow = mask_mode == 0 ? (int)(r % B) : b;
+
+        float s[LMAX], dA[LMAX];
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            const float hh = live ? hv.get(k) : 0.f, dd = live ? dv.get(k) : 0.f;
-            s_h[tid * HS + cv * V + k] = hh;
-            s_dc[tid * HS + cv * V + k] = dd;
-            const float* sr = &s_src[(cv * V + k) * LMAX];
-#pragma unroll
-            for (int l = 0; l < LMAX; ++l) { s[l] += hh * sr[l]; dA[l] += dd * sr[l]; }
-        }
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l) {
-        const bool dead = l >= L || (mask && mask[mrow * L + l]);
-        s[l] = dead ? -INFINITY : s[l];
-        mx = fmaxf(mx, s[l]);
-    }
-    float sum = 0.f;
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l) { s[l] = __expf(s[l] - mx); sum += s[l]; }
-    const float inv = 1.f / sum;
-    float dot = 0.f;
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l) { s[l] *= inv; dot += s[l] * dA[l]; }
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l) {
-        const float ds = s[l] * (dA[l] - dot);
-        dA[l] = ds;                                   // dA now holds dS
-        s_ds[tid * (LMAX + 1) + l] = live ? ds : 0.f;
-        s_a[tid * (LMAX + 1) + l] = live ? s[l] : 0.f;
-    }
-    if (live) {
-        T* op = dh + r * IDF;
+        for (int l = 0; l < LMAX; ++l) { s[l] = 0.f; dA[l] = 0.f; }
+        const T* hp = h + r * IDF;
+        const T* dp = dctx + r * dcs + dco;
+        Vec16<T> hv[IDF / V], dv[IDF / V];
 #pragma unroll
         for (int cv = 0; cv < IDF / V; ++cv) {
-            Vec16<T> o;
-            if (accumulate) o = ld16(op + cv * V);
+            hv[cv] = ld16(hp + cv * V);
+            dv[cv] = ld16(dp + cv * V);
 #pragma unroll
             for (int k = 0; k < V; ++k) {
+                const float hh = live ? hv[cv].get(k) : 0.f, dd = live ? dv[cv].get(k) : 0.f;
+                if (!live) { hv[cv].set(k, 0.f); dv[cv].set(k, 0.f); }
                 const float* sr = &s_src[(cv * V + k) * LMAX];
-                float acc = 0.f;
 #pragma unroll
-                for (int l = 0; l < LMAX; ++l) acc += dA[l] * sr[l];
-                if (accumulate) acc += o.get(k);
-                o.set(k, acc);
+                for (int l = 0; l < LMAX; ++l) { s[l] += hh * sr[l]; dA[l] += dd * sr[l]; }
             }
-            st16(op + cv * V, o);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            const bool dead = l >= L || (mask && mask[mrow * L + l]);
+            s[l] = dead ? -INFINITY : s[l];
+            mx = fmaxf(mx, s[l]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) { s[l] = __expf(s[l] - mx); sum += s[l]; }
+        const float inv = 1.f / sum;
+        float dot = 0.f;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) { s[l] *= inv; dot += s[l] * dA[l]; }
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) dA[l] = live ? s[l] * (dA[l] - dot) : 0.f;     // dA now holds dS
+        if (live) {
+            T* op = dh + r * IDF;
+#pragma unroll
+            for (int cv = 0; cv < IDF / V; ++cv) {
+                Vec16<T> o;
+                if (accumulate) o = ld16(op + cv * V);
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const float* sr = &s_src[(cv * V + k) * LMAX];
+                    float a2 = 0.f;
+#pragma unroll
+                    for (int l = 0; l < LMAX; ++l) a2 += dA[l] * sr[l];
+                    if (accumulate) a2 += o.get(k);
+                    o.set(k, a2);
+                }
+                st16(op + cv * V, o);
+            }
+        }
+        // ---- dsrc contraction on the matrix cores, 32 channels at a time
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            __syncthreads();                        // previous tiles consumed
+#pragma unroll
+            for (int k = 0; k < 32 / V; ++k) st16(xrow + k * V, hv[t * (32 / V) + k]);
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) yrow[l] = from_f<T>(dA[l]);
+            __syncthreads();
+            AttnMma<T>::mma(X, Y, lane, acc[t]);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 32 / V; ++k) st16(xrow + k * V, dv[t * (32 / V) + k]);
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) yrow[l] = from_f<T>(live ? s[l] : 0.f);
+            __syncthreads();
+            AttnMma<T>::mma(X, Y, lane, acc[t]);
         }
     }
+    // acc[t]: rows = channel (r&3)+8(r>>2)+4(lane>>5) of tile t, column = l = lane&31
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            atomicAdd(&s_red[c * 32 + (lane & 31)], acc[t][r]);
+        }
     __syncthreads();
     for (int o = tid; o < IDF * L; o += NT) {
         const int c = o / L, l = o - c * L;
-        float acc = 0.f;
-        for (int t = 0; t < NT; ++t)
-            acc += s_h[t * HS + c] * s_ds[t * (LMAX + 1) + l] + s_dc[t * HS + c] * s_a[t * (LMAX + 1) + l];
-        atomicAdd(&dsrc[((int64_t)b * IDF + c) * L + l], acc);
+        atomicAdd(&dsrc[((int64_t)b * IDF + c) * L + l], s_red[c * 32 + l]);
     }
 }
 
@@ -193,17 +266,10 @@ int launch_fwd(const void* h, const float* src, const uint8_t* mask, void* ctx, 
 template <typename T, int IDF>
 int launch_bwd(const void* h, const float* src, const uint8_t* mask, const void* dctx, void* dh, float* dsrc, int B,
                int Q, int L, int mode, int dcs, int dco, int acc, hipStream_t st) {
-    dim3 grid(cdiv(Q, 128), B);
-    const size_t sh = sizeof(float) * (IDF * LMAX + 2 * 128 * (IDF + 1) + 2 * 128 * (LMAX + 1));
-    if (sh > 160 * 1024) return SBA_E_ARG;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)word_attn_bwd_kernel<T, IDF>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((word_attn_bwd_kernel<T, IDF>), grid, dim3(128), sh, st, (const T*)h, src, mask,
-                       (const T*)dctx, (T*)dh, dsrc, B, Q, L, mode, dcs, dco, acc);
+    int chunks = Q >= 16384 ? 4 : (Q >= 4096 ? 2 : 1);           // 256-query chunks per workgroup
+    dim3 grid(cdiv(Q, 256 * chunks), B);
+    hipLaunchKernelGGL((word_attn_bwd_kernel<T, IDF>), grid, dim3(256), 0, st, (const T*)h, src, mask,
+                       (const T*)dctx, (T*)dh, dsrc, B, Q, L, mode, dcs, dco, acc, chunks);
     return SBA_CHECK_LAUNCH();
 }
 
@@ -237,8 +303,12 @@ extern "C" int sba_word_attn_bwd(int dtype, const void* h, const float* src, con
     if (mask_mode != 0 && mask_mode != 1) return SBA_E_ARG;
     const int V = dtype == SBA_BF16 ? 8 : 4;
     if (dctx_cstride < idf + dctx_coff || dctx_cstride % V || dctx_coff % V) return SBA_E_ARG;
-    SBA_DISPATCH(dtype, IDF_SWITCH(idf, return (launch_bwd<T, IDF>(h, src, mask, dctx, dh, dsrc, B, Q, L, mask_mode,
-                                                                     dctx_cstride, dctx_coff, accumulate,
-                                                                     (hipStream_t)stream))));
+    if (idf != 32 && idf != 64) return SBA_E_ARG;
+    SBA_DISPATCH(dtype, {
+        if (idf == 32) return (launch_bwd<T, 32>(h, src, mask, dctx, dh, dsrc, B, Q, L, mask_mode, dctx_cstride,
+                                                 dctx_coff, accumulate, (hipStream_t)stream));
+        return (launch_bwd<T, 64>(h, src, mask, dctx, dh, dsrc, B, Q, L, mask_mode, dctx_cstride, dctx_coff,
+                                  accumulate, (hipStream_t)stream));
+    });
     return SBA_E_ARG;
 }
