@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--phases', action='store_true', help='also print per-phase times of an eager step (stderr)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--child', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -158,11 +159,30 @@ def cpu_baseline(args):
                       'torch CPU threads=%d' % (nsteps, args.branch, B, cores)}
 
 
+def supervise(args):
+    """Single-GPU runs execute in a child process so that a failure of the optional hipGraph
+    capture (a ROCm runtime crash cannot be caught in-process) degrades to eager launches instead
+    of losing the measurement.  The parent never touches the GPU."""
+    import subprocess
+    base = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]] + ['--child']
+    for extra in ([], ['--graph', '0']):
+        p = subprocess.run(base + extra, stdout=subprocess.PIPE, text=True)
+        lines = [l for l in p.stdout.splitlines() if l.startswith('{') and '"metric"' in l]
+        if p.returncode == 0 and lines:
+            print(lines[-1], flush=True)
+            return 0
+        sys.stderr.write('bench child failed (rc=%d)%s\n' % (p.returncode, '; retrying with eager launches'
+                                                               if not extra else ''))
+    return 1
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if world == 1 and args.gpus <= 1 and args.graph and not args.child:
+        sys.exit(supervise(args))
     if args.gpus > 1 or world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')

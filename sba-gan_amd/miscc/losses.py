@@ -128,8 +128,11 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
                 g_loss = ops.BCEMultiFn.apply((1.,), (1.,), cond_logits)
         terms.append(g_loss)
         logs['g_loss%d' % i] = g_loss.detach()
-    # ranking loss on the last scale (losses.py:187-204)
-    with branch(numDs):
+    # ranking loss on the last scale (losses.py:187-204).  An encoder that forks its own streams
+    # (sbagan.inception_hip) stays on the calling stream: it already overlaps the D branches, and
+    # nested forks inside a captured branch crash hipStreamEndCapture on ROCm 7.2.
+    own = streams and not getattr(image_encoder, 'parallel', False)
+    with (branch(numDs) if own else contextlib.nullcontext()):
         region_features, cnn_code = image_encoder(fake_imgs[numDs - 1])
         w_loss0, w_loss1, _ = words_loss(region_features, words_embs, match_labels, cap_lens, class_ids,
                                          batch_size)

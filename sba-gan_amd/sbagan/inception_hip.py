@@ -100,6 +100,8 @@ class InceptionHIP(object):
         self.nef = enc.nef
         self._convs = {}
         self._geoms = {}
+        self._side, self._branch_ops, self._block = None, None, None
+        self.parallel = True
         dev = next(enc.parameters()).device
         self.device = dev
         for name, m in enc.named_modules():
@@ -147,8 +149,11 @@ class InceptionHIP(object):
         g = _geom(N, H, W, L.Ip, OH, OW, L.Op, taps, sy=L.stride, xcs=Ct, xco=x.coff, ycs=out.shape[3],
                   yco=out.coff, relu=1 if L.relu else 0)
         self._igemm(x.t.data_ptr(), L.w_fwd, out.t.data_ptr(), None, L.bias, g)
-        self.tape.append(('conv', L, x, out))
+        self._record(('conv', L, x, out))
         return out
+
+    def _record(self, op):
+        (self._branch_ops if self._branch_ops is not None else self.tape).append(op)
 
     def _grad_of(self, a):
         """gradient buffer of the tensor behind activation `a`, and whether it already holds a value"""
@@ -197,7 +202,7 @@ class InceptionHIP(object):
             out = _Act(self._new(N, OH, OW, x.C))
         call('sba_maxpool3x3s2_fwd', self._dt(), x.t.data_ptr(), out.t.data_ptr(), N, H, W, x.C, Ct, x.coff,
              out.shape[3], out.coff, ops._stream())
-        self.tape.append(('maxpool', None, x, out))
+        self._record(('maxpool', None, x, out))
         return out
 
     def _maxpool_bwd(self, x, out):
@@ -212,7 +217,7 @@ class InceptionHIP(object):
         out = _Act(self._new(N, H, W, x.C))
         call('sba_avgpool3x3', self._dt(), x.t.data_ptr(), out.t.data_ptr(), N, H, W, x.C, Ct, x.coff, x.C, 0, 0,
              ops._stream())
-        self.tape.append(('avgpool', None, x, out))
+        self._record(('avgpool', None, x, out))
         return out
 
     def _avgpool_bwd(self, x, out):
@@ -223,62 +228,130 @@ class InceptionHIP(object):
         gx[1] = True
 
     # ------------------------------------------------------------------ Inception blocks
+    # The branches of a block are independent given its input: each runs on its own HIP stream
+    # (forward and backward), which matters because the individual convs (M = 20*35^2 ... 20*8^2
+    # pixels) are far too small to fill 256 CUs one at a time.
+    def _streams(self):
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.device) for _ in range(4)]
+        return self._side
+
+    class _Branch(object):
+        def __init__(self, runner, k):
+            self.r, self.k = runner, k
+
+        def __enter__(self):
+            r = self.r
+            r._branch_ops = []
+            if r.parallel:
+                st = r._streams()[self.k]
+                st.wait_stream(r._main)
+                self.ctx = torch.cuda.stream(st)
+                self.ctx.__enter__()
+            return self
+
+        def __exit__(self, *a):
+            r = self.r
+            if r.parallel:
+                self.ctx.__exit__(*a)
+            r._block.append((self.k, r._branch_ops))
+            r._branch_ops = None
+
+    def _begin_block(self):
+        self._main = torch.cuda.current_stream()
+        self._block = []
+
+    def _end_block(self):
+        if self.parallel:
+            for k, _ in self._block:
+                self._main.wait_stream(self._streams()[k])
+        self.tape.append(('block', self._block))
+        self._block = None
+
     def _A(self, p, x, pf):
         N, H, W, _ = x.shape
         cat = self._new(N, H, W, 64 + 64 + 96 + pf)
-        self.conv(p + '.branch1x1', x, _Act(cat, 0, 64))
-        self.conv(p + '.branch5x5_2', self.conv(p + '.branch5x5_1', x), _Act(cat, 64, 64))
-        t = self.conv(p + '.branch3x3dbl_2', self.conv(p + '.branch3x3dbl_1', x))
-        self.conv(p + '.branch3x3dbl_3', t, _Act(cat, 128, 96))
-        self.conv(p + '.branch_pool', self.avgpool(x), _Act(cat, 224, pf))
+        self._begin_block()
+        with self._Branch(self, 0):
+            self.conv(p + '.branch1x1', x, _Act(cat, 0, 64))
+        with self._Branch(self, 1):
+            self.conv(p + '.branch5x5_2', self.conv(p + '.branch5x5_1', x), _Act(cat, 64, 64))
+        with self._Branch(self, 2):
+            t = self.conv(p + '.branch3x3dbl_2', self.conv(p + '.branch3x3dbl_1', x))
+            self.conv(p + '.branch3x3dbl_3', t, _Act(cat, 128, 96))
+        with self._Branch(self, 3):
+            self.conv(p + '.branch_pool', self.avgpool(x), _Act(cat, 224, pf))
+        self._end_block()
         return _Act(cat)
 
     def _B(self, p, x):
         N, H, W, _ = x.shape
         OH = (H - 3) // 2 + 1
         cat = self._new(N, OH, OH, 384 + 96 + x.C)
-        self.conv(p + '.branch3x3', x, _Act(cat, 0, 384))
-        t = self.conv(p + '.branch3x3dbl_2', self.conv(p + '.branch3x3dbl_1', x))
-        self.conv(p + '.branch3x3dbl_3', t, _Act(cat, 384, 96))
-        self.maxpool(x, _Act(cat, 480, x.C))
+        self._begin_block()
+        with self._Branch(self, 0):
+            self.conv(p + '.branch3x3', x, _Act(cat, 0, 384))
+        with self._Branch(self, 1):
+            t = self.conv(p + '.branch3x3dbl_2', self.conv(p + '.branch3x3dbl_1', x))
+            self.conv(p + '.branch3x3dbl_3', t, _Act(cat, 384, 96))
+        with self._Branch(self, 2):
+            self.maxpool(x, _Act(cat, 480, x.C))
+        self._end_block()
         return _Act(cat)
 
     def _C(self, p, x):
         N, H, W, _ = x.shape
         cat = self._new(N, H, W, 768)
-        self.conv(p + '.branch1x1', x, _Act(cat, 0, 192))
-        t = self.conv(p + '.branch7x7_2', self.conv(p + '.branch7x7_1', x))
-        self.conv(p + '.branch7x7_3', t, _Act(cat, 192, 192))
-        t = self.conv(p + '.branch7x7dbl_1', x)
-        for k in (2, 3, 4):
-            t = self.conv(p + '.branch7x7dbl_%d' % k, t)
-        self.conv(p + '.branch7x7dbl_5', t, _Act(cat, 384, 192))
-        self.conv(p + '.branch_pool', self.avgpool(x), _Act(cat, 576, 192))
+        self._begin_block()
+        with self._Branch(self, 0):
+            self.conv(p + '.branch1x1', x, _Act(cat, 0, 192))
+        with self._Branch(self, 1):
+            t = self.conv(p + '.branch7x7_2', self.conv(p + '.branch7x7_1', x))
+            self.conv(p + '.branch7x7_3', t, _Act(cat, 192, 192))
+        with self._Branch(self, 2):
+            t = self.conv(p + '.branch7x7dbl_1', x)
+            for k in (2, 3, 4):
+                t = self.conv(p + '.branch7x7dbl_%d' % k, t)
+            self.conv(p + '.branch7x7dbl_5', t, _Act(cat, 384, 192))
+        with self._Branch(self, 3):
+            self.conv(p + '.branch_pool', self.avgpool(x), _Act(cat, 576, 192))
+        self._end_block()
         return _Act(cat)
 
     def _D(self, p, x):
         N, H, W, _ = x.shape
         OH = (H - 3) // 2 + 1
         cat = self._new(N, OH, OH, 320 + 192 + x.C)
-        self.conv(p + '.branch3x3_2', self.conv(p + '.branch3x3_1', x), _Act(cat, 0, 320))
-        t = self.conv(p + '.branch7x7x3_1', x)
-        for k in (2, 3):
-            t = self.conv(p + '.branch7x7x3_%d' % k, t)
-        self.conv(p + '.branch7x7x3_4', t, _Act(cat, 320, 192))
-        self.maxpool(x, _Act(cat, 512, x.C))
+        self._begin_block()
+        with self._Branch(self, 0):
+            self.conv(p + '.branch3x3_2', self.conv(p + '.branch3x3_1', x), _Act(cat, 0, 320))
+        with self._Branch(self, 1):
+            t = self.conv(p + '.branch7x7x3_1', x)
+            for k in (2, 3):
+                t = self.conv(p + '.branch7x7x3_%d' % k, t)
+            self.conv(p + '.branch7x7x3_4', t, _Act(cat, 320, 192))
+        with self._Branch(self, 2):
+            self.maxpool(x, _Act(cat, 512, x.C))
+        self._end_block()
         return _Act(cat)
 
     def _E(self, p, x):
         N, H, W, _ = x.shape
         cat = self._new(N, H, W, 2048)
-        self.conv(p + '.branch1x1', x, _Act(cat, 0, 320))
-        t = self.conv(p + '.branch3x3_1', x)
-        self.conv(p + '.branch3x3_2a', t, _Act(cat, 320, 384))
-        self.conv(p + '.branch3x3_2b', t, _Act(cat, 704, 384))
-        t = self.conv(p + '.branch3x3dbl_2', self.conv(p + '.branch3x3dbl_1', x))
-        self.conv(p + '.branch3x3dbl_3a', t, _Act(cat, 1088, 384))
-        self.conv(p + '.branch3x3dbl_3b', t, _Act(cat, 1472, 384))
-        self.conv(p + '.branch_pool', self.avgpool(x), _Act(cat, 1856, 192))
+        self._begin_block()
+        with self._Branch(self, 0):
+            self.conv(p + '.branch1x1', x, _Act(cat, 0, 320))
+        with self._Branch(self, 1):
+            t = self.conv(p + '.branch3x3_1', x)
+            self.conv(p + '.branch3x3_2a', t, _Act(cat, 320, 384))
+            self.conv(p + '.branch3x3_2b', t, _Act(cat, 704, 384))
+        with self._Branch(self, 2):
+            t = self.conv(p + '.branch3x3dbl_2', self.conv(p + '.branch3x3dbl_1', x))
+            self.conv(p + '.branch3x3dbl_3a', t, _Act(cat, 1088, 384))
+            self.conv(p + '.branch3x3dbl_3b', t, _Act(cat, 1472, 384))
+        with self._Branch(self, 3):
+            self.conv(p + '.branch_pool', self.avgpool(x), _Act(cat, 1856, 192))
+        self._end_block()
         return _Act(cat)
 
     # ------------------------------------------------------------------ forward / backward
@@ -341,20 +414,48 @@ class InceptionHIP(object):
         if dcode is not None:
             gc[0].view(N, -1)[:, :self.nef] = dcode.to(self.dtype)
         gc[1] = True
-        for kind, L, x, out in reversed(self.tape):
+        def run(op):
+            kind, L, x, out = op
             if kind == 'conv':
+                self._conv_bwd(L, x, out)
                 if x is pooled_t:
-                    self._conv_bwd(L, x, out)
                     gp = self._grad_of(pooled_t)[0].view(N, 2048).float().contiguous()
                     gl = self._grad_of(last)
                     call('sba_global_avgpool', dt, gl[0].data_ptr(), gp.data_ptr(), N, 64, 2048, 1, st)
                     gl[1] = True
-                else:
-                    self._conv_bwd(L, x, out)
             elif kind == 'maxpool':
                 self._maxpool_bwd(x, out)
             else:
                 self._avgpool_bwd(x, out)
+
+        for entry in reversed(self.tape):
+            if entry[0] != 'block':
+                run(entry)
+                continue
+            # a block: every branch back-propagates on its own stream down to (excluding) its first
+            # op, the one that accumulates into the shared block-input gradient; those run in order
+            # on the main stream after the join
+            main = torch.cuda.current_stream()
+            heads = []
+            for k, ops_k in entry[1]:
+                heads.append(ops_k[0])
+                if len(ops_k) == 1:
+                    continue
+                if self.parallel:
+                    sk = self._streams()[k]
+                    sk.wait_stream(main)
+                    with torch.cuda.stream(sk):
+                        for op in reversed(ops_k[1:]):
+                            run(op)
+                else:
+                    for op in reversed(ops_k[1:]):
+                        run(op)
+            if self.parallel:
+                for k, ops_k in entry[1]:
+                    if len(ops_k) > 1:
+                        main.wait_stream(self._streams()[k])
+            for op in heads:
+                run(op)
         g0 = self._grad_of(a0)
         d299 = torch.empty_like(x299)
         call('sba_enc_stem_bwd', dt, self.stem_w.data_ptr(), a0.t.data_ptr(), g0[0].data_ptr(), d299.data_ptr(), N,
