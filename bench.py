@@ -43,7 +43,9 @@ def parse():
                     help='CNN_ENCODER inside the G step: the Inception-v3 trunk on the HIP kernels '
                          '(sbagan.inception_hip), the same module through PyTorch-ROCm/MIOpen, or the light '
                          'stand-in used by the parity fixtures')
-    ap.add_argument('--graph', type=int, default=1, help='replay the step from a captured hipGraph')
+    ap.add_argument('--graph', type=int, default=2,
+                    help='0: eager launches; 1: replay the step from a captured hipGraph; 2: capture, time a few '
+                         'untimed probe steps in both modes during warmup and keep the faster one')
     ap.add_argument('--phases', action='store_true', help='also print per-phase times of an eager step (stderr)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -235,6 +237,19 @@ def main():
                 graph.replay()
             torch.cuda.synchronize()
             mode = 'hipgraph'
+            if args.graph == 2:
+                def probe(fn, n=4):
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t) / n
+                t_graph, t_eager = probe(graph.replay), probe(one_step)
+                sys.stderr.write('launch probe: hipgraph %.2f ms, eager %.2f ms per step\n'
+                                 % (t_graph * 1e3, t_eager * 1e3))
+                if t_eager < t_graph:
+                    graph, mode = None, 'eager'
         except Exception as e:      # capture is an optimisation, never a requirement
             sys.stderr.write('graph capture failed (%s: %s); timing eager launches\n' % (type(e).__name__, e))
             graph = None

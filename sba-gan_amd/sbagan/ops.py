@@ -324,6 +324,57 @@ def conv_wgrad(x, dy, param, kind):
     call('sba_conv_wgrad', _dt(x), _p(x), _p(dy), _p(gbuf), ctypes.byref(g), _ksplit(tiles, M), _stream())
 
 
+# ---- weight gradients on a companion stream ---------------------------------------------
+# dW = dy^T (*) x and dx = conv^T(dy) of one layer are independent; with SIDE_WGRAD enabled the
+# weight-gradient launch goes to a companion of the current stream so that it overlaps the
+# data-gradient chain (the critical path of a backward pass).  The trainer joins the companions
+# before the optimizer reads the gradients; tensors handed to the companion are kept alive until
+# that join (no record_stream: safe under hipGraph capture).
+SIDE_WGRAD = False
+_COMPANION, _KEEPALIVE = {}, {}
+
+
+def conv_wgrad_overlapped(x, dy, param, kind):
+    if not SIDE_WGRAD:
+        return conv_wgrad(x, dy, param, kind)
+    cur = torch.cuda.current_stream()
+    key = cur.cuda_stream
+    comp = _COMPANION.get(key)
+    if comp is None:
+        comp = _COMPANION[key] = torch.cuda.Stream(device=x.device)
+        _KEEPALIVE[key] = []
+    param_grad(param)                     # allocate (if needed) on the caller's stream
+    comp.wait_stream(cur)
+    with torch.cuda.stream(comp):
+        conv_wgrad(x, dy, param, kind)
+    _KEEPALIVE[key].extend((x, dy))
+
+
+def join_wgrads():
+    """Make the current stream wait for the weight gradients issued from it."""
+    cur = torch.cuda.current_stream()
+    comp = _COMPANION.get(cur.cuda_stream)
+    if comp is not None:
+        cur.wait_stream(comp)
+        _KEEPALIVE[cur.cuda_stream].clear()
+
+
+def wgrad_tail_stream():
+    """One-way variant of join_wgrads for a stream that is itself a fork: returns the stream on
+    which the rest of the update (all-reduce, Adam) must be issued -- the companion, ordered
+    after everything the current stream has done -- instead of joining the companion back.
+    hipStreamEndCapture (ROCm 7.2) crashes on a fork -> sub-fork -> join-into-the-fork round
+    trip, while one-way edges that only re-join the capture's origin stream are fine
+    (tools/debug_nested.py)."""
+    cur = torch.cuda.current_stream()
+    comp = _COMPANION.get(cur.cuda_stream)
+    if comp is None:
+        return cur
+    comp.wait_stream(cur)
+    _KEEPALIVE[cur.cuda_stream].clear()
+    return comp
+
+
 class BNState(object):
     """per-forward BatchNorm quantities: rows of aux = scale, shift, mean, rstd."""
     __slots__ = ('aux', 'C', 'rows')
@@ -443,7 +494,7 @@ class ConvBNActFn(torch.autograd.Function):
                 sl = slice(g * ng, (g + 1) * ng)
                 bn_act_backward(y[sl], dout[sl], ctx.sts[g], layer.bn, act, ctx.needs_input_grad[2], dy=dy[sl])
         if ctx.needs_input_grad[1]:
-            conv_wgrad(x, dy, layer.conv.weight, kind)
+            conv_wgrad_overlapped(x, dy, layer.conv.weight, kind)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad(dy, layer.pw, kind, x.shape[2:])
@@ -477,11 +528,11 @@ class ResBlockFn(torch.autograd.Function):
         need_p = ctx.needs_input_grad[1]
         dy2 = bn_act_backward(y2, dout, ctx.st2, blk.l2.bn, ACT_NONE, need_p)
         if need_p:
-            conv_wgrad(a1, dy2, blk.l2.conv.weight, '3x3')
+            conv_wgrad_overlapped(a1, dy2, blk.l2.conv.weight, '3x3')
         da1 = conv_dgrad(dy2, blk.l2.pw, '3x3', a1.shape[2:])
         dy1 = bn_act_backward(y1, da1, ctx.st1, blk.l1.bn, ACT_GLU, need_p)
         if need_p:
-            conv_wgrad(x, dy1, blk.l1.conv.weight, '3x3')
+            conv_wgrad_overlapped(x, dy1, blk.l1.conv.weight, '3x3')
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv_dgrad(dy1, blk.l1.pw, '3x3', x.shape[2:], addend=dout)

@@ -163,6 +163,7 @@ class GANStep(object):
         out = {}
         mark = self._mark
         mark('start')
+        ops.SIDE_WGRAD = self.overlap_wgrad
         ops.ARENA.begin(self.device)          # one memset for all per-layer accumulators of the step
         netG.ca_net.eps = eps
         fake_imgs, _, mu, logvar = netG(noise, sent_emb, words_embs, mask)
@@ -174,6 +175,7 @@ class GANStep(object):
         # the streams become parallel branches of the graph.
         main = torch.cuda.current_stream()
         streams = self._d_streams()[:len(netsD)] if self.concurrent_d else [main] * len(netsD)
+        tails = []
         for i, netD in enumerate(netsD):
             st = streams[i]
             if st is not main:
@@ -184,9 +186,16 @@ class GANStep(object):
                                           self.fake_labels)
                 errD.backward()
                 out['errD%d' % i] = errD.detach()
-                self._allreduce_wait(self._allreduce_start(self.flatD[i]))
-                self.optD[i].step(1.0 / self.world)
-        for st in streams:
+                if st is main:
+                    ops.join_wgrads()
+                    tail = main
+                else:
+                    tail = ops.wgrad_tail_stream()
+                with torch.cuda.stream(tail):
+                    self._allreduce_wait(self._allreduce_start(self.flatD[i]))
+                    self.optD[i].step(1.0 / self.world)
+                tails.append(tail)
+        for st in streams + tails:
             if st is not main:
                 main.wait_stream(st)
         mark('d_steps')
@@ -201,6 +210,7 @@ class GANStep(object):
         errG_total = errG_total + kl
         mark('g_loss_forward')
         errG_total.backward()
+        ops.join_wgrads()
         mark('g_backward')
         for p in self._d_params:
             p.requires_grad_(True)
@@ -213,6 +223,7 @@ class GANStep(object):
         out.update(logs)
         self.fake_imgs = [f.detach() for f in fake_imgs]
         ops.ARENA.end()
+        ops.SIDE_WGRAD = False
         return out
 
     phase_events = None      # set to [] to record (name, cuda event) pairs per step (bench.py --phases)
@@ -224,6 +235,7 @@ class GANStep(object):
             self.phase_events.append((name, e))
 
     concurrent_d = True
+    overlap_wgrad = True
 
     def _d_streams(self):
         if getattr(self, '_streams', None) is None:
