@@ -16,6 +16,16 @@ namespace {
 
 constexpr int LMAX = 32;
 
+// bit l set <=> word l takes no part in the softmax (padding column l >= L, or masked in row `mrow`)
+__device__ __forceinline__ uint32_t dead_words(const uint8_t* __restrict__ mask, int mrow, int L) {
+    uint32_t bits = L < 32 ? ~((1u << L) - 1u) : 0u;
+    if (mask) {
+#pragma unroll 1
+        for (int l = 0; l < L; ++l) bits |= (mask[mrow * L + l] ? 1u : 0u) << l;
+    }
+    return bits;
+}
+
 template <typename T, int IDF>
 __global__ __launch_bounds__(256) void word_attn_fwd_kernel(
     const T* __restrict__ h, const float* __restrict__ src, const uint8_t* __restrict__ mask,
@@ -37,7 +47,9 @@ __global__ __launch_bounds__(256) void word_attn_fwd_kernel(
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) s[l] = 0.f;
     const T* hp = h + r * IDF;
-#pragma unroll
+    // The channel loops stay ROLLED: fully unrolled, the compiler hoists all IDF*LMAX LDS reads to the
+    // top of the kernel and spills them to scratch (2-15 KB per lane).
+#pragma unroll 1
     for (int cv = 0; cv < IDF / V; ++cv) {
         Vec16<T> hv = ld16(hp + cv * V);
 #pragma unroll
@@ -48,11 +60,11 @@ __global__ __launch_bounds__(256) void word_attn_fwd_kernel(
             for (int l = 0; l < LMAX; ++l) s[l] += hh * sr[l];
         }
     }
+    const uint32_t deadbits = dead_words(mask, mrow, L);
     float mx = -INFINITY;
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
-        const bool dead = l >= L || (mask && mask[mrow * L + l]);
-        s[l] = dead ? -INFINITY : s[l];
+        s[l] = ((deadbits >> l) & 1u) ? -INFINITY : s[l];
         mx = fmaxf(mx, s[l]);
     }
     float sum = 0.f;
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(256) void word_attn_fwd_kernel(
             if (l < L) att[((int64_t)b * L + l) * Q + q] = s[l];
     }
     T* op = ctx + r * ocs + oco;
-#pragma unroll
+#pragma unroll 1
     for (int cv = 0; cv < IDF / V; ++cv) {
         Vec16<T> o;
 #pragma unroll
@@ -95,6 +107,7 @@ __global__ __launch_bounds__(256) void word_attn_fwd_kernel(
 // workgroup walks; one LDS reduction + idf*L global atomics per workgroup at the end.
 template <typename T> struct AttnMma;
 template <> struct AttnMma<bf16_t> {
+    static constexpr int NW = 4;
     static constexpr int RS = 64;                      // bytes per [q][32] row
     // fragment of columns [0,32) over rows [16*ks, 16*ks+16) of a [64][32] bf16 tile
     static __device__ __forceinline__ bf16x8_t frag(const unsigned char* tile, int ks, int lane) {
@@ -118,6 +131,7 @@ template <> struct AttnMma<bf16_t> {
     }
 };
 template <> struct AttnMma<float> {
+    static constexpr int NW = 2;
     static constexpr int RS = 128;
     static __device__ __forceinline__ void mma(const unsigned char* X, const unsigned char* Y, int lane, f32x16_t& acc) {
         const int r = lane & 31, h = lane >> 5;
@@ -131,17 +145,19 @@ template <> struct AttnMma<float> {
 };
 
 template <typename T, int IDF>
-__global__ __launch_bounds__(256) void word_attn_bwd_kernel(
+__global__ __launch_bounds__(AttnMma<T>::NW * 64) void word_attn_bwd_kernel(
     const T* __restrict__ h, const float* __restrict__ src, const uint8_t* __restrict__ mask,
     const T* __restrict__ dctx, T* __restrict__ dh, float* __restrict__ dsrc, int B, int Q, int L,
     int mask_mode, int dcs, int dco, int accumulate, int chunks) {
     constexpr int V = Vec16<T>::N;
-    constexpr int NT = 256;
+    constexpr int NW = AttnMma<T>::NW;                   // waves per workgroup (LDS budget: 4 bf16, 2 f32)
+    constexpr int NT = NW * 64;
     constexpr int CT = IDF / 32;                         // 32-channel tiles
     constexpr int RS = AttnMma<T>::RS;
     constexpr int TILE = 64 * RS;                        // one [64 q][32] tile
+    constexpr int WAVE_BYTES = (2 * CT + 2) * TILE;      // per wave: h tiles, dctx tiles, dS tile, a tile
     __shared__ float s_src[IDF * LMAX];
-    __shared__ __attribute__((aligned(16))) unsigned char s_t[4 * 2 * TILE];   // per wave: X, Y
+    __shared__ __attribute__((aligned(16))) unsigned char s_t[NW * WAVE_BYTES];
     __shared__ float s_red[IDF * 32];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < IDF * LMAX; i += NT) {
@@ -150,10 +166,10 @@ __global__ __launch_bounds__(256) void word_attn_bwd_kernel(
     }
     for (int i = tid; i < IDF * 32; i += NT) s_red[i] = 0.f;
     __syncthreads();
-    unsigned char* X = s_t + wid * 2 * TILE;
-    unsigned char* Y = X + TILE;
-    T* xrow = reinterpret_cast<T*>(X + lane * RS);
-    T* yrow = reinterpret_cast<T*>(Y + lane * RS);
+    unsigned char* XH = s_t + wid * WAVE_BYTES;          // [CT][64 q][32 ch] of h
+    unsigned char* XD = XH + CT * TILE;                  // [CT][64 q][32 ch] of dctx
+    unsigned char* YS = XD + CT * TILE;                  // [64 q][32 l] of dS
+    unsigned char* YA = YS + TILE;                       // [64 q][32 l] of a
 
     f32x16_t acc[CT];
 #pragma unroll
@@ -172,25 +188,31 @@ __global__ __launch_bounds__(256) void word_attn_bwd_kernel(
         for (int l = 0; l < LMAX; ++l) { s[l] = 0.f; dA[l] = 0.f; }
         const T* hp = h + r * IDF;
         const T* dp = dctx + r * dcs + dco;
-        Vec16<T> hv[IDF / V], dv[IDF / V];
-#pragma unroll
+        // rolled channel loops (see the forward kernel); the rows go to the wave's LDS tiles as they
+        // are read, so nothing but the 2 x LMAX scores stays in registers
+#pragma unroll 1
         for (int cv = 0; cv < IDF / V; ++cv) {
-            hv[cv] = ld16(hp + cv * V);
-            dv[cv] = ld16(dp + cv * V);
+            Vec16<T> hv = ld16(hp + cv * V), dv = ld16(dp + cv * V);
+            if (!live) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) { hv.set(k, 0.f); dv.set(k, 0.f); }
+            }
+            const int t = (cv * V) / 32, cin = cv * V - t * 32;
+            st16(reinterpret_cast<T*>(XH + t * TILE + lane * RS) + cin, hv);
+            st16(reinterpret_cast<T*>(XD + t * TILE + lane * RS) + cin, dv);
 #pragma unroll
             for (int k = 0; k < V; ++k) {
-                const float hh = live ? hv[cv].get(k) : 0.f, dd = live ? dv[cv].get(k) : 0.f;
-                if (!live) { hv[cv].set(k, 0.f); dv[cv].set(k, 0.f); }
+                const float hh = hv.get(k), dd = dv.get(k);
                 const float* sr = &s_src[(cv * V + k) * LMAX];
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l) { s[l] += hh * sr[l]; dA[l] += dd * sr[l]; }
             }
         }
+        const uint32_t deadbits = dead_words(mask, mrow, L);
         float mx = -INFINITY;
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
-            const bool dead = l >= L || (mask && mask[mrow * L + l]);
-            s[l] = dead ? -INFINITY : s[l];
+            s[l] = ((deadbits >> l) & 1u) ? -INFINITY : s[l];
             mx = fmaxf(mx, s[l]);
         }
         float sum = 0.f;
@@ -202,9 +224,18 @@ __global__ __launch_bounds__(256) void word_attn_bwd_kernel(
         for (int l = 0; l < LMAX; ++l) { s[l] *= inv; dot += s[l] * dA[l]; }
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) dA[l] = live ? s[l] * (dA[l] - dot) : 0.f;     // dA now holds dS
+        {
+            T* ys = reinterpret_cast<T*>(YS + lane * RS);
+            T* ya = reinterpret_cast<T*>(YA + lane * RS);
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) {
+                ys[l] = from_f<T>(dA[l]);
+                ya[l] = from_f<T>(live ? s[l] : 0.f);
+            }
+        }
         if (live) {
             T* op = dh + r * IDF;
-#pragma unroll
+#pragma unroll 1
             for (int cv = 0; cv < IDF / V; ++cv) {
                 Vec16<T> o;
                 if (accumulate) o = ld16(op + cv * V);
@@ -220,24 +251,14 @@ __global__ __launch_bounds__(256) void word_attn_bwd_kernel(
                 st16(op + cv * V, o);
             }
         }
-        // ---- dsrc contraction on the matrix cores, 32 channels at a time
+        // ---- dsrc contraction on the matrix cores, 32 channels at a time (tiles are wave-private)
+        __syncthreads();
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
-            __syncthreads();                        // previous tiles consumed
-#pragma unroll
-            for (int k = 0; k < 32 / V; ++k) st16(xrow + k * V, hv[t * (32 / V) + k]);
-#pragma unroll
-            for (int l = 0; l < LMAX; ++l) yrow[l] = from_f<T>(dA[l]);
-            __syncthreads();
-            AttnMma<T>::mma(X, Y, lane, acc[t]);
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 32 / V; ++k) st16(xrow + k * V, dv[t * (32 / V) + k]);
-#pragma unroll
-            for (int l = 0; l < LMAX; ++l) yrow[l] = from_f<T>(live ? s[l] : 0.f);
-            __syncthreads();
-            AttnMma<T>::mma(X, Y, lane, acc[t]);
+            AttnMma<T>::mma(XH + t * TILE, YS, lane, acc[t]);
+            AttnMma<T>::mma(XD + t * TILE, YA, lane, acc[t]);
         }
+        __syncthreads();                            // tiles consumed before the next chunk overwrites them
     }
     // acc[t]: rows = channel (r&3)+8(r>>2)+4(lane>>5) of tile t, column = l = lane&31
 #pragma unroll
@@ -266,9 +287,10 @@ int launch_fwd(const void* h, const float* src, const uint8_t* mask, void* ctx, 
 template <typename T, int IDF>
 int launch_bwd(const void* h, const float* src, const uint8_t* mask, const void* dctx, void* dh, float* dsrc, int B,
                int Q, int L, int mode, int dcs, int dco, int acc, hipStream_t st) {
-    int chunks = Q >= 16384 ? 4 : (Q >= 4096 ? 2 : 1);           // 256-query chunks per workgroup
-    dim3 grid(cdiv(Q, 256 * chunks), B);
-    hipLaunchKernelGGL((word_attn_bwd_kernel<T, IDF>), grid, dim3(256), 0, st, (const T*)h, src, mask,
+    constexpr int NT = AttnMma<T>::NW * 64;
+    int chunks = Q >= 16384 ? 4 : (Q >= 4096 ? 2 : 1);           // NT-query chunks per workgroup
+    dim3 grid(cdiv(Q, NT * chunks), B);
+    hipLaunchKernelGGL((word_attn_bwd_kernel<T, IDF>), grid, dim3(NT), 0, st, (const T*)h, src, mask,
                        (const T*)dctx, (T*)dh, dsrc, B, Q, L, mode, dcs, dco, acc, chunks);
     return SBA_CHECK_LAUNCH();
 }

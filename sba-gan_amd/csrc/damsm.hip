@@ -12,7 +12,7 @@
 namespace {
 
 constexpr int NT = 320;       // threads per pair: >= R (289), 5 waves
-constexpr int CCH = 32;       // feature channels staged per LDS chunk
+constexpr int CCH = 16;       // feature channels staged per LDS chunk (sized so that two pairs fit one CU)
 constexpr int TMAX = 32;
 
 struct Lds {

@@ -32,6 +32,13 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
 // ---------------------------------------------------------------------------
 // MFMA over one 64-byte K slab held in LDS as rows of ROWB bytes
 // ---------------------------------------------------------------------------
+// two packed bf16 values + two packed bf16 values, rounded back to bf16
+__device__ __forceinline__ uint32_t add_bf16x2(uint32_t p, uint32_t q) {
+    const float lo = __uint_as_float(p << 16) + __uint_as_float(q << 16);
+    const float hi = __uint_as_float(p & 0xffff0000u) + __uint_as_float(q & 0xffff0000u);
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
 template <typename T> struct Mma;
 
 template <> struct Mma<bf16_t> {
@@ -91,8 +98,8 @@ template <> struct Mma<float> {
 // LDS: double-buffered A[BM] and B[BN] rows of 80 B (64 data + 16 pad: the
 // pad makes the 16-lane ds_read_b128 groups hit 16 distinct 4-bank slots).
 // ---------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, int KS>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const T* __restrict__ x, const T* __restrict__ w,
+template <typename T, int BM, int BN, int WM, int WN, int KS, int KG>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KG) void igemm_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                     T* __restrict__ y, const T* __restrict__ addend,
                                                     float* __restrict__ stats, const sba_conv_geom g,
                                                     const int M, float* __restrict__ ws,
@@ -101,18 +108,25 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
     constexpr int KS_CH = 64 / (int)sizeof(T);   // channels per slab
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    constexpr int NT = (BM / WM) * (BN / WN) * 64;   // threads: one wave per WM x WN sub-tile
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;   // threads of one K-group: one wave per WM x WN sub-tile
+    constexpr int NTT = NT * KG;                     // KG groups walk disjoint K ranges of the same tile
     constexpr int RP = NT / 4;                       // tile rows staged per pass (4 threads x 16 B per row)
     constexpr int AI = (BM + RP - 1) / RP, BI = (BN + RP - 1) / RP;    // 16-byte loads per thread per slab
     static_assert(BM % WM == 0 && BN % WN == 0 && WM % 32 == 0 && WN % 32 == 0, "tile");
     constexpr int TILE_BYTES = (BM + BN) * ROWB;
+    constexpr int GROUP_BYTES = 2 * KS * TILE_BYTES;
+    static_assert(KG == 1 || (KG - 1) * BM * BN * 4 <= KG * GROUP_BYTES, "K-group partials fit in the staging buffers");
 
-    // KS slabs are staged per barrier (KS > 1 for the small tiles, whose MFMA work per slab is short)
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * KS * TILE_BYTES + BM * 4 + BN * 8];
-    int* rowoff = reinterpret_cast<int*>(lds + 2 * KS * TILE_BYTES);
-    float* s_stat = reinterpret_cast<float*>(lds + 2 * KS * TILE_BYTES + BM * 4);
+    // KS slabs are staged per barrier (KS > 1 for the small tiles, whose MFMA work per slab is short);
+    // each K-group has its own double buffer
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[KG * GROUP_BYTES + BM * 4 + BN * 8];
+    int* rowoff = reinterpret_cast<int*>(lds_all + KG * GROUP_BYTES);
+    float* s_stat = reinterpret_cast<float*>(lds_all + KG * GROUP_BYTES + BM * 4);
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int kg = KG > 1 ? (int)threadIdx.x / NT : 0;
+    const int tid = KG > 1 ? (int)threadIdx.x - kg * NT : (int)threadIdx.x;
+    unsigned char* const lds = lds_all + kg * GROUP_BYTES;
+    const int lane = tid & 63, wid = tid >> 6;
     const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
     const int m_base = blockIdx.x * BM, n_base = blockIdx.y * BN;
     const int IHL = g.ups ? 2 * g.IH : g.IH, IWL = g.ups ? 2 * g.IW : g.IW;
@@ -136,7 +150,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
             a_nb[i] = 0;
         }
     }
-    for (int r = tid; r < BM; r += NT) {
+    for (int r = threadIdx.x; r < BM; r += NTT) {
         const int m = m_base + r;
         int off = -1;
         if (m < M) {
@@ -146,7 +160,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
         }
         rowoff[r] = off;
     }
-    for (int c = tid; c < 2 * BN; c += NT) s_stat[c] = 0.f;
+    for (int c = threadIdx.x; c < 2 * BN; c += NTT) s_stat[c] = 0.f;
 
     const int cpt = g.Cin / KS_CH;            // slabs per tap
     const int nsteps = g.ntaps * cpt;
@@ -161,9 +175,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
     const int xcs = g.x_cstride ? g.x_cstride : g.Cin;       // input pixel stride (channels)
     const int ycs = g.y_cstride ? g.y_cstride : g.Cout;      // output pixel stride (channels)
 
-    // split-K: this block walks slabs [s_begin, s_end)
-    const int s_begin = blockIdx.z * slabs_per_split;
-    const int s_end = min(s_begin + slabs_per_split, nsteps);
+    // split-K: this block walks slabs [b_begin, b_end), its K-group kg the sub-range [s_begin, s_end)
+    const int b_begin = blockIdx.z * slabs_per_split;
+    const int b_end = min(b_begin + slabs_per_split, nsteps);
+    const int per_group = KG > 1 ? ((b_end - b_begin + KG * KS - 1) / (KG * KS)) * KS : b_end - b_begin;
+    const int s_begin = b_begin + kg * per_group;
+    const int s_end = min(s_begin + per_group, b_end);
 
     // Address generation is hoisted out of the per-slab path: slabs are consumed in order, so the
     // (tap, channel-slab) position is tracked incrementally (no division), the per-row gather
@@ -254,7 +271,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nstages = (s_end - s_begin + KS - 1) / KS;
+    const int nstages = (per_group + KS - 1) / KS;      // uniform over the groups (dead slabs load zeros)
     gload(0);
     lstore(0);
     __syncthreads();
@@ -270,7 +287,36 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
         __syncthreads();
     }
 
+    if (KG > 1) {
+        // sum the K-groups' partial tiles into group 0 through the (now free) staging buffers
+        float* red = reinterpret_cast<float*>(lds_all);
+        if (kg > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[(((kg - 1) * TM * TN + i * TN + j) * 16 + r) * NT + tid] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int q = 0; q < KG - 1; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[i][j][r] += red[((q * TM * TN + i * TN + j) * 16 + r) * NT + tid];
+        }
+        __syncthreads();
+    }
+    const bool lead = KG == 1 || kg == 0;       // the group that owns the summed tile
+
     if (ws) {
+        if (!lead) return;
         // split-K partial: f32 atomics into ws[m][co]; y / addend / stats are done by splitk_finish_kernel
         const int col_s = lane & 31, rsel_s = 4 * (lane >> 5);
 #pragma unroll
@@ -291,11 +337,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
     const int col_l = lane & 31, rsel = 4 * (lane >> 5);
     constexpr bool kStageOut = sizeof(T) == 2;       // bf16: transpose through LDS -> 16-byte row stores
     constexpr int OROW = BN * 2 + 16;                // staged output row: BN bf16 + 16 B pad
-    static_assert(!kStageOut || BM * OROW <= 2 * KS * TILE_BYTES, "output tile fits in the staging buffers");
+    static_assert(!kStageOut || BM * OROW <= KG * GROUP_BYTES, "output tile fits in the staging buffers");
+    if (lead) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int co = n_base + wn0 + j * 32 + col_l;
         float csum = 0.f, csq = 0.f;
+        const float bco = bias ? bias[co < g.Cout ? co : 0] : 0.f;      // one load per column, not per element
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -304,11 +352,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
                 float v = acc[i][j][r];
                 csum += v;
                 csq += v * v;
-                if (bias) v += bias[co < g.Cout ? co : 0];
+                if (bias) v += bco;
                 if (g.relu) v = fmaxf(v, 0.f);
                 if (kStageOut) {
                     // (the main loop's last barrier has passed: the staging buffers are free)
-                    *reinterpret_cast<T*>(lds + row * OROW + (wn0 + j * 32 + col_l) * 2) = from_f<T>(v);
+                    *reinterpret_cast<T*>(lds_all + row * OROW + (wn0 + j * 32 + col_l) * 2) = from_f<T>(v);
                 } else {
                     const int pix = rowoff[row];
                     if (pix >= 0 && co < g.Cout) {
@@ -328,37 +376,43 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
             }
         }
     }
+    }
     if (kStageOut || stats) __syncthreads();
     if (kStageOut) {
         constexpr int CPRO = BN / 8;                 // 16-byte chunks per output row
-        for (int idx = tid; idx < BM * CPRO; idx += NT) {
+        for (int idx = threadIdx.x; idx < BM * CPRO; idx += NTT) {
             const int row = idx / CPRO, cc = idx - row * CPRO;
             const int pix = rowoff[row];
             const int co = n_base + cc * 8;
             if (pix < 0 || co >= g.Cout) continue;
-            uint4 v = *reinterpret_cast<const uint4*>(lds + row * OROW + cc * 16);
+            uint4 v = *reinterpret_cast<const uint4*>(lds_all + row * OROW + cc * 16);
             const int64_t o = (int64_t)pix * ycs + g.y_coff + co;
             if (co + 8 <= g.Cout) {
                 if (addend) {
                     const uint4 a = *reinterpret_cast<const uint4*>(addend + o);
-                    const bf16_t* ap = reinterpret_cast<const bf16_t*>(&a);
-                    bf16_t* vp = reinterpret_cast<bf16_t*>(&v);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) vp[k] = f2bf(bf2f(vp[k]) + bf2f(ap[k]));
+                    v.x = add_bf16x2(v.x, a.x);
+                    v.y = add_bf16x2(v.y, a.y);
+                    v.z = add_bf16x2(v.z, a.z);
+                    v.w = add_bf16x2(v.w, a.w);
                 }
                 *reinterpret_cast<uint4*>(y + o) = v;
             } else {                                  // ragged Cout tail: scalar
-                const bf16_t* vp = reinterpret_cast<const bf16_t*>(&v);
-                for (int k = 0; k < 8 && co + k < g.Cout; ++k) {
-                    float f = bf2f(vp[k]);
-                    if (addend) f += to_f<T>(addend[o + k]);
-                    y[o + k] = from_f<T>(f);
+                // (fully unrolled with static indices: a dynamically indexed private array would be
+                // promoted to LDS and make every wave read the AQL dispatch packet for its flat id)
+                const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (co + k < g.Cout) {
+                        float f = bf2f((bf16_t)((k & 1) ? (vw[k >> 1] >> 16) : (vw[k >> 1] & 0xffffu)));
+                        if (addend) f += to_f<T>(addend[o + k]);
+                        y[o + k] = from_f<T>(f);
+                    }
                 }
             }
         }
     }
     if (stats) {
-        for (int c = tid; c < BN; c += NT) {
+        for (int c = threadIdx.x; c < BN; c += NTT) {
             const int co = n_base + c;
             if (co < g.Cout) {
                 atomicAdd(&stats[co], s_stat[c]);
@@ -939,21 +993,22 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ 
 struct IgemmCfg { int bm, bn, ks, occ; float eff; bool split; };
 // A: big square tile, B: wide-M tile for Cout = 64, C: mid tile, D: small tile (+split-K),
 // E: skinny GEMM tile for the 4x4 / 8x8 maps with thousands of channels (+split-K)
-static const IgemmCfg kCfg[5] = {
+// F: the small tile with 4 in-workgroup K-groups (16 waves): latency-bound layers with too few tiles
+static const IgemmCfg kCfg[6] = {
     {128, 128, 1, 3, 1.00f, false}, {256, 64, 1, 3, 1.00f, false}, {128, 64, 2, 2, 0.80f, false},
-    {64, 64, 2, 3, 0.50f, true},    {320, 128, 2, 1, 0.90f, true}};
+    {64, 64, 2, 3, 0.50f, true},    {320, 128, 2, 1, 0.90f, true},  {64, 64, 1, 1, 0.50f, true}};
 
-template <typename T, int BM, int BN, int WM, int WN, int KS>
+template <typename T, int BM, int BN, int WM, int WN, int KS, int KG = 1>
 static void launch_cfg(const T* xp, const T* wp, T* yp, const T* ap, float* stats, const sba_conv_geom& g, int M,
                        int nslabs, int split, float* ws, hipStream_t st, const float* bias) {
-    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    constexpr int NT = (BM / WM) * (BN / WN) * 64 * KG;
     int sps = nslabs;
     if (split > 1) {
         sps = cdiv(cdiv(nslabs, split), KS) * KS;
         split = cdiv(nslabs, sps);
     }
     dim3 grid(cdiv(M, BM), cdiv(g.Cout, BN), split);
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KS>), grid, dim3(NT), 0, st, xp, wp, yp, ap, stats, g, M,
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KS, KG>), grid, dim3(NT), 0, st, xp, wp, yp, ap, stats, g, M,
                        split > 1 ? ws : (float*)nullptr, sps, bias);
     if (split > 1) {
         dim3 fgrid(cdiv(g.Cout / 4, 256), cdiv(M, 8));
@@ -965,7 +1020,7 @@ static int forced_cfg() {
     static int v = -2;
     if (v == -2) {
         const char* e = getenv("SBA_IGEMM_CFG");       // tuning aid only: A..E
-        v = (e && e[0] >= 'A' && e[0] <= 'E') ? e[0] - 'A' : -1;
+        v = (e && e[0] >= 'A' && e[0] <= 'F') ? e[0] - 'A' : -1;
     }
     return v;
 }
@@ -1000,6 +1055,11 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
     }
     if (forced_cfg() >= 0) best = forced_cfg();
     {
+        static int d2f = -1;
+        if (d2f < 0) { const char* e = getenv("SBA_IGEMM_D2F"); d2f = (e && e[0] == '1') ? 1 : 0; }
+        if (d2f && best == 3) best = 5;
+    }
+    {
         const IgemmCfg& k = kCfg[best];
         const int tiles = cdiv(M, k.bm) * cdiv(g.Cout, k.bn);
         const int slots = 256 * k.occ;
@@ -1016,6 +1076,7 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
         case 1: launch_cfg<T, 256, 64, 64, 64, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
         case 2: launch_cfg<T, 128, 64, 32, 64, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
         case 3: launch_cfg<T, 64, 64, 32, 32, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
+        case 5: launch_cfg<T, 64, 64, 32, 32, 1, 4>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
         default: launch_cfg<T, 320, 128, 64, 64, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
     }
     return SBA_CHECK_LAUNCH();

@@ -52,6 +52,39 @@ def main():
     print('%-88s %7s %10s %9s %6s' % ('kernel', 'calls', 'ms/step', 'avg_us', '%'))
     for n, (c, d) in sorted(by_name.items(), key=lambda kv: -kv[1][1])[:40]:
         print('%-88s %7.1f %10.3f %9.1f %6.1f' % (n, c / keep, d / 1e3 / keep, d / c, 100 * d / busy))
+    # wall-time attribution: every instant of the window is split equally among the kernels
+    # running at that instant (idle gaps are reported separately) -- this is what a kernel costs
+    # the step when streams overlap
+    ev = []
+    for i, r in enumerate(win):
+        ev.append((int(r['Start_Timestamp']), 1, i))
+        ev.append((int(r['End_Timestamp']), 0, i))
+    ev.sort()
+    active = set()
+    share = collections.defaultdict(float)
+    idle = 0.0
+    conc_hist = collections.defaultdict(float)
+    prev = ev[0][0]
+    for t, kind, i in ev:
+        dt = t - prev
+        if dt > 0:
+            if active:
+                for j in active:
+                    share[short(win[j]['Kernel_Name'])] += dt / len(active)
+            else:
+                idle += dt
+            conc_hist[min(len(active), 8)] += dt
+        prev = t
+        if kind:
+            active.add(i)
+        else:
+            active.discard(i)
+    print('\n## wall-time attribution (ms/step; time split equally among concurrently running kernels)')
+    print('idle (no kernel running): %.3f ms/step' % (idle / 1e6 / keep))
+    print('concurrency histogram (ms/step): ' + ', '.join('%d%s: %.2f' % (k, '+' if k == 8 else '', v / 1e6 / keep)
+                                                            for k, v in sorted(conc_hist.items())))
+    for n, d in sorted(share.items(), key=lambda kv: -kv[1])[:30]:
+        print('%-88s %10.3f' % (n, d / 1e6 / keep))
     print('\n## per kernel + launch grid (blocks), top 40 (per step)')
     for (n, g), (c, d) in sorted(by_shape.items(), key=lambda kv: -kv[1][1])[:40]:
         print('%-70s %-18s %6.1f %9.3f %9.1f' % (n[:70], str(g), c / keep, d / 1e3 / keep, d / c))
