@@ -90,6 +90,23 @@ int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* dw, const sb
  * kh = (1-py) + 2j, kw = (1-px) + 2i. */
 int sba_pack_weight(int dtype, const float* w, void* out, int Cout, int KH, int KW, int Cin,
                     int mode, void* stream);
+/* All packed copies of ONE network's conv weights in one launch (after its optimizer step, cf.
+ * trainer.py:275,296): per tensor the forward operand (mode-0 cast, skipped when fwd is NULL)
+ * and the data-gradient operand (mode 1 or 2 as above, skipped when tr is NULL) are written from a
+ * single read of the f32 master.  `descs` is a DEVICE array; workgroup b serves the tensor d with
+ * tile_begin[d] <= b < tile_begin[d+1] (tiles: tap-major, then 64-row Cout tiles, then 64-column
+ * Cin tiles; co_tiles = ceil(Cout/64), ci_tiles = ceil(Cin/64)); total_tiles = sum over tensors
+ * of KH*KW*co_tiles*ci_tiles.  Cin must be a multiple of 4. */
+typedef struct sba_pack_desc {
+    const float* w;
+    void* fwd;
+    void* tr;
+    int32_t Cout, KH, KW, Cin;
+    int32_t mode;
+    int32_t tile_begin;
+    int32_t co_tiles, ci_tiles;
+} sba_pack_desc;
+int sba_pack_weights_multi(int dtype, const sba_pack_desc* descs, int ndesc, int total_tiles, void* stream);
 /* sum each 2x2 block: dx[n][y][x][c] = sum dup[n][2y+a][2x+b][c] (bwd of nearest x2). */
 int sba_pool2x2_sum(int dtype, const void* dup, void* dx, int N, int H, int W, int C, void* stream);
 

@@ -927,6 +927,82 @@ __global__ __launch_bounds__(256) void pack_weight_tr_kernel(const float* __rest
     }
 }
 
+// every packed copy of one network in one launch: a workgroup owns one 64(co) x 64(ci) tile of one
+// source tap of one tensor, reads it once (float4 rows), writes the forward copy (same order) and
+// the transposed data-gradient copy (64 co contiguous = full 128-byte lines) through LDS
+template <typename T>
+__global__ __launch_bounds__(256) void pack_multi_kernel(const sba_pack_desc* __restrict__ descs, int ndesc) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = ndesc - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {                                   // last desc with tile_begin <= b (uniform)
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].tile_begin <= b) lo = mid; else hi = mid - 1;
+    }
+    const sba_pack_desc d = descs[lo];
+    const int local = b - d.tile_begin;
+    const int per_tap = d.co_tiles * d.ci_tiles;
+    const int src_tap = local / per_tap;
+    const int rem = local - src_tap * per_tap;
+    const int co0 = (rem / d.ci_tiles) * 64, ci0 = (rem % d.ci_tiles) * 64;
+    const int taps = d.KH * d.KW;
+    if (src_tap >= taps) return;
+    const int tid = threadIdx.x;
+    const int c4 = (tid & 15) * 4;
+    T* fwd = reinterpret_cast<T*>(d.fwd);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (tid >> 4) + 16 * i;
+        const int co = co0 + r, ci = ci0 + c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (co < d.Cout && ci < d.Cin) {
+            const int64_t o = ((int64_t)co * taps + src_tap) * d.Cin + ci;
+            v = *reinterpret_cast<const float4*>(d.w + o);
+            if (fwd) {
+                fwd[o] = from_f<T>(v.x); fwd[o + 1] = from_f<T>(v.y);
+                fwd[o + 2] = from_f<T>(v.z); fwd[o + 3] = from_f<T>(v.w);
+            }
+        }
+        tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
+    }
+    if (!d.tr) return;
+    __syncthreads();
+    int dst_tap, dtaps;
+    int64_t dst_base = 0;
+    if (d.mode == 1) {
+        const int kh = src_tap / d.KW, kw = src_tap - kh * d.KW;
+        dst_tap = (d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw);
+        dtaps = taps;
+    } else {
+        const int kh = src_tap >> 2, kw = src_tap & 3;      // kh = (1-py) + 2j, kw = (1-px) + 2i
+        const int py = 1 - (kh & 1), px = 1 - (kw & 1);
+        dst_tap = (kh >> 1) * 2 + (kw >> 1);
+        dtaps = 4;
+        dst_base = (int64_t)(py * 2 + px) * d.Cin * 4 * d.Cout;
+    }
+    T* tr = reinterpret_cast<T*>(d.tr);
+    const int c8 = (tid & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (tid >> 3) + 32 * i;                  // ci within the tile
+        const int ci = ci0 + r, co = co0 + c8;
+        if (ci >= d.Cin || co >= d.Cout) continue;
+        T* op = tr + dst_base + ((int64_t)ci * dtaps + dst_tap) * d.Cout + co;
+        if (co + 8 <= d.Cout && sizeof(T) == 2) {
+            uint4 o;
+            o.x = (uint32_t)f2bf(tile[c8 + 0][r]) | ((uint32_t)f2bf(tile[c8 + 1][r]) << 16);
+            o.y = (uint32_t)f2bf(tile[c8 + 2][r]) | ((uint32_t)f2bf(tile[c8 + 3][r]) << 16);
+            o.z = (uint32_t)f2bf(tile[c8 + 4][r]) | ((uint32_t)f2bf(tile[c8 + 5][r]) << 16);
+            o.w = (uint32_t)f2bf(tile[c8 + 6][r]) | ((uint32_t)f2bf(tile[c8 + 7][r]) << 16);
+            *reinterpret_cast<uint4*>(op) = o;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (co + k < d.Cout) op[k] = from_f<T>(tile[c8 + k][r]);
+        }
+    }
+}
+
 template <typename T>
 __global__ void pool2x2_kernel(const T* __restrict__ up, T* __restrict__ dx, int N, int H, int W, int C) {
     constexpr int V = Vec16<T>::N;
@@ -1201,6 +1277,15 @@ extern "C" int sba_pack_weight(int dtype, const float* w, void* out, int Cout, i
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     SBA_DISPATCH(dtype, hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(blocks), dim3(256), 0,
                                            (hipStream_t)stream, w, (T*)out, Cout, KH, KW, Cin, mode));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_pack_weights_multi(int dtype, const sba_pack_desc* descs, int ndesc, int total_tiles,
+                                      void* stream) {
+    if (!descs || ndesc <= 0 || total_tiles <= 0) return SBA_E_ARG;
+    if (((uintptr_t)descs & 7) != 0) return SBA_E_ARG;
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((pack_multi_kernel<T>), dim3(total_tiles), dim3(256), 0,
+                                           (hipStream_t)stream, descs, ndesc));
     return SBA_CHECK_LAUNCH();
 }
 

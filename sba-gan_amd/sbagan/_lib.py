@@ -43,6 +43,7 @@ SIGNATURES = {
     'sba_conv_igemm_bias': [I, P, P, P, P, P, P, G, P, L, P],
     'sba_conv_wgrad': [I, P, P, P, G, I, P],
     'sba_pack_weight': [I, P, P, I, I, I, I, I, P],
+    'sba_pack_weights_multi': [I, P, I, I, P],
     'sba_pool2x2_sum': [I, P, P, I, I, I, I, P],
     'sba_bn_finalize': [P, P, P, P, P, P, P, P, P, P, I, L, F, F, P],
     'sba_bn_stats': [I, P, P, L, I, P],

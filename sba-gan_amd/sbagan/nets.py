@@ -55,9 +55,9 @@ class GLU(nn.Module):
 class _Layer(object):
     """(conv, bn, packed weight) triple handed to the autograd Functions."""
 
-    def __init__(self, conv, bn):
+    def __init__(self, conv, bn, kind='3x3'):
         self.conv, self.bn = conv, bn
-        self.pw = ops.PackedWeight(conv.weight)
+        self.pw = ops.PackedWeight(conv.weight, kind)
 
 
 class _ConvBNAct(nn.Sequential):
@@ -69,7 +69,7 @@ class _ConvBNAct(nn.Sequential):
     def _layer(self):
         l = self.__dict__.get('_l')
         if l is None:
-            l = _Layer(self[self.conv_idx], self[self.conv_idx + 1])
+            l = _Layer(self[self.conv_idx], self[self.conv_idx + 1], self.kind)
             self.__dict__['_l'] = l
         return l
 
@@ -133,6 +133,19 @@ class ResBlock(nn.Module):
         l1, l2 = self._layers()
         return ops.ResBlockFn.apply(x, l1.conv.weight, l1.bn.weight, l1.bn.bias,
                                     l2.conv.weight, l2.bn.weight, l2.bn.bias, self)
+
+
+def pack_group(net):
+    """One ops.PackGroup over every fused conv layer of `net` (its packed weights are then
+    refreshed by a single launch per optimizer step)."""
+    layers = []
+    for m in net.modules():
+        if isinstance(m, _ConvBNAct):
+            layers.append((m._layer().pw, m.kind))
+        elif isinstance(m, ResBlock):
+            l1, l2 = m._layers()
+            layers += [(l1.pw, '3x3'), (l2.pw, '3x3')]
+    return ops.PackGroup(layers) if layers else None
 
 
 def _linear(x, lin):

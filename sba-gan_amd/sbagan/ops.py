@@ -155,10 +155,13 @@ def _conv_out_hw(kind, H, W):
 class PackedWeight(object):
     """Packed copies of one OIHW conv parameter (stored channels_last, i.e.
     [O][KH][KW][I] f32 in memory): the forward operand in the compute dtype and
-    the data-gradient operand, rebuilt lazily when the parameter changes."""
+    the data-gradient operand, rebuilt lazily when the parameter changes.  Inside a PackGroup
+    (one per trained network) a stale copy triggers ONE launch that refreshes the whole network."""
 
-    def __init__(self, param):
+    def __init__(self, param, kind=None):
         self.param = param
+        self.kind = kind
+        self.group = None
         self._fwd = self._dgrad = None
         self._kf = self._kd = None
 
@@ -177,6 +180,9 @@ class PackedWeight(object):
             return self._master()
         k = self._key(dtype)
         if self._kf != k:
+            if self.group is not None:
+                self.group.refresh(dtype)
+                return self._fwd
             p = self._master()
             O, I, KH, KW = p.shape
             if self._fwd is None or self._fwd.dtype != dtype:
@@ -188,6 +194,9 @@ class PackedWeight(object):
     def dgrad(self, dtype, kind):
         k = self._key(dtype) + (kind,)
         if self._kd != k:
+            if self.group is not None and kind == self.kind:
+                self.group.refresh(dtype)
+                return self._dgrad
             p = self._master()
             O, I, KH, KW = p.shape
             if self._dgrad is None or self._dgrad.dtype != dtype:
@@ -197,6 +206,69 @@ class PackedWeight(object):
             call('sba_pack_weight', dcode, _p(p), _p(self._dgrad), O, KH, KW, I, mode, _stream())
             self._kd = k
         return self._dgrad
+
+
+class PackGroup(object):
+    """The packed weights of all conv layers of one network, kept in two flat buffers (forward
+    operands, data-gradient operands) and refreshed by ONE sba_pack_weights_multi launch when any
+    of them is stale (normally: once after the network's optimizer step) instead of two launches
+    per layer.  `layers` = [(PackedWeight, kind)] with kind in '3x3' | '3x3up' | '4x4s2'."""
+
+    _DESC = [('w', '<u8'), ('fwd', '<u8'), ('tr', '<u8'), ('Cout', '<i4'), ('KH', '<i4'), ('KW', '<i4'),
+             ('Cin', '<i4'), ('mode', '<i4'), ('tile_begin', '<i4'), ('co_tiles', '<i4'), ('ci_tiles', '<i4')]
+
+    def __init__(self, layers):
+        self.layers = [(pw, kind) for pw, kind in layers if pw.param.shape[1] % 4 == 0]
+        self.state = {}             # dtype -> dict(fwd, tr, descs, ptrs, tiles)
+        for pw, kind in self.layers:
+            pw.group, pw.kind = self, kind
+
+    def _build(self, dtype):
+        import numpy as np
+        dev = self.layers[0][0].param.device
+        sizes = [pw.param.numel() for pw, _ in self.layers]
+        offs, n = [], 0
+        for k in sizes:
+            offs.append(n)
+            n += (k + 7) // 8 * 8
+        st = {'fwd': torch.empty(n, dtype=dtype, device=dev) if dtype != torch.float32 else None,
+              'tr': torch.empty(n, dtype=dtype, device=dev)}
+        esz = st['tr'].element_size()
+        desc = np.zeros(len(self.layers), dtype=np.dtype(self._DESC, align=True))
+        assert desc.dtype.itemsize == 56
+        tiles = 0
+        for i, ((pw, kind), o) in enumerate(zip(self.layers, offs)):
+            O, I, KH, KW = pw.param.shape
+            d = desc[i]
+            d['w'] = pw.param.data_ptr()
+            d['fwd'] = st['fwd'].data_ptr() + o * esz if st['fwd'] is not None else 0
+            d['tr'] = st['tr'].data_ptr() + o * esz
+            d['Cout'], d['KH'], d['KW'], d['Cin'] = O, KH, KW, I
+            d['mode'] = 2 if kind == '4x4s2' else 1
+            d['tile_begin'] = tiles
+            d['co_tiles'], d['ci_tiles'] = (O + 63) // 64, (I + 63) // 64
+            tiles += KH * KW * d['co_tiles'] * d['ci_tiles']
+            if st['fwd'] is not None:
+                pw._fwd = st['fwd'][o:o + sizes[i]]
+            pw._dgrad = st['tr'][o:o + sizes[i]]
+        st['descs'] = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
+        st['ptrs'] = [pw.param.data_ptr() for pw, _ in self.layers]
+        st['tiles'] = tiles
+        self.state = {dtype: st}        # one compute dtype at a time (the views above belong to it)
+        return st
+
+    def refresh(self, dtype):
+        st = self.state.get(dtype)
+        if st is None or st['ptrs'] != [pw.param.data_ptr() for pw, _ in self.layers]:
+            st = self._build(dtype)
+        for pw, _ in self.layers:
+            if not pw.param.is_contiguous(memory_format=CL):
+                raise RuntimeError('conv parameters must be stored channels_last (use sbagan layers)')
+        dcode = _lib.SBA_BF16 if dtype == torch.bfloat16 else _lib.SBA_F32
+        call('sba_pack_weights_multi', dcode, st['descs'].data_ptr(), len(self.layers), st['tiles'], _stream())
+        for pw, kind in self.layers:
+            k = pw._key(dtype)
+            pw._kf, pw._kd = k, k + (kind,)
 
 
 class ZeroArena(object):

@@ -51,6 +51,8 @@ class FlatParams(object):
         self.epoch = [0]
         ops.register_epoch(params, self.epoch)
         ops.weights_changed()
+        from . import nets
+        self.packs = nets.pack_group(net)      # all packed conv weights of the network: one launch per step
 
     def zero_grad(self):
         self.grad.zero_()
