@@ -27,7 +27,7 @@ def main():
     hi = marks[(n - back + 1) * 4 - 1] + 2
     win = rows[lo:hi]
     t0 = int(win[0]['Start_Timestamp'])
-    qkey = 'Stream_Id' if 'Stream_Id' in win[0] and len(set(r['Stream_Id'] for r in win)) > 1 else 'Queue_Id'
+    qkey = sys.argv[3] if len(sys.argv) > 3 else ('Stream_Id' if 'Stream_Id' in win[0] and len(set(r['Stream_Id'] for r in win)) > 1 else 'Queue_Id')
     by_q = collections.defaultdict(list)
     for r in win:
         by_q[r[qkey]].append(r)
