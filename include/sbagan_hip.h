@@ -111,32 +111,31 @@ int sba_pack_weights_multi(int dtype, const sba_pack_desc* descs, int ndesc, int
 int sba_pool2x2_sum(int dtype, const void* dup, void* dx, int N, int H, int W, int C, void* stream);
 
 /* ---- BatchNorm(train) + activation (model.py:43-44,62-65,543-544,553-554) ---- */
-/* stats (sum, sumsq over `count` rows) -> scale/shift for the normalise pass, saved mean/rstd,
- * running stats update (momentum 0.1, unbiased var), num_batches_tracked += 1. */
-int sba_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
-                    float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
-                    float* mean, float* rstd, int C, int64_t count, float eps, float momentum,
-                    void* stream);
-/* stats[0..C) += sum(y), stats[C..2C) += sum(y^2) over `rows` NHWC rows (caller zeroes): used when one
- * conv launch covers several BatchNorm batches (real | fake), so the conv epilogue cannot split them. */
-int sba_bn_stats(int dtype, const void* y, float* stats, int64_t rows, int C, void* stream);
-/* out = act(y*scale+shift) (+ residual).  GLU halves the channel count.  out may have a larger
- * channel stride (out_cstride) and offset (out_coff) so that it can be written into a concat. */
-int sba_bn_act_fwd(int dtype, const void* y, const float* scale, const float* shift,
-                   const void* residual, void* out, int64_t rows, int C, int act,
-                   int out_cstride, int out_coff, void* stream);
-/* pass 1 of the backward: red[0..C) += sum dz, red[C..2C) += sum dz*xhat, where dz is the
+/* All BatchNorm entry points take `groups` >= 1 independent BatchNorm batches laid back to back
+ * (`rows` NHWC rows each; the discriminator's real | fake passes of losses.py:139-140 share one conv
+ * launch); per-group arrays are stats[groups][2C], aux[groups][4C] (= scale, shift, mean, rstd),
+ * red[groups][2C].  C a power of two <= 4096. */
+/* stats[g][0..C) += sum(y), stats[g][C..2C) += sum(y^2) (caller zeroes): only needed when the conv
+ * epilogue could not produce them (groups > 1). */
+int sba_bn_stats(int dtype, const void* y, float* stats, int64_t rows, int groups, int C, void* stream);
+/* finalize + normalise + activation in one launch: scale/shift/mean/rstd from stats (training) or
+ * from the running statistics (training == 0) -> aux; running stats update per group in order
+ * (momentum, unbiased var), num_batches_tracked += groups; out = act(y*scale+shift) (+ residual).
+ * GLU halves the channel count.  out may have a larger channel stride (out_cstride) and offset
+ * (out_coff) so that it can be written into a concat. */
+int sba_bn_act_fwd(int dtype, const void* y, const float* stats, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float* aux,
+                   const void* residual, void* out, int64_t rows, int groups, int C, int act,
+                   int out_cstride, int out_coff, float eps, float momentum, int training, void* stream);
+/* pass 1 of the backward: red[g][0..C) += sum dz, red[g][C..2C) += sum dz*xhat, where dz is the
  * gradient w.r.t. the BN output (activation backward applied to dout on the fly). */
-int sba_bn_act_bwd_reduce(int dtype, const void* y, const void* dout, const float* scale,
-                          const float* shift, const float* mean, const float* rstd, float* red,
-                          int64_t rows, int C, int act, int dout_cstride, int dout_coff,
+int sba_bn_act_bwd_reduce(int dtype, const void* y, const void* dout, const float* aux, float* red,
+                          int64_t rows, int groups, int C, int act, int dout_cstride, int dout_coff,
                           void* stream);
-/* pass 2: dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); also dgamma += red[C+c], dbeta += red[c]. */
-int sba_bn_act_bwd_apply(int dtype, const void* y, const void* dout, const float* scale,
-                         const float* shift, const float* mean, const float* rstd,
-                         const float* gamma, const float* red, void* dy, float* dgamma,
-                         float* dbeta, int64_t rows, int C, int act, int dout_cstride,
-                         int dout_coff, void* stream);
+/* pass 2: dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); also dgamma += red[g][C+c], dbeta += red[g][c]. */
+int sba_bn_act_bwd_apply(int dtype, const void* y, const void* dout, const float* aux, const float* red,
+                         void* dy, float* dgamma, float* dbeta, int64_t rows, int groups, int C, int act,
+                         int dout_cstride, int dout_coff, void* stream);
 /* Linear(no bias)+BatchNorm1d(train)+GLU on [B][F] f32, output permuted to NHWC [B][4*4][F/2/16]
  * (INIT_STAGE_G.fc + view, model.py:353-356,372-373). */
 int sba_bn1d_glu_fwd(int dtype, const float* y, const float* gamma, const float* beta,

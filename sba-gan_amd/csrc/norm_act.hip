@@ -10,36 +10,26 @@ namespace {
 
 constexpr float LRELU_SLOPE = 0.2f;
 
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ rmean,
-                                   float* __restrict__ rvar, int64_t* __restrict__ nbt,
-                                   float* __restrict__ scale, float* __restrict__ shift,
-                                   float* __restrict__ mean_o, float* __restrict__ rstd_o, int C,
-                                   float count, float eps, float momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) *nbt += 1;
-    if (c >= C) return;
-    const float mean = stats[c] / count;
-    float var = stats[C + c] / count - mean * mean;
-    var = fmaxf(var, 0.f);
-    const float rstd = rsqrtf(var + eps);
-    const float sc = gamma[c] * rstd;
-    scale[c] = sc;
-    shift[c] = beta[c] - mean * sc;
-    mean_o[c] = mean;
-    rstd_o[c] = rstd;
-    if (rmean) {
-        const float unb = count > 1.f ? var * count / (count - 1.f) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
-    }
+// per-channel (scale, shift, mean, rstd) of one BatchNorm batch from its (sum, sumsq)
+struct BnCoef { float scale, shift, mean, rstd, var; };
+__device__ __forceinline__ BnCoef bn_coef(const float* __restrict__ stats, const float* __restrict__ gamma,
+                                          const float* __restrict__ beta, int C, int c, float count, float eps) {
+    BnCoef k;
+    k.mean = stats[c] / count;
+    k.var = fmaxf(stats[C + c] / count - k.mean * k.mean, 0.f);
+    k.rstd = rsqrtf(k.var + eps);
+    k.scale = gamma[c] * k.rstd;
+    k.shift = beta[c] - k.mean * k.scale;
+    return k;
 }
 
 // ---- batch statistics of an NHWC tensor (used when the conv epilogue cannot provide them:
-//      grouped passes, where one conv launch covers several BatchNorm batches) ----
+//      grouped passes, where one conv launch covers several BatchNorm batches); blockIdx.y = group ----
 template <typename T>
-__global__ void bn_stats_kernel(const T* __restrict__ y, float* __restrict__ stats, int64_t rows, int C) {
+__global__ void bn_stats_kernel(const T* __restrict__ y_all, float* __restrict__ stats_all, int64_t rows, int C) {
     constexpr int V = Vec16<T>::N;
+    const T* y = y_all + (int64_t)blockIdx.y * rows * C;
+    float* stats = stats_all + (int64_t)blockIdx.y * 2 * C;
     const int cv = C / V;
     extern __shared__ float s_acc[];                        // [2*C]
     for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.f;
@@ -67,13 +57,58 @@ __global__ void bn_stats_kernel(const T* __restrict__ y, float* __restrict__ sta
     for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&stats[i], s_acc[i]);
 }
 
-// ---- forward: out = act(y*scale+shift) (+residual) ----
+// ---- forward: finalize + out = act(y*scale+shift) (+residual) in one launch; blockIdx.y = group.
+// Every workgroup derives scale/shift of its group's C channels from the (sum, sumsq) statistics into
+// LDS (C rsqrt: noise next to the streaming pass); workgroup (0, g) also stores aux[g] = scale,
+// shift, mean, rstd for the backward, and workgroup (0, 0) applies the running-statistics updates
+// of all groups in order (momentum, unbiased variance), as consecutive module calls would.
 template <typename T, int ACT>
-__global__ void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
-                                  const float* __restrict__ shift, const T* __restrict__ residual,
-                                  T* __restrict__ out, int64_t rows, int C, int out_cstride, int out_coff) {
+__global__ void bn_act_fwd_kernel(const T* __restrict__ y_all, const float* __restrict__ stats_all,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                  float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ nbt,
+                                  float* __restrict__ aux_all, const T* __restrict__ residual_all,
+                                  T* __restrict__ out_all, int64_t rows, int C, int out_cstride, int out_coff,
+                                  float eps, float momentum, int training) {
     constexpr int V = Vec16<T>::N;
+    extern __shared__ float s_co[];                         // scale[C], shift[C]
+    const int g = blockIdx.y;
     const int Co = ACT == SBA_ACT_GLU ? C / 2 : C;
+    const float count = (float)rows;
+    float* aux = aux_all + (int64_t)g * 4 * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        BnCoef k;
+        if (training) {
+            k = bn_coef(stats_all + (int64_t)g * 2 * C, gamma, beta, C, c, count, eps);
+        } else {                                            // inference: running statistics
+            k.mean = rmean[c];
+            k.rstd = rsqrtf(rvar[c] + eps);
+            k.scale = gamma[c] * k.rstd;
+            k.shift = beta[c] - k.mean * k.scale;
+        }
+        s_co[c] = k.scale;
+        s_co[C + c] = k.shift;
+        if (blockIdx.x == 0) {
+            aux[c] = k.scale; aux[C + c] = k.shift; aux[2 * C + c] = k.mean; aux[3 * C + c] = k.rstd;
+        }
+        if (blockIdx.x == 0 && g == 0 && training && rmean) {
+            float rm = rmean[c], rv = rvar[c];
+            for (int gg = 0; gg < (int)gridDim.y; ++gg) {
+                const BnCoef q = bn_coef(stats_all + (int64_t)gg * 2 * C, gamma, beta, C, c, count, eps);
+                const float unb = count > 1.f ? q.var * count / (count - 1.f) : q.var;
+                rm = (1.f - momentum) * rm + momentum * q.mean;
+                rv = (1.f - momentum) * rv + momentum * unb;
+            }
+            rmean[c] = rm;
+            rvar[c] = rv;
+        }
+    }
+    if (blockIdx.x == 0 && g == 0 && threadIdx.x == 0 && training && nbt) *nbt += gridDim.y;
+    __syncthreads();
+    const float* scale = s_co;
+    const float* shift = s_co + C;
+    const T* y = y_all + (int64_t)g * rows * C;
+    const T* residual = residual_all ? residual_all + (int64_t)g * rows * Co : nullptr;
+    T* out = out_all + (int64_t)g * rows * out_cstride;
     const int cv = Co / V;
     const int64_t total = rows * cv;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -104,14 +139,21 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restri
     }
 }
 
-// ---- backward pass 1: per-channel sum(dz), sum(dz*xhat) ----
+// ---- backward pass 1: per-channel sum(dz), sum(dz*xhat); blockIdx.y = group ----
 // thread mapping: each thread keeps a fixed set of channel vectors and strides over rows
 template <typename T, int ACT>
-__global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ dout,
-                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                     const float* __restrict__ mean, const float* __restrict__ rstd,
-                                     float* __restrict__ red, int64_t rows, int C, int dcs, int dco) {
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ y_all, const T* __restrict__ dout_all,
+                                     const float* __restrict__ aux_all, float* __restrict__ red_all,
+                                     int64_t rows, int C, int dcs, int dco) {
     constexpr int V = Vec16<T>::N;
+    const int g = blockIdx.y;
+    const T* y = y_all + (int64_t)g * rows * C;
+    const T* dout = dout_all + (int64_t)g * rows * dcs;
+    const float* scale = aux_all + (int64_t)g * 4 * C;
+    const float* shift = scale + C;
+    const float* mean = scale + 2 * C;
+    const float* rstd = scale + 3 * C;
+    float* red = red_all + (int64_t)g * 2 * C;
     const int Co = ACT == SBA_ACT_GLU ? C / 2 : C;
     const int cv = Co / V;                                  // power of two
     extern __shared__ float s_acc[];                        // [2*C]
@@ -123,8 +165,16 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restric
     for (int cvi = tc; cvi < cv; cvi += tpr) {
         const int c = cvi * V;
         float s0[V], s1[V], g0[V], g1[V];
+        float sc[V], sh[V], mn[V], rs[V], scg[V], shg[V], mng[V], rsg[V];
 #pragma unroll
-        for (int k = 0; k < V; ++k) { s0[k] = s1[k] = g0[k] = g1[k] = 0.f; }
+        for (int k = 0; k < V; ++k) {
+            s0[k] = s1[k] = g0[k] = g1[k] = 0.f;
+            sc[k] = scale[c + k]; sh[k] = shift[c + k]; mn[k] = mean[c + k]; rs[k] = rstd[c + k];
+            if (ACT == SBA_ACT_GLU) {
+                scg[k] = scale[Co + c + k]; shg[k] = shift[Co + c + k];
+                mng[k] = mean[Co + c + k]; rsg[k] = rstd[Co + c + k];
+            }
+        }
         for (int64_t row = (int64_t)blockIdx.x * rpi + tr; row < rows; row += (int64_t)gridDim.x * rpi) {
             Vec16<T> a = ld16(y + row * C + c);
             Vec16<T> d = ld16(dout + row * dcs + dco + c);
@@ -132,25 +182,25 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restric
                 Vec16<T> gt = ld16(y + row * C + Co + c);
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
-                    const float n = a.get(k) * scale[c + k] + shift[c + k];
-                    const float gp = gt.get(k) * scale[Co + c + k] + shift[Co + c + k];
+                    const float n = a.get(k) * sc[k] + sh[k];
+                    const float gp = gt.get(k) * scg[k] + shg[k];
                     const float s = sigmoidf_(gp), dd = d.get(k);
                     const float dza = dd * s, dzg = dd * n * s * (1.f - s);
                     s0[k] += dza;
-                    s1[k] += dza * (a.get(k) - mean[c + k]) * rstd[c + k];
+                    s1[k] += dza * (a.get(k) - mn[k]) * rs[k];
                     g0[k] += dzg;
-                    g1[k] += dzg * (gt.get(k) - mean[Co + c + k]) * rstd[Co + c + k];
+                    g1[k] += dzg * (gt.get(k) - mng[k]) * rsg[k];
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
                     float dz = d.get(k);
                     if (ACT == SBA_ACT_LRELU) {
-                        const float n = a.get(k) * scale[c + k] + shift[c + k];
+                        const float n = a.get(k) * sc[k] + sh[k];
                         dz = n > 0.f ? dz : LRELU_SLOPE * dz;
                     }
                     s0[k] += dz;
-                    s1[k] += dz * (a.get(k) - mean[c + k]) * rstd[c + k];
+                    s1[k] += dz * (a.get(k) - mn[k]) * rs[k];
                 }
             }
         }
@@ -168,24 +218,40 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y, const T* __restric
     for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&red[i], s_acc[i]);
 }
 
-// ---- backward pass 2: dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)) ----
+// ---- backward pass 2: dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); blockIdx.y = group ----
+// per-channel coefficients live in LDS: A = scale, B = shift, M = mean, R = rstd, P = red0/rows, Q = red1/rows
 template <typename T, int ACT>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ y, const T* __restrict__ dout,
-                                    const float* __restrict__ scale, const float* __restrict__ shift,
-                                    const float* __restrict__ mean, const float* __restrict__ rstd,
-                                    const float* __restrict__ red, T* __restrict__ dy,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows,
-                                    int C, int dcs, int dco) {
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ y_all, const T* __restrict__ dout_all,
+                                    const float* __restrict__ aux_all, const float* __restrict__ red_all,
+                                    T* __restrict__ dy_all, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                    int64_t rows, int C, int dcs, int dco) {
     constexpr int V = Vec16<T>::N;
-    const int Co = ACT == SBA_ACT_GLU ? C / 2 : C;
-    const int cv = Co / V;
+    extern __shared__ float s_k[];                          // [6][C]
+    const int g = blockIdx.y;
+    const float* aux = aux_all + (int64_t)g * 4 * C;
+    const float* red = red_all + (int64_t)g * 2 * C;
     const float inv = 1.f / (float)rows;
-    if (blockIdx.x == 0 && dgamma) {
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            dgamma[c] += red[C + c];
-            dbeta[c] += red[c];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        s_k[c] = aux[c]; s_k[C + c] = aux[C + c]; s_k[2 * C + c] = aux[2 * C + c]; s_k[3 * C + c] = aux[3 * C + c];
+        s_k[4 * C + c] = red[c] * inv;
+        s_k[5 * C + c] = red[C + c] * inv;
+        if (blockIdx.x == 0 && dgamma) {                    // groups accumulate into the same parameter
+            atomicAdd(&dgamma[c], red[C + c]);
+            atomicAdd(&dbeta[c], red[c]);
         }
     }
+    __syncthreads();
+    const float* scale = s_k;
+    const float* shift = s_k + C;
+    const float* mean = s_k + 2 * C;
+    const float* rstd = s_k + 3 * C;
+    const float* P = s_k + 4 * C;
+    const float* Q = s_k + 5 * C;
+    const T* y = y_all + (int64_t)g * rows * C;
+    const T* dout = dout_all + (int64_t)g * rows * dcs;
+    T* dy = dy_all + (int64_t)g * rows * C;
+    const int Co = ACT == SBA_ACT_GLU ? C / 2 : C;
+    const int cv = Co / V;
     const int64_t total = rows * cv;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -205,8 +271,8 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ y, const T* __restrict
                 const float dza = dd * s, dzg = dd * n * s * (1.f - s);
                 const float xa = (a.get(k) - mean[ca]) * rstd[ca];
                 const float xg = (gt.get(k) - mean[cg]) * rstd[cg];
-                o.set(k, scale[ca] * (dza - red[ca] * inv - xa * red[C + ca] * inv));
-                og.set(k, scale[cg] * (dzg - red[cg] * inv - xg * red[C + cg] * inv));
+                o.set(k, scale[ca] * (dza - P[ca] - xa * Q[ca]));
+                og.set(k, scale[cg] * (dzg - P[cg] - xg * Q[cg]));
             }
             st16(dy + row * C + Co + c, og);
         } else {
@@ -219,7 +285,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ y, const T* __restrict
                     dz = n > 0.f ? dz : LRELU_SLOPE * dz;
                 }
                 const float xa = (a.get(k) - mean[ca]) * rstd[ca];
-                o.set(k, scale[ca] * (dz - red[ca] * inv - xa * red[C + ca] * inv));
+                o.set(k, scale[ca] * (dz - P[ca] - xa * Q[ca]));
             }
         }
         st16(dy + row * C + c, o);
@@ -454,26 +520,19 @@ inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 }  // namespace
 
-extern "C" int sba_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
-                               float* running_var, int64_t* nbt, float* scale, float* shift, float* mean,
-                               float* rstd, int C, int64_t count, float eps, float momentum, void* stream) {
-    if (!stats || !gamma || !beta || !scale || !shift || !mean || !rstd || C <= 0 || count <= 0) return SBA_E_ARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, gamma,
-                       beta, running_mean, running_var, nbt, scale, shift, mean, rstd, C, (float)count, eps,
-                       momentum);
-    return SBA_CHECK_LAUNCH();
-}
-
-extern "C" int sba_bn_stats(int dtype, const void* y, float* stats, int64_t rows, int C, void* stream) {
+extern "C" int sba_bn_stats(int dtype, const void* y, float* stats, int64_t rows, int groups, int C,
+                            void* stream) {
     const int V = dtype == SBA_BF16 ? 8 : 4;
-    if (!y || !stats || rows <= 0 || C <= 0 || C % V || !pow2(C / V) || C > 4096) return SBA_E_ARG;
+    if (!y || !stats || rows <= 0 || groups <= 0 || groups > 65535 || C <= 0 || C % V || !pow2(C / V) || C > 4096)
+        return SBA_E_ARG;
     const int cv = C / V;
     const int rpi = cv < 256 ? 256 / cv : 1;
     int blocks = cdiv(rows, (int64_t)rpi * 8);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(blocks), dim3(256), 2 * (size_t)C * sizeof(float),
-                                           (hipStream_t)stream, (const T*)y, stats, rows, C));
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(blocks, groups), dim3(256),
+                                           2 * (size_t)C * sizeof(float), (hipStream_t)stream, (const T*)y, stats,
+                                           rows, C));
     return SBA_CHECK_LAUNCH();
 }
 
@@ -485,33 +544,38 @@ extern "C" int sba_bn_stats(int dtype, const void* y, float* stats, int64_t rows
         default: return SBA_E_ARG;                                              \
     }
 
-static bool bn_shape_ok(int dtype, int64_t rows, int C, int act) {
+static bool bn_shape_ok(int dtype, int64_t rows, int groups, int C, int act) {
     const int V = dtype == SBA_BF16 ? 8 : 4;
     const int Co = act == SBA_ACT_GLU ? C / 2 : C;
-    return rows > 0 && C > 0 && pow2(C) && Co % V == 0 && C <= 4096;
+    return rows > 0 && groups > 0 && groups <= 65535 && C > 0 && pow2(C) && Co % V == 0 && C <= 4096;
 }
 
-extern "C" int sba_bn_act_fwd(int dtype, const void* y, const float* scale, const float* shift,
-                              const void* residual, void* out, int64_t rows, int C, int act,
-                              int out_cstride, int out_coff, void* stream) {
-    if (!y || !scale || !shift || !out || !bn_shape_ok(dtype, rows, C, act)) return SBA_E_ARG;
+extern "C" int sba_bn_act_fwd(int dtype, const void* y, const float* stats, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var,
+                              int64_t* num_batches_tracked, float* aux, const void* residual, void* out,
+                              int64_t rows, int groups, int C, int act, int out_cstride, int out_coff, float eps,
+                              float momentum, int training, void* stream) {
+    if (!y || !gamma || !beta || !aux || !out || !bn_shape_ok(dtype, rows, groups, C, act)) return SBA_E_ARG;
+    if (training ? !stats : (!running_mean || !running_var)) return SBA_E_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return SBA_E_ARG;
     if (act == SBA_ACT_GLU && residual) return SBA_E_ARG;
     const int Co = act == SBA_ACT_GLU ? C / 2 : C;
     const int V = dtype == SBA_BF16 ? 8 : 4;
     if (out_cstride < Co + out_coff || out_cstride % V || out_coff % V) return SBA_E_ARG;
     const int blocks = grid_for(rows * (Co / V));
-    SBA_DISPATCH(dtype, ACT_SWITCH(act, hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT>), dim3(blocks), dim3(256),
-                                                           0, (hipStream_t)stream, (const T*)y, scale, shift,
-                                                           (const T*)residual, (T*)out, rows, C, out_cstride,
-                                                           out_coff)));
+    const size_t sh = 2 * (size_t)C * sizeof(float);
+    SBA_DISPATCH(dtype, ACT_SWITCH(act, hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT>), dim3(blocks, groups),
+                                                           dim3(256), sh, (hipStream_t)stream, (const T*)y, stats,
+                                                           gamma, beta, running_mean, running_var,
+                                                           num_batches_tracked, aux, (const T*)residual, (T*)out,
+                                                           rows, C, out_cstride, out_coff, eps, momentum,
+                                                           training)));
     return SBA_CHECK_LAUNCH();
 }
 
-extern "C" int sba_bn_act_bwd_reduce(int dtype, const void* y, const void* dout, const float* scale,
-                                     const float* shift, const float* mean, const float* rstd, float* red,
-                                     int64_t rows, int C, int act, int dcs, int dco, void* stream) {
-    if (!y || !dout || !scale || !shift || !mean || !rstd || !red || !bn_shape_ok(dtype, rows, C, act))
-        return SBA_E_ARG;
+extern "C" int sba_bn_act_bwd_reduce(int dtype, const void* y, const void* dout, const float* aux, float* red,
+                                     int64_t rows, int groups, int C, int act, int dcs, int dco, void* stream) {
+    if (!y || !dout || !aux || !red || !bn_shape_ok(dtype, rows, groups, C, act)) return SBA_E_ARG;
     const int Co = act == SBA_ACT_GLU ? C / 2 : C;
     const int V = dtype == SBA_BF16 ? 8 : 4;
     if (dcs < Co + dco || dcs % V || dco % V) return SBA_E_ARG;
@@ -521,29 +585,26 @@ extern "C" int sba_bn_act_bwd_reduce(int dtype, const void* y, const void* dout,
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     const size_t sh = 2 * (size_t)C * sizeof(float);
-    SBA_DISPATCH(dtype, ACT_SWITCH(act, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, ACT>), dim3(blocks),
+    SBA_DISPATCH(dtype, ACT_SWITCH(act, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, ACT>), dim3(blocks, groups),
                                                            dim3(256), sh, (hipStream_t)stream, (const T*)y,
-                                                           (const T*)dout, scale, shift, mean, rstd, red, rows, C,
-                                                           dcs, dco)));
+                                                           (const T*)dout, aux, red, rows, C, dcs, dco)));
     return SBA_CHECK_LAUNCH();
 }
 
-extern "C" int sba_bn_act_bwd_apply(int dtype, const void* y, const void* dout, const float* scale,
-                                    const float* shift, const float* mean, const float* rstd, const float* gamma,
-                                    const float* red, void* dy, float* dgamma, float* dbeta, int64_t rows, int C,
-                                    int act, int dcs, int dco, void* stream) {
-    (void)gamma;
-    if (!y || !dout || !scale || !shift || !mean || !rstd || !red || !dy || !bn_shape_ok(dtype, rows, C, act))
-        return SBA_E_ARG;
+extern "C" int sba_bn_act_bwd_apply(int dtype, const void* y, const void* dout, const float* aux,
+                                    const float* red, void* dy, float* dgamma, float* dbeta, int64_t rows,
+                                    int groups, int C, int act, int dcs, int dco, void* stream) {
+    if (!y || !dout || !aux || !red || !dy || !bn_shape_ok(dtype, rows, groups, C, act)) return SBA_E_ARG;
     if ((dgamma == nullptr) != (dbeta == nullptr)) return SBA_E_ARG;
     const int Co = act == SBA_ACT_GLU ? C / 2 : C;
     const int V = dtype == SBA_BF16 ? 8 : 4;
     if (dcs < Co + dco || dcs % V || dco % V) return SBA_E_ARG;
     const int blocks = grid_for(rows * (Co / V));
-    SBA_DISPATCH(dtype, ACT_SWITCH(act, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, ACT>), dim3(blocks), dim3(256),
-                                                           0, (hipStream_t)stream, (const T*)y, (const T*)dout,
-                                                           scale, shift, mean, rstd, red, (T*)dy, dgamma, dbeta,
-                                                           rows, C, dcs, dco)));
+    const size_t sh = 6 * (size_t)C * sizeof(float);
+    SBA_DISPATCH(dtype, ACT_SWITCH(act, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, ACT>), dim3(blocks, groups),
+                                                           dim3(256), sh, (hipStream_t)stream, (const T*)y,
+                                                           (const T*)dout, aux, red, (T*)dy, dgamma, dbeta, rows, C,
+                                                           dcs, dco)));
     return SBA_CHECK_LAUNCH();
 }
 

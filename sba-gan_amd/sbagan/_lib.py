@@ -45,11 +45,10 @@ SIGNATURES = {
     'sba_pack_weight': [I, P, P, I, I, I, I, I, P],
     'sba_pack_weights_multi': [I, P, I, I, P],
     'sba_pool2x2_sum': [I, P, P, I, I, I, I, P],
-    'sba_bn_finalize': [P, P, P, P, P, P, P, P, P, P, I, L, F, F, P],
-    'sba_bn_stats': [I, P, P, L, I, P],
-    'sba_bn_act_fwd': [I, P, P, P, P, P, L, I, I, I, I, P],
-    'sba_bn_act_bwd_reduce': [I, P, P, P, P, P, P, P, L, I, I, I, I, P],
-    'sba_bn_act_bwd_apply': [I, P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P],
+    'sba_bn_stats': [I, P, P, L, I, I, P],
+    'sba_bn_act_fwd': [I, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, F, F, I, P],
+    'sba_bn_act_bwd_reduce': [I, P, P, P, P, L, I, I, I, I, I, P],
+    'sba_bn_act_bwd_apply': [I, P, P, P, P, P, P, P, L, I, I, I, I, I, P],
     'sba_bn1d_glu_fwd': [I, P, P, P, P, P, P, P, P, P, I, I, F, F, P],
     'sba_bn1d_glu_bwd': [I, P, P, P, P, P, P, P, P, P, I, I, P],
     'sba_linear_fwd': [P, P, P, P, I, I, I, P],

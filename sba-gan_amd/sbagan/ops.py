@@ -448,63 +448,45 @@ def wgrad_tail_stream():
 
 
 class BNState(object):
-    """per-forward BatchNorm quantities: rows of aux = scale, shift, mean, rstd."""
-    __slots__ = ('aux', 'C', 'rows')
+    """per-forward BatchNorm quantities: aux[g] = (scale, shift, mean, rstd) of group g."""
+    __slots__ = ('aux', 'C', 'rows', 'groups')
 
 
-def bn_prepare(stats, bn, rows, training):
-    C = bn.weight.numel()
+def bn_act_forward(y, stats, bn, act, residual=None, groups=1):
+    """BatchNorm (train: batch statistics `stats` = per-group (sum, sumsq); eval: running stats) +
+    activation (+ residual) in ONE launch for all `groups` BatchNorm batches of y; returns (out, state)."""
+    N, C, H, W = y.shape
+    Co = C // 2 if act == ACT_GLU else C
     st = BNState()
-    st.C, st.rows = C, rows
-    st.aux = torch.empty((4, C), dtype=torch.float32, device=bn.weight.device)
-    a = st.aux
-    if training:
-        call('sba_bn_finalize', _p(stats), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
-             _p(bn.num_batches_tracked), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), C, rows, BN_EPS, BN_MOMENTUM,
-             _stream())
-    else:   # inference: running statistics (host-side tensor math on [C] vectors, off the training path)
-        with torch.no_grad():
-            rstd = torch.rsqrt(bn.running_var + BN_EPS)
-            a[0] = bn.weight * rstd
-            a[1] = bn.bias - bn.running_mean * a[0]
-            a[2] = bn.running_mean
-            a[3] = rstd
-    return st
+    st.C, st.rows, st.groups = C, (N // groups) * H * W, groups
+    st.aux = torch.empty((groups, 4, C), dtype=torch.float32, device=y.device)
+    out = empty_act(N, Co, H, W, y)
+    call('sba_bn_act_fwd', _dt(y), _p(y), _p(stats), _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
+         _p(bn.running_var), _p(bn.num_batches_tracked), _p(st.aux), _p(residual), _p(out), st.rows, groups, C,
+         act, Co, 0, BN_EPS, BN_MOMENTUM, 1 if bn.training else 0, _stream())
+    return out, st
 
 
-def bn_act_forward(y, st, act, residual=None, out=None):
+def bn_act_backward(y, dout, st, bn, act, need_param_grad=True):
     N, C, H, W = y.shape
     Co = C // 2 if act == ACT_GLU else C
-    if out is None:
-        out = empty_act(N, Co, H, W, y)
-    call('sba_bn_act_fwd', _dt(y), _p(y), _p(st.aux[0]), _p(st.aux[1]), _p(residual), _p(out), N * H * W, C,
-         act, Co, 0, _stream())
-    return out
-
-
-def bn_act_backward(y, dout, st, bn, act, need_param_grad=True, dy=None):
-    N, C, H, W = y.shape
-    Co = C // 2 if act == ACT_GLU else C
-    rows = N * H * W
-    a = st.aux
-    red = zeros_f32(2 * C, y.device)
-    call('sba_bn_act_bwd_reduce', _dt(y), _p(y), _p(dout), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(red),
-         rows, C, act, Co, 0, _stream())
-    if dy is None:
-        dy = torch.empty_like(y)
+    red = zeros_f32((st.groups, 2 * C), y.device)
+    call('sba_bn_act_bwd_reduce', _dt(y), _p(y), _p(dout), _p(st.aux), _p(red), st.rows, st.groups, C, act, Co, 0,
+         _stream())
+    dy = torch.empty_like(y)
     dg = db = None
     if need_param_grad:
         dg, db = param_grad(bn.weight), param_grad(bn.bias)
-    call('sba_bn_act_bwd_apply', _dt(y), _p(y), _p(dout), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]),
-         _p(bn.weight), _p(red), _p(dy), _p(dg), _p(db), rows, C, act, Co, 0, _stream())
+    call('sba_bn_act_bwd_apply', _dt(y), _p(y), _p(dout), _p(st.aux), _p(red), _p(dy), _p(dg), _p(db), st.rows,
+         st.groups, C, act, Co, 0, _stream())
     return dy
 
 
-def bn_stats(y):
-    """per-channel (sum, sumsq) of an NHWC tensor by a separate pass (grouped batches)."""
+def bn_stats(y, groups=1):
+    """per-group, per-channel (sum, sumsq) of an NHWC tensor by a separate pass (grouped batches)."""
     N, C, H, W = y.shape
-    stats = zeros_f32(2 * C, y.device)
-    call('sba_bn_stats', _dt(y), _p(y), _p(stats), N * H * W, C, _stream())
+    stats = zeros_f32((groups, 2 * C), y.device)
+    call('sba_bn_stats', _dt(y), _p(y), _p(stats), (N // groups) * H * W, groups, C, _stream())
     return stats
 
 
@@ -531,22 +513,12 @@ class ConvBNActFn(torch.autograd.Function):
     def forward(ctx, x, weight, gamma, beta, layer, kind, act, residual, groups=1):
         x = as_act(x)
         if groups == 1:
-            y, stats = conv_forward(x, layer.pw, kind)
-            N, C, H, W = y.shape
-            sts = [bn_prepare(stats, layer.bn, N * H * W, layer.bn.training)]
-            out = bn_act_forward(y, sts[0], act, residual)
+            y, stats = conv_forward(x, layer.pw, kind, want_stats=layer.bn.training)
         else:
             assert residual is None and x.shape[0] % groups == 0
             y, _ = conv_forward(x, layer.pw, kind, want_stats=False)
-            N, C, H, W = y.shape
-            ng = N // groups
-            out = empty_act(N, C // 2 if act == ACT_GLU else C, H, W, y)
-            sts = []
-            for g in range(groups):
-                yg = y[g * ng:(g + 1) * ng]
-                st = bn_prepare(bn_stats(yg), layer.bn, ng * H * W, layer.bn.training)
-                bn_act_forward(yg, st, act, out=out[g * ng:(g + 1) * ng])
-                sts.append(st)
+            stats = bn_stats(y, groups) if layer.bn.training else None
+        out, sts = bn_act_forward(y, stats, layer.bn, act, residual, groups)
         ctx.layer, ctx.kind, ctx.act, ctx.sts, ctx.groups = layer, kind, act, sts, groups
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, y)
@@ -557,14 +529,7 @@ class ConvBNActFn(torch.autograd.Function):
         x, y = ctx.saved_tensors
         layer, kind, act, groups = ctx.layer, ctx.kind, ctx.act, ctx.groups
         dout = _c(dout)
-        if groups == 1:
-            dy = bn_act_backward(y, dout, ctx.sts[0], layer.bn, act, ctx.needs_input_grad[2])
-        else:
-            dy = torch.empty_like(y)
-            ng = y.shape[0] // groups
-            for g in range(groups):
-                sl = slice(g * ng, (g + 1) * ng)
-                bn_act_backward(y[sl], dout[sl], ctx.sts[g], layer.bn, act, ctx.needs_input_grad[2], dy=dy[sl])
+        dy = bn_act_backward(y, dout, ctx.sts, layer.bn, act, ctx.needs_input_grad[2])
         if ctx.needs_input_grad[1]:
             conv_wgrad_overlapped(x, dy, layer.conv.weight, kind)
         dx = None
@@ -581,13 +546,10 @@ class ResBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, blk):
         x = as_act(x)
-        y1, s1 = conv_forward(x, blk.l1.pw, '3x3')
-        N, C1, H, W = y1.shape
-        st1 = bn_prepare(s1, blk.l1.bn, N * H * W, blk.l1.bn.training)
-        a1 = bn_act_forward(y1, st1, ACT_GLU)
-        y2, s2 = conv_forward(a1, blk.l2.pw, '3x3')
-        st2 = bn_prepare(s2, blk.l2.bn, N * H * W, blk.l2.bn.training)
-        out = bn_act_forward(y2, st2, ACT_NONE, residual=x)
+        y1, s1 = conv_forward(x, blk.l1.pw, '3x3', want_stats=blk.l1.bn.training)
+        a1, st1 = bn_act_forward(y1, s1, blk.l1.bn, ACT_GLU)
+        y2, s2 = conv_forward(a1, blk.l2.pw, '3x3', want_stats=blk.l2.bn.training)
+        out, st2 = bn_act_forward(y2, s2, blk.l2.bn, ACT_NONE, residual=x)
         ctx.blk, ctx.st1, ctx.st2 = blk, st1, st2
         ctx.save_for_backward(x, y1, a1, y2)
         return out
