@@ -15,33 +15,39 @@ constexpr int NT = 320;       // threads per pair: >= R (289), 5 waves
 constexpr int CCH = 16;       // feature channels staged per LDS chunk (sized so that two pairs fit one CU)
 constexpr int TMAX = 32;
 
+// The word axis of the LDS-resident [nef][words] matrices is padded to a COMPILE-TIME stride LP (20 for the
+// 18-word captions of the reference configs, else 32) and zero-filled beyond the caption length, so that
+// the nef x words inner products are unconditional, fully unrolled FMA runs fed by ds_read_b128.  (With a
+// run-time word count every single FMA became branch + ds_read_b32 + full LDS wait: ~10x slower.)
 struct Lds {
-    float* q;     // [nef][Lw]   words of caption i (zero beyond T)
+    float* q;     // [nef][LP]   words of caption i (zero beyond T)
     float* z;     // [Lw][R]     attention (scratch / A)
-    float* w;     // [nef][Lw]   weighted context (fwd) / dwctx (bwd)
+    float* w;     // [nef][LP]   weighted context (fwd) / dwctx (bwd)
     float* f;     // [CCH][R]    staged feature chunk
     float* t;     // [4*TMAX]    per-word scalars
 };
-__device__ __forceinline__ Lds carve(float* sm, int nef, int Lw, int R) {
+__device__ __forceinline__ Lds carve(float* sm, int nef, int LP, int Lw, int R) {
     Lds l;
     l.q = sm;
-    l.z = l.q + nef * Lw;
-    l.w = l.z + Lw * R;
-    l.f = l.w + nef * Lw;
+    l.z = l.q + nef * LP;
+    l.w = l.z + ((Lw * R + 3) & ~3);
+    l.f = l.w + nef * LP;
     l.t = l.f + CCH * R;
     return l;
 }
-inline size_t lds_bytes(int nef, int Lw, int R) {
-    return sizeof(float) * ((size_t)2 * nef * Lw + (size_t)Lw * R + (size_t)CCH * R + 4 * TMAX);
+inline size_t lds_bytes(int nef, int LP, int Lw, int R) {
+    const size_t zf = ((size_t)Lw * R + 3) & ~(size_t)3;       // keep the later arrays 16-byte aligned
+    return sizeof(float) * ((size_t)2 * nef * LP + zf + (size_t)CCH * R + 4 * TMAX);
 }
 
 // ---------------------------------------------------------------------------
+template <int LP>
 __global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
     const float* __restrict__ feat, const float* __restrict__ words, const int64_t* __restrict__ cap_lens,
     float* __restrict__ sim, float* __restrict__ attn, float* __restrict__ attn1, float* __restrict__ wctx_o,
     int B, int nef, int R, int Lw, float gamma1, float gamma2) {
-    extern __shared__ float sm[];
-    Lds L = carve(sm, nef, Lw, R);
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    Lds L = carve(sm, nef, LP, Lw, R);
     const int i = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6, nw = NT / 64;
     int T = (int)cap_lens[i];
@@ -49,16 +55,16 @@ __global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
     const int64_t pair = (int64_t)j * B + i;
     const float* fj = feat + (int64_t)j * nef * R;
 
-    for (int k = tid; k < nef * Lw; k += NT) {
-        const int t = k % Lw;
-        L.q[k] = t < T ? words[(int64_t)i * nef * Lw + k] : 0.f;
+    for (int k = tid; k < nef * LP; k += NT) {
+        const int c = k / LP, t = k - c * LP;
+        L.q[k] = t < T ? words[((int64_t)i * nef + c) * Lw + t] : 0.f;
     }
     __syncthreads();
 
     // phase 1: S[r][t] = sum_c f[c][r] q[c][t]; softmax over t; x gamma1
-    float s[TMAX];
+    float s[LP];
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) s[t] = 0.f;
+    for (int t = 0; t < LP; ++t) s[t] = 0.f;
     if (tid < R) {
         // 8 independent loads in flight per thread (a dependent load -> FMA chain made this
         // phase pure latency)
@@ -68,25 +74,28 @@ __global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
             for (int k = 0; k < 8; ++k) fv8[k] = fj[(int64_t)(c0 + k) * R + tid];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float* qr = &L.q[(c0 + k) * Lw];
+                const float4* qr = reinterpret_cast<const float4*>(&L.q[(c0 + k) * LP]);
 #pragma unroll
-                for (int t = 0; t < TMAX; ++t)
-                    if (t < Lw) s[t] += fv8[k] * qr[t];
+                for (int t4 = 0; t4 < LP / 4; ++t4) {
+                    const float4 qv = qr[t4];
+                    s[4 * t4] += fv8[k] * qv.x; s[4 * t4 + 1] += fv8[k] * qv.y;
+                    s[4 * t4 + 2] += fv8[k] * qv.z; s[4 * t4 + 3] += fv8[k] * qv.w;
+                }
             }
         }
         float mx = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t)
+        for (int t = 0; t < LP; ++t)
             if (t < T) mx = fmaxf(mx, s[t]);
         float sum = 0.f;
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
+        for (int t = 0; t < LP; ++t) {
             s[t] = t < T ? expf(s[t] - mx) : 0.f;
             sum += s[t];
         }
         const float inv = 1.f / sum;
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t)
+        for (int t = 0; t < LP; ++t)
             if (t < T) {
                 const float a1 = s[t] * inv;
                 attn1[(pair * Lw + t) * R + tid] = a1;
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
             const int cl = o / T, t = o - cl * T;
             float acc = 0.f;
             for (int r = 0; r < R; ++r) acc += L.f[cl * R + r] * L.z[t * R + r];
-            L.w[(c0 + cl) * Lw + t] = acc;
+            L.w[(c0 + cl) * LP + t] = acc;
             wctx_o[(pair * Lw + t) * nef + c0 + cl] = acc;
         }
         __syncthreads();
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
     for (int t = wid; t < T; t += nw) {
         float w12 = 0.f, n1 = 0.f, n2 = 0.f;
         for (int c = lane; c < nef; c += 64) {
-            const float qv = L.q[c * Lw + t], wv = L.w[c * Lw + t];
+            const float qv = L.q[c * LP + t], wv = L.w[c * LP + t];
             w12 += qv * wv; n1 += qv * qv; n2 += wv * wv;
         }
         w12 = wave_sum(w12); n1 = wave_sum(n1); n2 = wave_sum(n2);
@@ -146,13 +155,14 @@ __global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------
+template <int LP>
 __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
     const float* __restrict__ feat, const float* __restrict__ words, const int64_t* __restrict__ cap_lens,
     const float* __restrict__ sim, const float* __restrict__ attn, const float* __restrict__ attn1,
     const float* __restrict__ wctx_i, const float* __restrict__ dsim, float* __restrict__ dfeat,
     float* __restrict__ dwords, int B, int nef, int R, int Lw, float gamma1, float gamma2) {
-    extern __shared__ float sm[];
-    Lds L = carve(sm, nef, Lw, R);
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    Lds L = carve(sm, nef, LP, Lw, R);
     const int i = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6, nw = NT / 64;
     int T = (int)cap_lens[i];
@@ -162,9 +172,9 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
     const float g = dsim[pair];
     const float zsum = expf(sim[pair]);
 
-    for (int k = tid; k < nef * Lw; k += NT) {
-        const int t = k % Lw, c = k / Lw;
-        L.q[k] = t < T ? words[(int64_t)i * nef * Lw + k] : 0.f;
+    for (int k = tid; k < nef * LP; k += NT) {
+        const int c = k / LP, t = k - c * LP;
+        L.q[k] = t < T ? words[((int64_t)i * nef + c) * Lw + t] : 0.f;
         L.w[k] = t < T ? wctx_i[(pair * Lw + t) * nef + c] : 0.f;
     }
     __syncthreads();
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
     for (int t = wid; t < T; t += nw) {
         float w12 = 0.f, n1 = 0.f, n2 = 0.f;
         for (int c = lane; c < nef; c += 64) {
-            const float qv = L.q[c * Lw + t], wv = L.w[c * Lw + t];
+            const float qv = L.q[c * LP + t], wv = L.w[c * LP + t];
             w12 += qv * wv; n1 += qv * qv; n2 += wv * wv;
         }
         w12 = wave_sum(w12); n1 = wave_sum(n1); n2 = wave_sum(n2);
@@ -190,8 +200,8 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
     __syncthreads();
     // dq_direct[c][t] (kept in registers of the owning thread is not possible: write to dwords now),
     // then overwrite L.w with dwctx[c][t] = a*q - b*wctx
-    for (int k = tid; k < nef * Lw; k += NT) {
-        const int t = k % Lw, c = k / Lw;
+    for (int k = tid; k < nef * LP; k += NT) {
+        const int c = k / LP, t = k - c * LP;
         if (t < T) {
             const float qv = L.q[k], wv = L.w[k];
             if (dwords)
@@ -203,9 +213,9 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
     }
     __syncthreads();
     // pass A over the features: dA[t][r] = sum_c dwctx[c][t] f[c][r]
-    float dA[TMAX];
+    float dA[LP];
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) dA[t] = 0.f;
+    for (int t = 0; t < LP; ++t) dA[t] = 0.f;
     if (tid < R) {
         for (int c0 = 0; c0 < nef; c0 += 8) {
             float fv8[8];
@@ -213,14 +223,17 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
             for (int k = 0; k < 8; ++k) fv8[k] = fj[(int64_t)(c0 + k) * R + tid];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float* wr = &L.w[(c0 + k) * Lw];
+                const float4* wr = reinterpret_cast<const float4*>(&L.w[(c0 + k) * LP]);
 #pragma unroll
-                for (int t = 0; t < TMAX; ++t)
-                    if (t < Lw) dA[t] += fv8[k] * wr[t];
+                for (int t4 = 0; t4 < LP / 4; ++t4) {
+                    const float4 wv = wr[t4];
+                    dA[4 * t4] += fv8[k] * wv.x; dA[4 * t4 + 1] += fv8[k] * wv.y;
+                    dA[4 * t4 + 2] += fv8[k] * wv.z; dA[4 * t4 + 3] += fv8[k] * wv.w;
+                }
             }
         }
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t)
+        for (int t = 0; t < LP; ++t)
             if (t < T) L.z[t * R + tid] = dA[t] * attn[(pair * Lw + t) * R + tid];    // A*dA
     }
     __syncthreads();
@@ -233,13 +246,13 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
     }
     __syncthreads();
     // per region: dz = A (dA - dot), da1 = gamma1 dz, dS = a1 (da1 - sum_t a1 da1); keep A and dS in registers
-    float av[TMAX], ds[TMAX];
+    float av[LP], ds[LP];
 #pragma unroll
-    for (int t = 0; t < TMAX; ++t) { av[t] = 0.f; ds[t] = 0.f; }
+    for (int t = 0; t < LP; ++t) { av[t] = 0.f; ds[t] = 0.f; }
     if (tid < R) {
         float dot1 = 0.f;
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t)
+        for (int t = 0; t < LP; ++t)
             if (t < T) {
                 const float a = attn[(pair * Lw + t) * R + tid];
                 const float a1 = attn1[(pair * Lw + t) * R + tid];
@@ -250,19 +263,23 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
                 dot1 += a1 * da1;
             }
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t)
-            if (t < T) {
-                ds[t] = dA[t] * (ds[t] - dot1);
-                L.z[t * R + tid] = ds[t];
-            }
-        // pass B: dfeat[c][r] += sum_t dwctx[c][t] A[t][r] + dS[r][t] q[c][t]
+        for (int t = 0; t < LP; ++t) {
+            ds[t] = t < T ? dA[t] * (ds[t] - dot1) : 0.f;
+            if (t < T) L.z[t * R + tid] = ds[t];
+        }
+        // pass B: dfeat[c][r] += sum_t dwctx[c][t] A[t][r] + dS[r][t] q[c][t]  (padding columns are zero)
         for (int c = 0; c < nef; ++c) {
-            const float* wr = &L.w[c * Lw];
-            const float* qr = &L.q[c * Lw];
+            const float4* wr = reinterpret_cast<const float4*>(&L.w[c * LP]);
+            const float4* qr = reinterpret_cast<const float4*>(&L.q[c * LP]);
             float acc = 0.f;
 #pragma unroll
-            for (int t = 0; t < TMAX; ++t)
-                if (t < Lw) acc += wr[t] * av[t] + ds[t] * qr[t];
+            for (int t4 = 0; t4 < LP / 4; ++t4) {
+                const float4 wv = wr[t4], qv = qr[t4];
+                acc += wv.x * av[4 * t4] + ds[4 * t4] * qv.x;
+                acc += wv.y * av[4 * t4 + 1] + ds[4 * t4 + 1] * qv.y;
+                acc += wv.z * av[4 * t4 + 2] + ds[4 * t4 + 2] * qv.z;
+                acc += wv.w * av[4 * t4 + 3] + ds[4 * t4 + 3] * qv.w;
+            }
             atomicAdd(&dfeat[((int64_t)j * nef + c) * R + tid], acc);
         }
     }
@@ -368,12 +385,20 @@ extern "C" int sba_damsm_words_fwd(const float* feat, const float* words, const 
                                    float gamma1, float gamma2, void* stream) {
     if (!feat || !words || !cap_lens || !sim || !attn || !attn1 || !wctx) return SBA_E_ARG;
     if (B <= 0 || B > 1024 || nef <= 0 || nef % CCH || R <= 0 || R > NT || L <= 0 || L > TMAX) return SBA_E_ARG;
-    const size_t sh = lds_bytes(nef, L, R);
+    const int LP = L <= 20 ? 20 : 32;
+    const size_t sh = lds_bytes(nef, LP, L, R);
     if (sh > 160 * 1024) return SBA_E_ARG;
-    (void)hipFuncSetAttribute((const void*)damsm_words_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)sh);
-    hipLaunchKernelGGL(damsm_words_fwd_kernel, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words, cap_lens,
-                       sim, attn, attn1, wctx, B, nef, R, L, gamma1, gamma2);
+    if (LP == 20) {
+        (void)hipFuncSetAttribute((const void*)damsm_words_fwd_kernel<20>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(damsm_words_fwd_kernel<20>, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words,
+                           cap_lens, sim, attn, attn1, wctx, B, nef, R, L, gamma1, gamma2);
+    } else {
+        (void)hipFuncSetAttribute((const void*)damsm_words_fwd_kernel<32>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(damsm_words_fwd_kernel<32>, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words,
+                           cap_lens, sim, attn, attn1, wctx, B, nef, R, L, gamma1, gamma2);
+    }
     return SBA_CHECK_LAUNCH();
 }
 
@@ -383,12 +408,20 @@ extern "C" int sba_damsm_words_bwd(const float* feat, const float* words, const 
                                    float gamma2, void* stream) {
     if (!feat || !words || !cap_lens || !sim || !attn || !attn1 || !wctx || !dsim || !dfeat) return SBA_E_ARG;
     if (B <= 0 || B > 1024 || nef <= 0 || nef % CCH || R <= 0 || R > NT || L <= 0 || L > TMAX) return SBA_E_ARG;
-    const size_t sh = lds_bytes(nef, L, R);
+    const int LP = L <= 20 ? 20 : 32;
+    const size_t sh = lds_bytes(nef, LP, L, R);
     if (sh > 160 * 1024) return SBA_E_ARG;
-    (void)hipFuncSetAttribute((const void*)damsm_words_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)sh);
-    hipLaunchKernelGGL(damsm_words_bwd_kernel, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words, cap_lens,
-                       sim, attn, attn1, wctx, dsim, dfeat, dwords, B, nef, R, L, gamma1, gamma2);
+    if (LP == 20) {
+        (void)hipFuncSetAttribute((const void*)damsm_words_bwd_kernel<20>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(damsm_words_bwd_kernel<20>, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words,
+                           cap_lens, sim, attn, attn1, wctx, dsim, dfeat, dwords, B, nef, R, L, gamma1, gamma2);
+    } else {
+        (void)hipFuncSetAttribute((const void*)damsm_words_bwd_kernel<32>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipLaunchKernelGGL(damsm_words_bwd_kernel<32>, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words,
+                           cap_lens, sim, attn, attn1, wctx, dsim, dfeat, dwords, B, nef, R, L, gamma1, gamma2);
+    }
     return SBA_CHECK_LAUNCH();
 }
 

@@ -98,7 +98,7 @@ template <> struct Mma<float> {
 // LDS: double-buffered A[BM] and B[BN] rows of 80 B (64 data + 16 pad: the
 // pad makes the 16-lane ds_read_b128 groups hit 16 distinct 4-bank slots).
 // ---------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, int KS, int KG>
+template <typename T, int BM, int BN, int WM, int WN, int KS, int KG, int PF>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KG) void igemm_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                     T* __restrict__ y, const T* __restrict__ addend,
                                                     float* __restrict__ stats, const sba_conv_geom g,
@@ -114,7 +114,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KG) void igemm_kernel(
     constexpr int AI = (BM + RP - 1) / RP, BI = (BN + RP - 1) / RP;    // 16-byte loads per thread per slab
     static_assert(BM % WM == 0 && BN % WN == 0 && WM % 32 == 0 && WN % 32 == 0, "tile");
     constexpr int TILE_BYTES = (BM + BN) * ROWB;
-    constexpr int GROUP_BYTES = 2 * KS * TILE_BYTES;
+    // PF = stages of global loads kept in flight (register sets); PF == 1: double-buffered LDS, one
+    // stage ahead.  PF == 3 (small tiles, ~1 workgroup per CU, nothing else to hide the load latency
+    // behind): three register sets + three LDS buffers, loads issued three stages ahead.
+    static_assert(PF == 1 || PF == 3, "prefetch depth");
+    constexpr int NBUF = PF == 1 ? 2 : 3;
+    constexpr int GROUP_BYTES = NBUF * KS * TILE_BYTES;
     static_assert(KG == 1 || (KG - 1) * BM * BN * 4 <= KG * GROUP_BYTES, "K-group partials fit in the staging buffers");
 
     // KS slabs are staged per barrier (KS > 1 for the small tiles, whose MFMA work per slab is short);
@@ -209,8 +214,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KG) void igemm_kernel(
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, w_bytes, 0x00020000);
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
-    uint4 ra[KS][AI], rb[KS][BI];
-    auto gload = [&](int /*stage*/) {
+    uint4 rra[PF][KS][AI], rrb[PF][KS][BI];
+    auto gload = [&](uint4 (&ra)[KS][AI], uint4 (&rb)[KS][BI]) {
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const bool live = g_step < s_end;
@@ -248,7 +253,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KG) void igemm_kernel(
             if (++g_c == cpt) { g_c = 0; ++g_tap; }
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const uint4 (&ra)[KS][AI], const uint4 (&rb)[KS][BI]) {
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             unsigned char* base = lds + (buf * KS + k) * TILE_BYTES;
@@ -272,19 +277,47 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KG) void igemm_kernel(
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nstages = (per_group + KS - 1) / KS;      // uniform over the groups (dead slabs load zeros)
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int s = 0; s < nstages; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nstages) gload(s + 1);
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            const unsigned char* base = lds + (buf * KS + k) * TILE_BYTES;
-            Mma<T>::template slab<TM, TN, ROWB>(base + wm0 * ROWB, base + (BM + wn0) * ROWB, lane, acc);
-        }
-        if (s + 1 < nstages) lstore(buf ^ 1);
+    if (PF == 1) {
+        gload(rra[0], rrb[0]);
+        lstore(0, rra[0], rrb[0]);
         __syncthreads();
+        for (int s = 0; s < nstages; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < nstages) gload(rra[0], rrb[0]);
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                const unsigned char* base = lds + (buf * KS + k) * TILE_BYTES;
+                Mma<T>::template slab<TM, TN, ROWB>(base + wm0 * ROWB, base + (BM + wn0) * ROWB, lane, acc);
+            }
+            if (s + 1 < nstages) lstore(buf ^ 1, rra[0], rrb[0]);
+            __syncthreads();
+        }
+    } else {
+        // stage s: LDS buffer s % 3 holds it; register set (s+1) % 3 and (s+2) % 3 hold the loads of
+        // stages s+1, s+2 (in flight); set s % 3 is free -> issue stage s+3 into it.  Stages past the
+        // end load zeros (OOB offsets), so the trip count is simply rounded up to a multiple of 3.
+        constexpr int P1 = PF > 1 ? 1 : 0, P2 = PF > 2 ? 2 : 0;
+        gload(rra[0], rrb[0]);
+        gload(rra[P1], rrb[P1]);
+        gload(rra[P2], rrb[P2]);
+        lstore(0, rra[0], rrb[0]);
+        __syncthreads();
+        auto stage = [&](int buf, uint4 (&fa)[KS][AI], uint4 (&fb)[KS][BI], const uint4 (&na)[KS][AI],
+                         const uint4 (&nb)[KS][BI]) {
+            gload(fa, fb);
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                const unsigned char* base = lds + (buf * KS + k) * TILE_BYTES;
+                Mma<T>::template slab<TM, TN, ROWB>(base + wm0 * ROWB, base + (BM + wn0) * ROWB, lane, acc);
+            }
+            lstore(buf == 2 ? 0 : buf + 1, na, nb);
+            __syncthreads();
+        };
+        for (int s = 0; s < nstages; s += 3) {
+            stage(0, rra[0], rrb[0], rra[P1], rrb[P1]);
+            stage(1, rra[P1], rrb[P1], rra[P2], rrb[P2]);
+            stage(2, rra[P2], rrb[P2], rra[0], rrb[0]);
+        }
     }
 
     if (KG > 1) {
@@ -1083,11 +1116,15 @@ struct IgemmCfg { int bm, bn, ks, occ; float eff; bool split; };
 // A: big square tile, B: wide-M tile for Cout = 64, C: mid tile, D: small tile (+split-K),
 // E: skinny GEMM tile for the 4x4 / 8x8 maps with thousands of channels (+split-K)
 // F: the small tile with 4 in-workgroup K-groups (16 waves): latency-bound layers with too few tiles
-static const IgemmCfg kCfg[6] = {
+// G: the small tile with three stages of loads in flight
+// H: the small tile with two in-workgroup K-groups (8 waves = 2 per SIMD, so that one wave's
+//    ds_read -> MFMA -> barrier chain overlaps the other's)
+static const IgemmCfg kCfg[8] = {
     {128, 128, 1, 3, 1.00f, false}, {256, 64, 1, 3, 1.00f, false}, {128, 64, 2, 2, 0.80f, false},
-    {64, 64, 2, 3, 0.50f, true},    {320, 128, 2, 1, 0.90f, true},  {64, 64, 1, 1, 0.50f, true}};
+    {64, 64, 2, 3, 0.50f, true},    {320, 128, 2, 1, 0.90f, true},  {64, 64, 1, 1, 0.50f, true},
+    {64, 64, 2, 2, 0.50f, true},    {64, 64, 2, 1, 0.50f, true}};
 
-template <typename T, int BM, int BN, int WM, int WN, int KS, int KG = 1>
+template <typename T, int BM, int BN, int WM, int WN, int KS, int KG = 1, int PF = 1>
 static void launch_cfg(const T* xp, const T* wp, T* yp, const T* ap, float* stats, const sba_conv_geom& g, int M,
                        int nslabs, int split, float* ws, hipStream_t st, const float* bias) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64 * KG;
@@ -1097,7 +1134,7 @@ static void launch_cfg(const T* xp, const T* wp, T* yp, const T* ap, float* stat
         split = cdiv(nslabs, sps);
     }
     dim3 grid(cdiv(M, BM), cdiv(g.Cout, BN), split);
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KS, KG>), grid, dim3(NT), 0, st, xp, wp, yp, ap, stats, g, M,
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KS, KG, PF>), grid, dim3(NT), 0, st, xp, wp, yp, ap, stats, g, M,
                        split > 1 ? ws : (float*)nullptr, sps, bias);
 }
 
@@ -1105,7 +1142,7 @@ static int forced_cfg() {
     static int v = -2;
     if (v == -2) {
         const char* e = getenv("SBA_IGEMM_CFG");       // tuning aid only: A..E
-        v = (e && e[0] >= 'A' && e[0] <= 'F') ? e[0] - 'A' : -1;
+        v = (e && e[0] >= 'A' && e[0] <= 'H') ? e[0] - 'A' : -1;
     }
     return v;
 }
@@ -1145,12 +1182,17 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
         static int d2f = -1;
         if (d2f < 0) { const char* e = getenv("SBA_IGEMM_D2F"); d2f = (e && e[0] == '1') ? 1 : 0; }
         if (d2f && best == 3) best = 5;
+        static int d2g = -1;
+        if (d2g < 0) { const char* e = getenv("SBA_IGEMM_D2G"); d2g = (e && e[0] == '1') ? 1 : 0; }
+        if (d2g && best == 3) best = 6;
     }
     {
         const IgemmCfg& k = kCfg[best];
         const int tiles = cdiv(M, k.bm) * cdiv(g.Cout, k.bn);
         const int slots = 256 * k.occ;
-        if (k.split && can_split && tiles < slots && M <= 2048) {     // split-K only pays on the GEMM-like maps
+        static int split_m = -1;
+        if (split_m < 0) { const char* e = getenv("SBA_IGEMM_SPLIT_M"); split_m = e ? atoi(e) : 2048; }
+        if (k.split && can_split && tiles < slots && M <= split_m) {     // split-K only pays on the GEMM-like maps
             int split = cdiv(slots, tiles);
             if (split > nslabs / 8) split = nslabs / 8;
             if (split > 32) split = 32;
@@ -1164,6 +1206,8 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
         case 2: launch_cfg<T, 128, 64, 32, 64, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
         case 3: launch_cfg<T, 64, 64, 32, 32, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
         case 5: launch_cfg<T, 64, 64, 32, 32, 1, 4>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
+        case 6: launch_cfg<T, 64, 64, 32, 32, 2, 1, 3>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
+        case 7: launch_cfg<T, 64, 64, 32, 32, 2, 2, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
         default: launch_cfg<T, 320, 128, 64, 64, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
     }
     return SBA_CHECK_LAUNCH();
