@@ -119,137 +119,163 @@ __global__ __launch_bounds__(256) void img_head_bwd_kernel(const T* __restrict__
 }
 
 // ------------------------------------------------------------------ discriminator stem
-// thread = (output pixel, V-channel vector); weights transposed in LDS as [48][C]
+// conv4x4 s2 (3 -> C) + LeakyReLU(0.2) on the NCHW f32 image.  K = 48 is too thin for the implicit-GEMM
+// tiles, so forward and data-gradient are VALU kernels organised so that every LDS access is a
+// ds_read_b128 feeding 4 FMAs; the weight gradient (a 64-pixel-deep K loop per tile) runs on the f32
+// matrix cores.
+constexpr int STEM_CB = 32;          // output channels per thread (forward)
+
+// forward: thread = (output pixel, 32-channel block); the 48 patch values live in registers, the
+// block's weights in LDS as [48][32]
 template <typename T>
 __global__ __launch_bounds__(256) void d_stem_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                          T* __restrict__ out, int N, int S, int C) {
     constexpr int V = Vec16<T>::N;
-    extern __shared__ float s_w[];       // [48][C]: k = (kh*4+kw)*3+ci
-    for (int i = threadIdx.x; i < 48 * C; i += blockDim.x) {
-        const int co = i / 48, k = i - co * 48;
-        s_w[k * C + co] = w[i];
+    __shared__ __attribute__((aligned(16))) float s_w[48 * STEM_CB];
+    const int c0 = blockIdx.y * STEM_CB;
+    for (int i = threadIdx.x; i < 48 * STEM_CB; i += blockDim.x) {
+        const int k = i / STEM_CB, cl = i - k * STEM_CB;       // w is [co][kh][kw][ci] = [co][48]
+        s_w[i] = w[(c0 + cl) * 48 + k];
     }
     __syncthreads();
-    const int O = S / 2, cv = C / V;
-    const int64_t total = (int64_t)N * O * O * cv;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cv) * V;
-        int64_t p = i / cv;
-        const int ox = (int)(p % O), oy = (int)((p / O) % O), n = (int)(p / ((int64_t)O * O));
-        float acc[V];
+    const int O = S / 2;
+    const int64_t total = (int64_t)N * O * O;
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const int ox = (int)(p % O), oy = (int)((p / O) % O), n = (int)(p / ((int64_t)O * O));
+    float pv[48];
 #pragma unroll
-        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    for (int kh = 0; kh < 4; ++kh) {
+        const int iy = 2 * oy + kh - 1;
+        const bool oky = iy >= 0 && iy < S;
+        const int iyc = oky ? iy : 0;
 #pragma unroll
-        for (int kh = 0; kh < 4; ++kh) {
-            const int iy = 2 * oy + kh - 1;
-            if (iy < 0 || iy >= S) continue;
+        for (int kw = 0; kw < 4; ++kw) {
+            const int ix = 2 * ox + kw - 1;
+            const bool ok = oky && ix >= 0 && ix < S;
+            const int ixc = (ix >= 0 && ix < S) ? ix : 0;
 #pragma unroll
-            for (int kw = 0; kw < 4; ++kw) {
-                const int ix = 2 * ox + kw - 1;
-                if (ix < 0 || ix >= S) continue;
-#pragma unroll
-                for (int ci = 0; ci < 3; ++ci) {
-                    const float v = img[(((int64_t)n * 3 + ci) * S + iy) * S + ix];
-                    const float* wr = &s_w[((kh * 4 + kw) * 3 + ci) * C + c];
-#pragma unroll
-                    for (int k = 0; k < V; ++k) acc[k] += v * wr[k];
-                }
+            for (int ci = 0; ci < 3; ++ci) {
+                const float v = img[(((int64_t)n * 3 + ci) * S + iyc) * S + ixc];
+                pv[(kh * 4 + kw) * 3 + ci] = ok ? v : 0.f;
             }
         }
+    }
+    float acc[STEM_CB];
+#pragma unroll
+    for (int c = 0; c < STEM_CB; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 48; ++k) {
+        const float4* wr = reinterpret_cast<const float4*>(&s_w[k * STEM_CB]);
+#pragma unroll
+        for (int c4 = 0; c4 < STEM_CB / 4; ++c4) {
+            const float4 wv = wr[c4];
+            acc[4 * c4] += pv[k] * wv.x; acc[4 * c4 + 1] += pv[k] * wv.y;
+            acc[4 * c4 + 2] += pv[k] * wv.z; acc[4 * c4 + 3] += pv[k] * wv.w;
+        }
+    }
+    T* op = out + p * C + c0;
+#pragma unroll
+    for (int cv = 0; cv < STEM_CB / V; ++cv) {
         Vec16<T> o;
 #pragma unroll
-        for (int k = 0; k < V; ++k) o.set(k, acc[k] > 0.f ? acc[k] : 0.2f * acc[k]);
-        st16(out + p * C + c, o);
+        for (int k = 0; k < V; ++k) {
+            const float a = acc[cv * V + k];
+            o.set(k, a > 0.f ? a : 0.2f * a);
+        }
+        st16(op + cv * V, o);
     }
 }
 
-// dw[co][k] += sum_pix dpre[pix][co] * patch[pix][k]; block = TILES x 64 output pixels,
-// thread owns a 4(co) x 3(k) register block
+// dw[co][k] += sum_pix dpre[pix][co] * patch[pix][k] on the f32 matrix cores: per 64-pixel tile the
+// workgroup stages dpre [64][C] and the patches [64][48 (+16 zero)] in LDS (row strides = 32 mod 64
+// floats, so the two half-waves of an MFMA operand read hit disjoint banks) and each wave accumulates
+// its 32(co) x 32(k) tiles over the 64 pixels with 32 v_mfma_f32_32x32x2_f32.
 template <typename T>
 __global__ __launch_bounds__(256) void d_stem_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ out,
                                                            const T* __restrict__ dout, float* __restrict__ dw, int N,
                                                            int S, int C, int tiles_per_block) {
-    extern __shared__ float sm[];
-    const int DS = C + 4;
-    float* s_d = sm;                 // [64][C+4]
-    float* s_p = s_d + 64 * DS;      // [64][52]
-    const int tid = threadIdx.x;
+    constexpr int V = Vec16<T>::N;
+    constexpr int PS = 96;                       // patch row stride (64 columns used, 48 real)
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int DS = C + (C % 64 == 0 ? 32 : 0);   // C is a multiple of 32 -> DS = 32 mod 64
+    float* s_d = sm;                             // [64][DS]
+    float* s_p = s_d + 64 * DS;                  // [64][PS]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int O = S / 2;
     const int64_t total = (int64_t)N * O * O;
-    const int items = (C / 4) * 16;
-    float acc[4][12];                // up to 4 items per thread (C <= 256)
+    const int ntile = (C / 32) * 2;              // (co tile, k tile) pairs, <= 16
+    f32x16_t acc[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 12; ++b) acc[a][b] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    for (int i = tid; i < 64 * PS; i += 256) s_p[i] = 0.f;       // padding columns stay zero
     for (int tile = 0; tile < tiles_per_block; ++tile) {
         const int64_t p0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * 64;
         if (p0 >= total) break;
         __syncthreads();
-        for (int i = tid; i < 64 * C; i += 256) {
-            const int t = i / C, c = i - t * C;
-            const int64_t p = p0 + t;
-            float v = 0.f;
-            if (p < total) {
-                const float o = to_f<T>(out[p * C + c]);
-                v = to_f<T>(dout[p * C + c]) * (o > 0.f ? 1.f : 0.2f);
-            }
-            s_d[t * DS + c] = v;
+        const int cvn = C / V;
+        for (int i = tid; i < 64 * cvn; i += 256) {
+            const int t = i / cvn, c = (i - t * cvn) * V;
+            const int64_t pp = p0 + t;
+            Vec16<T> ov, dv;
+            const bool live = pp < total;
+            if (live) { ov = ld16(out + pp * C + c); dv = ld16(dout + pp * C + c); }
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+                s_d[t * DS + c + k] = live ? dv.get(k) * (ov.get(k) > 0.f ? 1.f : 0.2f) : 0.f;
         }
         for (int i = tid; i < 64 * 48; i += 256) {
             const int t = i / 48, k = i - t * 48;
-            const int64_t p = p0 + t;
+            const int64_t pp = p0 + t;
             float v = 0.f;
-            if (p < total) {
-                const int ox = (int)(p % O), oy = (int)((p / O) % O), n = (int)(p / ((int64_t)O * O));
+            if (pp < total) {
+                const int ox = (int)(pp % O), oy = (int)((pp / O) % O), n = (int)(pp / ((int64_t)O * O));
                 const int ci = k % 3, kw = (k / 3) % 4, kh = k / 12;
                 const int iy = 2 * oy + kh - 1, ix = 2 * ox + kw - 1;
                 if (iy >= 0 && iy < S && ix >= 0 && ix < S) v = img[(((int64_t)n * 3 + ci) * S + iy) * S + ix];
             }
-            s_p[t * 52 + k] = v;
+            s_p[t * PS + k] = v;
         }
         __syncthreads();
+        const int rl = lane & 31, hf = lane >> 5;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const int it = tid + 256 * a;
-            if (it < items) {
-                const int cg = it / 16, kg = it - cg * 16;
-                for (int t = 0; t < 64; ++t) {
-                    float dv[4], pv[3];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) dv[u] = s_d[t * DS + cg * 4 + u];
-#pragma unroll
-                    for (int u = 0; u < 3; ++u) pv[u] = s_p[t * 52 + kg * 3 + u];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int v2 = 0; v2 < 3; ++v2) acc[a][u * 3 + v2] += dv[u] * pv[v2];
-                }
+            const int tl = wid + 4 * a;
+            if (tl < ntile) {
+                const int mt = tl >> 1, nt = tl & 1;
+                const float* ap = s_d + hf * DS + mt * 32 + rl;
+                const float* bp = s_p + hf * PS + nt * 32 + rl;
+#pragma unroll 8
+                for (int kk = 0; kk < 32; ++kk)
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk * DS], bp[2 * kk * PS], acc[a], 0, 0, 0);
             }
         }
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-        const int it = tid + 256 * a;
-        if (it < items) {
-            const int cg = it / 16, kg = it - cg * 16;
+        const int tl = wid + 4 * a;
+        if (tl < ntile) {
+            const int mt = tl >> 1, nt = tl & 1;
+            const int k = nt * 32 + (lane & 31);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v2 = 0; v2 < 3; ++v2)
-                    atomicAdd(&dw[(cg * 4 + u) * 48 + kg * 3 + v2], acc[a][u * 3 + v2]);
+            for (int r = 0; r < 16; ++r) {
+                const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (k < 48) atomicAdd(&dw[co * 48 + k], acc[a][r]);
+            }
         }
     }
 }
 
-// dimg[n][ci][iy][ix] = sum over the (<=4) output pixels reading it, all co
+// dimg[n][ci][iy][ix] = sum over the (<=4) output pixels reading it, all co.  thread = input pixel;
+// weights in LDS as [48][C] (co contiguous): per 8 channels of dpre, 6 ds_read_b128 feed 24 FMAs
 template <typename T>
 __global__ __launch_bounds__(256) void d_stem_dgrad_kernel(const float* __restrict__ w, const T* __restrict__ out,
                                                            const T* __restrict__ dout, float* __restrict__ dimg,
                                                            int N, int S, int C) {
     constexpr int V = Vec16<T>::N;
-    extern __shared__ float s_w[];       // [48][C]
+    extern __shared__ __attribute__((aligned(16))) float s_w[];       // [48][C]
     for (int i = threadIdx.x; i < 48 * C; i += blockDim.x) {
         const int co = i / 48, k = i - co * 48;
         s_w[k * C + co] = w[i];
@@ -257,36 +283,44 @@ __global__ __launch_bounds__(256) void d_stem_dgrad_kernel(const float* __restri
     __syncthreads();
     const int O = S / 2;
     const int64_t total = (int64_t)N * S * S;
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total;
-         p += (int64_t)gridDim.x * blockDim.x) {
-        const int ix = (int)(p % S), iy = (int)((p / S) % S), n = (int)(p / ((int64_t)S * S));
-        float acc[3] = {0.f, 0.f, 0.f};
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const int ix = (int)(p % S), iy = (int)((p / S) % S), n = (int)(p / ((int64_t)S * S));
+    float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int kh = ((iy + 1) & 1) + 2 * j;
-            const int oy = (iy + 1 - kh) / 2;
-            if (oy < 0 || oy >= O || iy + 1 - kh < 0) continue;
+    for (int j = 0; j < 2; ++j) {
+        const int kh = ((iy + 1) & 1) + 2 * j;
+        const int ty = iy + 1 - kh;                    // = 2 * oy
+        const int oy = ty >> 1;
+        const bool oky = ty >= 0 && oy < O;
 #pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2) {
-                const int kw = ((ix + 1) & 1) + 2 * i2;
-                const int ox = (ix + 1 - kw) / 2;
-                if (ox < 0 || ox >= O || ix + 1 - kw < 0) continue;
-                const int64_t q = (((int64_t)n * O + oy) * O + ox) * C;
-                for (int cv = 0; cv < C / V; ++cv) {
-                    Vec16<T> ov = ld16(out + q + cv * V), dv = ld16(dout + q + cv * V);
+        for (int i2 = 0; i2 < 2; ++i2) {
+            const int kw = ((ix + 1) & 1) + 2 * i2;
+            const int tx = ix + 1 - kw;
+            const int ox = tx >> 1;
+            const bool ok = oky && tx >= 0 && ox < O;
+            const int64_t q = (((int64_t)n * O + (oky ? oy : 0)) * O + ((tx >= 0 && ox < O) ? ox : 0)) * C;
+            const float* wt = &s_w[(kh * 4 + kw) * 3 * C];
+            for (int cv = 0; cv < C / V; ++cv) {
+                Vec16<T> ov = ld16(out + q + cv * V), dv = ld16(dout + q + cv * V);
+                float dp[V];
 #pragma unroll
-                    for (int k = 0; k < V; ++k) {
-                        const float dp = dv.get(k) * (ov.get(k) > 0.f ? 1.f : 0.2f);
-                        const int co = cv * V + k;
+                for (int k = 0; k < V; ++k) dp[k] = ok ? dv.get(k) * (ov.get(k) > 0.f ? 1.f : 0.2f) : 0.f;
 #pragma unroll
-                        for (int ci = 0; ci < 3; ++ci) acc[ci] += dp * s_w[((kh * 4 + kw) * 3 + ci) * C + co];
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float4* wr = reinterpret_cast<const float4*>(wt + ci * C + cv * V);
+#pragma unroll
+                    for (int k4 = 0; k4 < V / 4; ++k4) {
+                        const float4 wv = wr[k4];
+                        acc[ci] += dp[4 * k4] * wv.x + dp[4 * k4 + 1] * wv.y + dp[4 * k4 + 2] * wv.z +
+                                   dp[4 * k4 + 3] * wv.w;
                     }
                 }
             }
         }
-#pragma unroll
-        for (int ci = 0; ci < 3; ++ci) dimg[(((int64_t)n * 3 + ci) * S + iy) * S + ix] = acc[ci];
     }
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) dimg[(((int64_t)n * 3 + ci) * S + iy) * S + ix] = acc[ci];
 }
 
 // ------------------------------------------------------------------ logits head
@@ -433,21 +467,19 @@ extern "C" int sba_img_head_bwd(int dtype, const void* h, const float* w, const 
 
 extern "C" int sba_d_stem_fwd(int dtype, const float* img, const float* w, void* out, int N, int S, int C,
                               void* stream) {
-    if (!img || !w || !out || N <= 0 || S <= 0 || S % 2 || C <= 0 || C % 8 || C > 256) return SBA_E_ARG;
-    const int V = dtype == SBA_BF16 ? 8 : 4;
-    const int64_t total = (int64_t)N * (S / 2) * (S / 2) * (C / V);
-    const size_t sh = sizeof(float) * 48 * C;
+    if (!img || !w || !out || N <= 0 || S <= 0 || S % 2 || C <= 0 || C % STEM_CB || C > 256) return SBA_E_ARG;
+    const int64_t pix = (int64_t)N * (S / 2) * (S / 2);
+    if ((pix + 255) / 256 > 0x7fffffff) return SBA_E_ARG;
     SBA_DISPATCH(dtype, {
-        set_lds(d_stem_fwd_kernel<T>, sh);
-        hipLaunchKernelGGL((d_stem_fwd_kernel<T>), dim3(grid_for(total, 4096)), dim3(256), sh, (hipStream_t)stream,
-                           img, w, (T*)out, N, S, C);
+        hipLaunchKernelGGL((d_stem_fwd_kernel<T>), dim3((unsigned)((pix + 255) / 256), C / STEM_CB), dim3(256), 0,
+                           (hipStream_t)stream, img, w, (T*)out, N, S, C);
     });
     return SBA_CHECK_LAUNCH();
 }
 
 extern "C" int sba_d_stem_bwd(int dtype, const float* img, const float* w, const void* out, const void* dout,
                               float* dimg, float* dw, int N, int S, int C, void* stream) {
-    if (!img || !w || !out || !dout || N <= 0 || S <= 0 || S % 2 || C <= 0 || C % 8 || C > 256) return SBA_E_ARG;
+    if (!img || !w || !out || !dout || N <= 0 || S <= 0 || S % 2 || C <= 0 || C % 32 || C > 256) return SBA_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (dw) {
         const int64_t pix = (int64_t)N * (S / 2) * (S / 2);
@@ -455,7 +487,7 @@ extern "C" int sba_d_stem_bwd(int dtype, const float* img, const float* w, const
         int tpb = (int)((tiles + 511) / 512);
         if (tpb < 1) tpb = 1;
         const int blocks = (int)((tiles + tpb - 1) / tpb);
-        const size_t sh = sizeof(float) * (64 * (C + 4) + 64 * 52);
+        const size_t sh = sizeof(float) * (64 * (C + (C % 64 == 0 ? 32 : 0)) + 64 * 96);
         SBA_DISPATCH(dtype, {
             set_lds(d_stem_wgrad_kernel<T>, sh);
             hipLaunchKernelGGL((d_stem_wgrad_kernel<T>), dim3(blocks), dim3(256), sh, st, img, (const T*)out,
@@ -466,8 +498,8 @@ extern "C" int sba_d_stem_bwd(int dtype, const float* img, const float* w, const
         const size_t sh = sizeof(float) * 48 * C;
         SBA_DISPATCH(dtype, {
             set_lds(d_stem_dgrad_kernel<T>, sh);
-            hipLaunchKernelGGL((d_stem_dgrad_kernel<T>), dim3(grid_for((int64_t)N * S * S, 4096)), dim3(256), sh, st,
-                               w, (const T*)out, (const T*)dout, dimg, N, S, C);
+            hipLaunchKernelGGL((d_stem_dgrad_kernel<T>), dim3((unsigned)(((int64_t)N * S * S + 255) / 256)), dim3(256),
+                               sh, st, w, (const T*)out, (const T*)dout, dimg, N, S, C);
         });
     }
     return SBA_CHECK_LAUNCH();
