@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256) void img_head_fwd_kernel(const T* __restrict__
 }
 
 // one thread per INPUT pixel p: d[27] = dpre of the 9 output pixels that read p (x 3 channels);
-// dh[p][ci] = sum d[co,kh,kw] w[co][kh][kw][ci];  dw[co][kh][kw][ci] += sum_p d[p][co,kh,kw] h[p][ci]
+// dh[p][ci] = sum d[co,kh,kw] w[co][kh][kw][ci]   (27 x C FMAs per pixel, weights via ds_read_b128)
+// dw[co][kh][kw][ci] += sum_p d[p][co,kh,kw] h[p][ci]: a (27 -> 32) x C x 256-pixel contraction per
+// workgroup on the f32 matrix cores (each wave takes 64 of the 256 pixels), reduced through LDS
 template <typename T, int C>
 __global__ __launch_bounds__(256) void img_head_bwd_kernel(const T* __restrict__ h, const float* __restrict__ w,
                                                            const float* __restrict__ img,
@@ -55,41 +57,44 @@ __global__ __launch_bounds__(256) void img_head_bwd_kernel(const T* __restrict__
                                                            float* __restrict__ dw, int N, int H, int W,
                                                            int accumulate) {
     constexpr int V = Vec16<T>::N;
-    constexpr int HS = C + 1, DS = 28;
-    extern __shared__ float sm[];
+    constexpr int HS = (C % 64 == 32) ? C : C + 32, DS = 32;     // row strides = 32 mod 64 floats (half-waves on disjoint banks)
+    constexpr int NTL = C / 32;                  // 32-channel tiles of dw
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     float* s_w = sm;                 // [27][C]
     float* s_h = s_w + 27 * C;       // [256][HS]
-    float* s_d = s_h + 256 * HS;     // [256][DS]
-    const int tid = threadIdx.x;
+    float* s_d = s_h + 256 * HS;     // [256][DS]   columns 27..31 zero
+    float* s_r = s_d + 256 * DS;     // [32][C]     dw partial sums of the workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < 27 * C; i += 256) s_w[i] = w[i];
+    for (int i = tid; i < 32 * C; i += 256) s_r[i] = 0.f;
     const int64_t total = (int64_t)N * H * W;
     const int64_t p = blockIdx.x * (int64_t)256 + tid;
     const bool live = p < total;
     float d[27];
 #pragma unroll
     for (int i = 0; i < 27; ++i) d[i] = 0.f;
-    int x = 0, y = 0, n = 0;
     if (live) {
-        x = (int)(p % W); y = (int)((p / W) % H); n = (int)(p / ((int64_t)W * H));
+        const int x = (int)(p % W), y = (int)((p / W) % H), n = (int)(p / ((int64_t)W * H));
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int oy = y - kh + 1;
-            if (oy < 0 || oy >= H) continue;
+            const bool oky = oy >= 0 && oy < H;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int ox = x - kw + 1;
-                if (ox < 0 || ox >= W) continue;
+                const bool ok = oky && ox >= 0 && ox < W;
 #pragma unroll
                 for (int co = 0; co < 3; ++co) {
-                    const int64_t o = (((int64_t)n * 3 + co) * H + oy) * W + ox;
+                    const int64_t o = (((int64_t)n * 3 + co) * H + (oky ? oy : 0)) * W + ((ox >= 0 && ox < W) ? ox : 0);
                     const float t = img[o];
-                    d[(co * 3 + kh) * 3 + kw] = dimg[o] * (1.f - t * t);
+                    const float g = dimg[o];
+                    d[(co * 3 + kh) * 3 + kw] = ok ? g * (1.f - t * t) : 0.f;
                 }
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 27; ++i) s_d[tid * DS + i] = d[i];
+    for (int i = 0; i < 32; ++i) s_d[tid * DS + i] = i < 27 ? d[i < 27 ? i : 0] : 0.f;
     __syncthreads();     // s_w ready
     const T* hp = h + p * C;
     T* op = dh + p * C;
@@ -98,24 +103,49 @@ __global__ __launch_bounds__(256) void img_head_bwd_kernel(const T* __restrict__
         Vec16<T> hv, o, prev;
         if (live) hv = ld16(hp + cv * V);
         if (live && accumulate) prev = ld16(op + cv * V);
+        float acc[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             s_h[tid * HS + cv * V + k] = live ? hv.get(k) : 0.f;
-            float acc = 0.f;
-#pragma unroll
-            for (int i = 0; i < 27; ++i) acc += d[i] * s_w[i * C + cv * V + k];
-            if (live && accumulate) acc += prev.get(k);
-            o.set(k, acc);
+            acc[k] = 0.f;
         }
+#pragma unroll
+        for (int i = 0; i < 27; ++i) {
+            const float4* wr = reinterpret_cast<const float4*>(&s_w[i * C + cv * V]);
+#pragma unroll
+            for (int k4 = 0; k4 < V / 4; ++k4) {
+                const float4 wv = wr[k4];
+                acc[4 * k4] += d[i] * wv.x; acc[4 * k4 + 1] += d[i] * wv.y;
+                acc[4 * k4 + 2] += d[i] * wv.z; acc[4 * k4 + 3] += d[i] * wv.w;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) o.set(k, acc[k] + ((live && accumulate) ? prev.get(k) : 0.f));
         if (live) st16(op + cv * V, o);
     }
     __syncthreads();
-    for (int o = tid; o < 27 * C; o += 256) {
-        const int i = o / C, ci = o - i * C;
-        float acc = 0.f;
-        for (int t = 0; t < 256; ++t) acc += s_d[t * DS + i] * s_h[t * HS + ci];
-        atomicAdd(&dw[o], acc);
+    // dw tile(s): rows = i (27 of 32), columns = ci; this wave contracts its own 64 pixels
+    {
+        const int rl = lane & 31, hf = lane >> 5;
+        const float* ap = s_d + (wid * 64 + hf) * DS + rl;
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) {
+            f32x16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* bp = s_h + (wid * 64 + hf) * HS + nt * 32 + rl;
+#pragma unroll 8
+            for (int kk = 0; kk < 32; ++kk)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk * DS], bp[2 * kk * HS], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                if (i < 27) atomicAdd(&s_r[i * C + nt * 32 + rl], acc[r]);
+            }
+        }
     }
+    __syncthreads();
+    for (int o = tid; o < 27 * C; o += 256) atomicAdd(&dw[o], s_r[o]);
 }
 
 // ------------------------------------------------------------------ discriminator stem
@@ -454,10 +484,10 @@ extern "C" int sba_img_head_fwd(int dtype, const void* h, const float* w, float*
 extern "C" int sba_img_head_bwd(int dtype, const void* h, const float* w, const float* img, const float* dimg,
                                 void* dh, float* dw, int N, int H, int W, int C_, int accumulate, void* stream) {
     if (!h || !w || !img || !dimg || !dh || !dw || N <= 0 || H <= 0 || W <= 0) return SBA_E_ARG;
-    if (C_ > 64) return SBA_E_ARG;       // LDS budget of the fused wgrad reduction
+    if (C_ > 64) return SBA_E_ARG;       // LDS budget of the fused wgrad contraction
     const int64_t total = (int64_t)N * H * W;
     SBA_DISPATCH(dtype, CH_SWITCH(C_, {
-        const size_t sh = sizeof(float) * (27 * C + 256 * (C + 1) + 256 * 28);
+        const size_t sh = sizeof(float) * (27 * C + 256 * ((C % 64 == 32) ? C : C + 32) + 256 * 32 + 32 * C);
         set_lds(img_head_bwd_kernel<T, C>, sh);
         hipLaunchKernelGGL((img_head_bwd_kernel<T, C>), dim3(cdiv(total, 256)), dim3(256), sh, (hipStream_t)stream,
                            (const T*)h, w, img, dimg, (T*)dh, dw, N, H, W, accumulate);
