@@ -298,53 +298,66 @@ __global__ __launch_bounds__(256) void d_stem_wgrad_kernel(const float* __restri
     }
 }
 
-// dimg[n][ci][iy][ix] = sum over the (<=4) output pixels reading it, all co.  thread = input pixel;
-// weights in LDS as [48][C] (co contiguous): per 8 channels of dpre, 6 ds_read_b128 feed 24 FMAs
+// dimg[n][ci][iy][ix] = sum over the (<=4) output pixels reading it, all co.  Workgroup = 16x16 input
+// pixels: the 10x10 output pixels they touch are staged once in LDS as dpre = dout * lrelu'(out) (f32,
+// zero outside the map, so the tap loop needs no bounds checks), instead of every thread pulling its
+// four 2*C-element rows through L1 (4x redundant).  Weights in LDS as [48][C] (co contiguous): per 4
+// channels of dpre one ds_read_b128 + three weight ds_read_b128 feed 12 FMAs.
 template <typename T>
 __global__ __launch_bounds__(256) void d_stem_dgrad_kernel(const float* __restrict__ w, const T* __restrict__ out,
                                                            const T* __restrict__ dout, float* __restrict__ dimg,
                                                            int N, int S, int C) {
     constexpr int V = Vec16<T>::N;
-    extern __shared__ __attribute__((aligned(16))) float s_w[];       // [48][C]
-    for (int i = threadIdx.x; i < 48 * C; i += blockDim.x) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int DSd = C + 4;
+    float* s_w = sm;                     // [48][C]
+    float* s_d = sm + 48 * C;            // [100][C + 4]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 48 * C; i += 256) {
         const int co = i / 48, k = i - co * 48;
         s_w[k * C + co] = w[i];
     }
-    __syncthreads();
     const int O = S / 2;
-    const int64_t total = (int64_t)N * S * S;
-    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (p >= total) return;
-    const int ix = (int)(p % S), iy = (int)((p / S) % S), n = (int)(p / ((int64_t)S * S));
+    const int tiles_x = (S + 15) / 16;
+    const int n = blockIdx.y;
+    const int ty0 = (blockIdx.x / tiles_x) * 16, tx0 = (blockIdx.x % tiles_x) * 16;
+    const int oy0 = ty0 / 2 - 1, ox0 = tx0 / 2 - 1;
+    const int cvn = C / V;
+    for (int i = tid; i < 100 * cvn; i += 256) {
+        const int t = i / cvn, c = (i - t * cvn) * V;
+        const int oy = oy0 + t / 10, ox = ox0 + t % 10;
+        const bool ok = oy >= 0 && oy < O && ox >= 0 && ox < O;
+        Vec16<T> ov, dv;
+        if (ok) {
+            const int64_t q = (((int64_t)n * O + oy) * O + ox) * C + c;
+            ov = ld16(out + q);
+            dv = ld16(dout + q);
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+            s_d[t * DSd + c + k] = ok ? dv.get(k) * (ov.get(k) > 0.f ? 1.f : 0.2f) : 0.f;
+    }
+    __syncthreads();
+    const int ly = tid >> 4, lx = tid & 15;
+    const int iy = ty0 + ly, ix = tx0 + lx;
+    if (iy >= S || ix >= S) return;
     float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int kh = ((iy + 1) & 1) + 2 * j;
-        const int ty = iy + 1 - kh;                    // = 2 * oy
-        const int oy = ty >> 1;
-        const bool oky = ty >= 0 && oy < O;
+        const int ry = ((iy + 1 - kh) >> 1) - oy0;          // row inside the staged 10x10 patch (0..9)
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2) {
             const int kw = ((ix + 1) & 1) + 2 * i2;
-            const int tx = ix + 1 - kw;
-            const int ox = tx >> 1;
-            const bool ok = oky && tx >= 0 && ox < O;
-            const int64_t q = (((int64_t)n * O + (oky ? oy : 0)) * O + ((tx >= 0 && ox < O) ? ox : 0)) * C;
-            const float* wt = &s_w[(kh * 4 + kw) * 3 * C];
-            for (int cv = 0; cv < C / V; ++cv) {
-                Vec16<T> ov = ld16(out + q + cv * V), dv = ld16(dout + q + cv * V);
-                float dp[V];
-#pragma unroll
-                for (int k = 0; k < V; ++k) dp[k] = ok ? dv.get(k) * (ov.get(k) > 0.f ? 1.f : 0.2f) : 0.f;
+            const int rx = ((ix + 1 - kw) >> 1) - ox0;
+            const float4* dp = reinterpret_cast<const float4*>(s_d + (ry * 10 + rx) * DSd);
+            const float* wt = s_w + (kh * 4 + kw) * 3 * C;
+            for (int c4 = 0; c4 < C / 4; ++c4) {
+                const float4 dv = dp[c4];
 #pragma unroll
                 for (int ci = 0; ci < 3; ++ci) {
-                    const float4* wr = reinterpret_cast<const float4*>(wt + ci * C + cv * V);
-#pragma unroll
-                    for (int k4 = 0; k4 < V / 4; ++k4) {
-                        const float4 wv = wr[k4];
-                        acc[ci] += dp[4 * k4] * wv.x + dp[4 * k4 + 1] * wv.y + dp[4 * k4 + 2] * wv.z +
-                                   dp[4 * k4 + 3] * wv.w;
-                    }
+                    const float4 wv = reinterpret_cast<const float4*>(wt + ci * C)[c4];
+                    acc[ci] += dv.x * wv.x + dv.y * wv.y + dv.z * wv.z + dv.w * wv.w;
                 }
             }
         }
@@ -525,11 +538,13 @@ extern "C" int sba_d_stem_bwd(int dtype, const float* img, const float* w, const
         });
     }
     if (dimg) {
-        const size_t sh = sizeof(float) * 48 * C;
+        const size_t sh = sizeof(float) * (48 * C + 100 * (C + 4));
+        const int tiles = ((S + 15) / 16) * ((S + 15) / 16);
+        if (N > 65535) return SBA_E_ARG;
         SBA_DISPATCH(dtype, {
             set_lds(d_stem_dgrad_kernel<T>, sh);
-            hipLaunchKernelGGL((d_stem_dgrad_kernel<T>), dim3((unsigned)(((int64_t)N * S * S + 255) / 256)), dim3(256),
-                               sh, st, w, (const T*)out, (const T*)dout, dimg, N, S, C);
+            hipLaunchKernelGGL((d_stem_dgrad_kernel<T>), dim3(tiles, N), dim3(256), sh, st, w, (const T*)out,
+                               (const T*)dout, dimg, N, S, C);
         });
     }
     return SBA_CHECK_LAUNCH();

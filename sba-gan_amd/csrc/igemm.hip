@@ -349,73 +349,19 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KG) void igemm_kernel(
     const bool lead = KG == 1 || kg == 0;       // the group that owns the summed tile
 
     if (ws) {
-        // split-K: f32 atomics into ws[m][co]; the LAST block to arrive for this (m, n) tile (a
-        // device-scope counter per tile, kept after the partial sums in the workspace) turns the sums
-        // into y / addend / bias / stats and leaves both the sums and the counter zeroed for the next
-        // user of the workspace -- no separate finish launch.
-        if (lead) {
-            const int col_s = lane & 31, rsel_s = 4 * (lane >> 5);
+        if (!lead) return;
+        // split-K partial: f32 atomics into ws[m][co]; y / addend / stats are done by splitk_finish_kernel
+        const int col_s = lane & 31, rsel_s = 4 * (lane >> 5);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int co = n_base + wn0 + j * 32 + col_s;
+        for (int j = 0; j < TN; ++j) {
+            const int co = n_base + wn0 + j * 32 + col_s;
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m_base + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel_s;
-                        if (m < M && co < g.Cout) atomicAdd(&ws[(int64_t)m * g.Cout + co], acc[i][j][r]);
-                    }
-            }
-        }
-        // The sums and the counter are device-scope atomics (performed at the coherence point, not in
-        // this XCD's L2): waiting for this wave's atomics to be acknowledged (vmcnt 0) before the
-        // barrier orders them ahead of the counter increment.  __threadfence() would also write the
-        // whole L2 back, per workgroup -- measured 30% slower end to end.
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        int* counters = reinterpret_cast<int*>(ws + (((int64_t)M * g.Cout + 3) & ~(int64_t)3));
-        const int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
-        int* s_flag = reinterpret_cast<int*>(lds_all);          // staging buffers are free by now
-        if (threadIdx.x == 0) {
-            const int prev = atomicAdd(&counters[tile_id], 1);
-            const int last = prev == (int)gridDim.z - 1;
-            if (last) counters[tile_id] = 0;
-            *s_flag = last;
-        }
-        __syncthreads();
-        if (!*s_flag) return;
-        constexpr int C4 = BN / 4;
-        for (int idx = threadIdx.x; idx < BM * C4; idx += NTT) {
-            const int row = idx / C4, c = n_base + (idx - row * C4) * 4;
-            const int m = m_base + row;
-            const int pix = rowoff[row];
-            if (pix < 0 || c >= g.Cout) continue;            // (Cout % 4 == 0 is a split-K precondition)
-            float* wp = ws + (int64_t)m * g.Cout + c;
-            float v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = atomicExch(wp + k, 0.f);
-            const int64_t o = (int64_t)pix * ycs + g.y_coff + c;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (stats) {
-                    atomicAdd(&s_stat[c - n_base + k], v[k]);
-                    atomicAdd(&s_stat[BN + c - n_base + k], v[k] * v[k]);
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m_base + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel_s;
+                    if (m < M && co < g.Cout) atomicAdd(&ws[(int64_t)m * g.Cout + co], acc[i][j][r]);
                 }
-                if (bias) v[k] += bias[c + k];
-                if (g.relu) v[k] = fmaxf(v[k], 0.f);
-                if (addend) v[k] += to_f<T>(addend[o + k]);
-                y[o + k] = from_f<T>(v[k]);
-            }
-        }
-        if (stats) {
-            __syncthreads();
-            for (int c = threadIdx.x; c < BN; c += NTT) {
-                const int co = n_base + c;
-                if (co < g.Cout) {
-                    atomicAdd(&stats[co], s_stat[c]);
-                    atomicAdd(&stats[g.Cout + co], s_stat[BN + c]);
-                }
-            }
         }
         return;
     }
@@ -1111,6 +1057,55 @@ __global__ void pool2x2_kernel(const T* __restrict__ up, T* __restrict__ dx, int
     }
 }
 
+// split-K finish: y[pix(m)][co] = ws[m][co] (+ addend), per-channel stats; thread = 4 channels x 8 rows
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ ws, T* __restrict__ y,
+                                                            const T* __restrict__ addend,
+                                                            float* __restrict__ stats, const sba_conv_geom g,
+                                                            const int M, const float* __restrict__ bias) {
+    const int ycs = g.y_cstride ? g.y_cstride : g.Cout;
+    const int cq = g.Cout / 4;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cq) return;
+    const int c = t * 4;
+    const int m0 = blockIdx.y * 8, m1 = min(m0 + 8, M);
+    const int sub = g.OHs * g.OWs;
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 rows[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {                       // all loads in flight before any use
+        const int m = m0 + r;
+        float4* wp = reinterpret_cast<float4*>(ws + (int64_t)(m < m1 ? m : m0) * g.Cout + c);
+        rows[r] = *wp;
+        if (m < m1) *wp = make_float4(0.f, 0.f, 0.f, 0.f);      // leave the workspace zero-filled for its next user
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int m = m0 + r;
+        if (m >= m1) break;
+        float v[4] = {rows[r].x, rows[r].y, rows[r].z, rows[r].w};
+        const int n = m / sub, rem = m - n * sub;
+        const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
+        const int64_t o = ((int64_t)(n * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox) * ycs + g.y_coff + c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s0[k] += v[k];
+            s1[k] += v[k] * v[k];
+            if (bias) v[k] += bias[c + k];
+            if (g.relu) v[k] = fmaxf(v[k], 0.f);
+            if (addend) v[k] += to_f<T>(addend[o + k]);
+            y[o + k] = from_f<T>(v[k]);
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            atomicAdd(&stats[c + k], s0[k]);
+            atomicAdd(&stats[g.Cout + c + k], s1[k]);
+        }
+    }
+}
+
 // ---- tile configurations and their selection --------------------------------------------
 struct IgemmCfg { int bm, bn, ks, occ; float eff; bool split; };
 // A: big square tile, B: wide-M tile for Cout = 64, C: mid tile, D: small tile (+split-K),
@@ -1136,6 +1131,10 @@ static void launch_cfg(const T* xp, const T* wp, T* yp, const T* ap, float* stat
     dim3 grid(cdiv(M, BM), cdiv(g.Cout, BN), split);
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KS, KG, PF>), grid, dim3(NT), 0, st, xp, wp, yp, ap, stats, g, M,
                        split > 1 ? ws : (float*)nullptr, sps, bias);
+    if (split > 1) {
+        dim3 fgrid(cdiv(g.Cout / 4, 256), cdiv(M, 8));
+        hipLaunchKernelGGL((splitk_finish_kernel<T>), fgrid, dim3(256), 0, st, ws, yp, ap, stats, g, M, bias);
+    }
 }
 
 static int forced_cfg() {
@@ -1154,9 +1153,7 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
     const int M = g.N * g.OHs * g.OWs;
     const T* xp = (const T*)x; const T* wp = (const T*)w; T* yp = (T*)y; const T* ap = (const T*)addend;
     const int nslabs = g.ntaps * (g.Cin / (64 / (int)sizeof(T)));
-    // workspace = f32 partial sums [M][Cout] followed by one int counter per output tile (<= 64x64 tiles)
-    const bool can_split = workspace && g.Cout % 4 == 0 && nslabs >= 16 &&
-                           (int64_t)M * g.Cout * 4 + 16 + (int64_t)cdiv(M, 64) * cdiv(g.Cout, 64) * 4 <= ws_bytes;
+    const bool can_split = workspace && g.Cout % 4 == 0 && (int64_t)M * g.Cout * 4 <= ws_bytes && nslabs >= 16;
     // Rule table calibrated with tools/bench_conv.py on the B=20 layer shapes (profiles/r01_conv_tiles.txt):
     //  - GEMM-like maps (M <= 2048): small tile D with split-K;
     //  - Cout multiple of 128: A when it yields >= 320 workgroups, E (320x128, 10 waves) when it yields
