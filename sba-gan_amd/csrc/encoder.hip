@@ -27,22 +27,40 @@ __global__ void resize_fwd_kernel(const float* __restrict__ in, float* __restric
     }
 }
 
+// adjoint of resize_fwd as a GATHER (one thread per input pixel, no atomics): input row r receives
+// (1-wy) from the output rows whose y0 == r and wy from those whose y1 == r; the candidate rows are the
+// few y with y*sc in (r-1, r+1).  The weights are recomputed with exactly the forward's arithmetic.
+__device__ __forceinline__ float resize_adj_w(int o, int r, float sc, int S) {
+    const float f = o * sc;
+    int i0 = (int)f;
+    i0 = min(i0, S - 1);
+    const int i1 = min(i0 + 1, S - 1);
+    const float wgt = f - i0;
+    return (i0 == r ? 1.f - wgt : 0.f) + (i1 == r ? wgt : 0.f);
+}
+
 __global__ void resize_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int NC, int S, int D) {
-    const int64_t total = (int64_t)NC * D * D;
+    const int64_t total = (int64_t)NC * S * S;
     const float sc = (float)(S - 1) / (float)(D - 1);
+    const float inv = 1.f / sc;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % D), y = (int)((i / D) % D);
-        const int64_t nc = i / ((int64_t)D * D);
-        const float fy = y * sc, fx = x * sc;
-        int y0 = (int)fy, x0 = (int)fx;
-        y0 = min(y0, S - 1); x0 = min(x0, S - 1);
-        const int y1 = min(y0 + 1, S - 1), x1 = min(x0 + 1, S - 1);
-        const float wy = fy - y0, wx = fx - x0, g = dout[i];
-        float* p = din + nc * S * S;
-        atomicAdd(&p[y0 * S + x0], g * (1.f - wy) * (1.f - wx));
-        atomicAdd(&p[y0 * S + x1], g * (1.f - wy) * wx);
-        atomicAdd(&p[y1 * S + x0], g * wy * (1.f - wx));
-        atomicAdd(&p[y1 * S + x1], g * wy * wx);
+        const int c = (int)(i % S), r = (int)((i / S) % S);
+        const int64_t nc = i / ((int64_t)S * S);
+        const int ylo = max(0, (int)floorf((r - 1) * inv) - 1), yhi = min(D - 1, (int)ceilf((r + 1) * inv) + 1);
+        const int xlo = max(0, (int)floorf((c - 1) * inv) - 1), xhi = min(D - 1, (int)ceilf((c + 1) * inv) + 1);
+        const float* g = dout + nc * D * D;
+        float acc = 0.f;
+        for (int y = ylo; y <= yhi; ++y) {
+            const float wy = resize_adj_w(y, r, sc, S);
+            if (wy == 0.f) continue;
+            float row = 0.f;
+            for (int x = xlo; x <= xhi; ++x) {
+                const float wx = resize_adj_w(x, c, sc, S);
+                if (wx != 0.f) row += g[y * D + x] * wx;
+            }
+            acc += wy * row;
+        }
+        din[i] = acc;
     }
 }
 
@@ -312,8 +330,7 @@ extern "C" int sba_resize_bilinear(const float* in, float* out, int NC, int S, i
     if (!backward) {
         hipLaunchKernelGGL(resize_fwd_kernel, dim3(grid_for((int64_t)NC * D * D)), dim3(256), 0, st, in, out, NC, S, D);
     } else {     // in = d(out) [NC][D][D], out = d(in) [NC][S][S]
-        if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)NC * S * S, st) != hipSuccess) return SBA_E_LAUNCH;
-        hipLaunchKernelGGL(resize_bwd_kernel, dim3(grid_for((int64_t)NC * D * D)), dim3(256), 0, st, in, out, NC, S, D);
+        hipLaunchKernelGGL(resize_bwd_kernel, dim3(grid_for((int64_t)NC * S * S)), dim3(256), 0, st, in, out, NC, S, D);
     }
     return SBA_CHECK_LAUNCH();
 }

@@ -12,6 +12,7 @@ reference's checkpoints) and is a drop-in callable: (B x 3 x S x S f32) ->
 (B x nef x 17 x 17 f32, B x nef f32).
 """
 import ctypes
+import os
 
 import torch
 
@@ -101,7 +102,7 @@ class InceptionHIP(object):
         self._convs = {}
         self._geoms = {}
         self._side, self._branch_ops, self._block = None, None, None
-        self.parallel = True
+        self.parallel = os.environ.get('SBA_ENC_PARALLEL', '1') == '1'      # Inception branches on side streams
         dev = next(enc.parameters()).device
         self.device = dev
         for name, m in enc.named_modules():
