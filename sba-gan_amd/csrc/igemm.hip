@@ -90,6 +90,107 @@ template <> struct Mma<float> {
 };
 
 // ---------------------------------------------------------------------------
+// shared tile epilogue: per-channel BatchNorm statistics, bias / ReLU, residual addend, NHWC store
+// (bf16 tiles are transposed through LDS into 16-byte row stores).  `lead` marks the threads that
+// own accumulators; rowoff[row] = output pixel index of tile row `row` (or -1).
+// ---------------------------------------------------------------------------
+template <typename T, int BM, int BN, int TM, int TN, int NTT, int STAGE_BYTES>
+__device__ __forceinline__ void tile_epilogue(f32x16_t (&acc)[TM][TN], const bool lead, unsigned char* lds_all,
+                                              const int* rowoff, float* s_stat, const int wm0, const int wn0,
+                                              const int lane, const int n_base, const int ycs,
+                                              const sba_conv_geom& g, T* __restrict__ y,
+                                              const T* __restrict__ addend, float* __restrict__ stats,
+                                              const float* __restrict__ bias) {
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col_l = lane & 31, rsel = 4 * (lane >> 5);
+    constexpr bool kStageOut = sizeof(T) == 2;       // bf16: transpose through LDS -> 16-byte row stores
+    constexpr int OROW = BN * 2 + 16;                // staged output row: BN bf16 + 16 B pad
+    static_assert(!kStageOut || BM * OROW <= STAGE_BYTES, "output tile fits in the staging buffers");
+    if (lead) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = n_base + wn0 + j * 32 + col_l;
+        float csum = 0.f, csq = 0.f;
+        const float bco = bias ? bias[co < g.Cout ? co : 0] : 0.f;      // one load per column, not per element
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
+                float v = acc[i][j][r];
+                csum += v;
+                csq += v * v;
+                if (bias) v += bco;
+                if (g.relu) v = fmaxf(v, 0.f);
+                if (kStageOut) {
+                    // (the main loop's last barrier has passed: the staging buffers are free)
+                    *reinterpret_cast<T*>(lds_all + row * OROW + (wn0 + j * 32 + col_l) * 2) = from_f<T>(v);
+                } else {
+                    const int pix = rowoff[row];
+                    if (pix >= 0 && co < g.Cout) {
+                        const int64_t o = (int64_t)pix * ycs + g.y_coff + co;
+                        if (addend) v += to_f<T>(addend[o]);
+                        y[o] = from_f<T>(v);
+                    }
+                }
+            }
+        }
+        if (stats) {
+            csum += __shfl_xor(csum, 32, 64);
+            csq += __shfl_xor(csq, 32, 64);
+            if (lane < 32) {
+                atomicAdd(&s_stat[wn0 + j * 32 + col_l], csum);
+                atomicAdd(&s_stat[BN + wn0 + j * 32 + col_l], csq);
+            }
+        }
+    }
+    }
+    if (kStageOut || stats) __syncthreads();
+    if (kStageOut) {
+        constexpr int CPRO = BN / 8;                 // 16-byte chunks per output row
+        for (int idx = threadIdx.x; idx < BM * CPRO; idx += NTT) {
+            const int row = idx / CPRO, cc = idx - row * CPRO;
+            const int pix = rowoff[row];
+            const int co = n_base + cc * 8;
+            if (pix < 0 || co >= g.Cout) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(lds_all + row * OROW + cc * 16);
+            const int64_t o = (int64_t)pix * ycs + g.y_coff + co;
+            if (co + 8 <= g.Cout) {
+                if (addend) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(addend + o);
+                    v.x = add_bf16x2(v.x, a.x);
+                    v.y = add_bf16x2(v.y, a.y);
+                    v.z = add_bf16x2(v.z, a.z);
+                    v.w = add_bf16x2(v.w, a.w);
+                }
+                *reinterpret_cast<uint4*>(y + o) = v;
+            } else {                                  // ragged Cout tail: scalar
+                // (fully unrolled with static indices: a dynamically indexed private array would be
+                // promoted to LDS and make every wave read the AQL dispatch packet for its flat id)
+                const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (co + k < g.Cout) {
+                        float f = bf2f((bf16_t)((k & 1) ? (vw[k >> 1] >> 16) : (vw[k >> 1] & 0xffffu)));
+                        if (addend) f += to_f<T>(addend[o + k]);
+                        y[o + k] = from_f<T>(f);
+                    }
+                }
+            }
+        }
+    }
+    if (stats) {
+        for (int c = threadIdx.x; c < BN; c += NTT) {
+            const int co = n_base + c;
+            if (co < g.Cout) {
+                atomicAdd(&stats[co], s_stat[c]);
+                atomicAdd(&stats[g.Cout + co], s_stat[BN + c]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // forward / data-gradient implicit GEMM
 //   rows  = output pixels of the (OHs x OWs) sub-grid, M = N*OHs*OWs
 //   cols  = output channels
@@ -366,93 +467,146 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KG) void igemm_kernel(
         return;
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int col_l = lane & 31, rsel = 4 * (lane >> 5);
-    constexpr bool kStageOut = sizeof(T) == 2;       // bf16: transpose through LDS -> 16-byte row stores
-    constexpr int OROW = BN * 2 + 16;                // staged output row: BN bf16 + 16 B pad
-    static_assert(!kStageOut || BM * OROW <= KG * GROUP_BYTES, "output tile fits in the staging buffers");
-    if (lead) {
+    tile_epilogue<T, BM, BN, TM, TN, NTT, KG * GROUP_BYTES>(acc, lead, lds_all, rowoff, s_stat, wm0, wn0, lane, n_base,
+                                                            ycs, g, y, addend, stats, bias);
+}
+
+// ---------------------------------------------------------------------------
+// 3x3 stride-1 convolution (optionally behind a nearest x2 upsample) from a HALO TILE:
+// a workgroup owns an 8 x 32 block of output pixels of one image and stages the (8+2) x (32+2)
+// input pixels it touches (6 x 18 source pixels when upsampling) in LDS ONCE; the nine taps are then
+// nine shifted views of that tile.  Compared with the generic implicit GEMM above this removes 8/9 of
+// the A-operand global->LDS traffic, all per-slab address generation and half of the barriers (one per
+// tap, for the double-buffered weight rows), so the main loop is just ds_read_b128 + MFMA.
+// Pixel / weight rows are (2*CIN + 16) bytes apart: the 16-lane phases of a ds_read_b128 then hit 16
+// distinct 4-bank groups (x2 upsampling: lane pairs share a pixel -> broadcast).
+// Waves: wave w owns tile rows 2w, 2w+1 (two 32-pixel M tiles) x all BN output channels.
+// ---------------------------------------------------------------------------
+template <int CIN, int BN, int UPS>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                           bf16_t* __restrict__ y, const bf16_t* __restrict__ addend,
+                                                           float* __restrict__ stats, const sba_conv_geom g,
+                                                           const float* __restrict__ bias) {
+    typedef bf16_t T;
+    constexpr int TH = 8, TW = 32, BM = TH * TW;
+    constexpr int PIXB = CIN * 2 + 16;
+    constexpr int HR = UPS ? TH / 2 + 2 : TH + 2, HC = UPS ? TW / 2 + 2 : TW + 2;
+    constexpr int A_BYTES = HR * HC * PIXB, B_BYTES = BN * PIXB;
+    constexpr int OUT_BYTES = BM * (BN * 2 + 16);         // the epilogue's bf16 staging tile reuses the buffers
+    constexpr int STAGE = A_BYTES + 2 * B_BYTES > OUT_BYTES ? A_BYTES + 2 * B_BYTES : OUT_BYTES;
+    constexpr int TM = 2, TN = BN / 32;
+    constexpr int CPP = CIN / 8;                          // 16-byte chunks per pixel / weight row
+    constexpr int BI = (BN * CPP + 255) / 256;            // weight chunks per thread per tap
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STAGE + BM * 4 + BN * 8];
+    unsigned char* const lA = lds;
+    unsigned char* const lB = lds + A_BYTES;
+    int* rowoff = reinterpret_cast<int*>(lds + STAGE);
+    float* s_stat = reinterpret_cast<float*>(lds + STAGE + BM * 4);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tiles_x = g.OW / TW, tiles_y = g.OH / TH;
+    const int tx_ = blockIdx.x % tiles_x, ty_ = (blockIdx.x / tiles_x) % tiles_y, n = blockIdx.x / (tiles_x * tiles_y);
+    const int oy0 = ty_ * TH, ox0 = tx_ * TW;
+    const int n_base = blockIdx.y * BN;
+    const int xcs = g.x_cstride ? g.x_cstride : g.Cin;
+    const int ycs = g.y_cstride ? g.y_cstride : g.Cout;
+    {
+        const int r = tid;                                // BM == 256 threads
+        rowoff[r] = (n * g.OH + oy0 + (r >> 5)) * g.OW + ox0 + (r & 31);
+    }
+    for (int c = tid; c < 2 * BN; c += 256) s_stat[c] = 0.f;
+
+    constexpr uint32_t OOB = 0xFFFFFFFFu;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    const uint32_t x_bytes = (uint32_t)((int64_t)g.N * g.IH * g.IW * xcs * 2);
+    const uint32_t w_bytes = (uint32_t)((int64_t)g.Cout * 9 * CIN * 2);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, w_bytes, 0x00020000);
+
+    // ---- halo tile: source rows sy0 .. sy0+HR-1, columns sx0 .. sx0+HC-1 (zeros outside the image)
+    const int sy0 = UPS ? (oy0 >> 1) - 1 : oy0 - 1, sx0 = UPS ? (ox0 >> 1) - 1 : ox0 - 1;
+    for (int idx = tid; idx < HR * HC * CPP; idx += 256) {
+        const int p = idx / CPP, ch = idx - p * CPP;
+        const int hr = p / HC, hc = p - hr * HC;
+        const int iy = sy0 + hr, ix = sx0 + hc;
+        const bool ok = iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+        const uint32_t o = ok ? (uint32_t)((n * g.IH + iy) * g.IW + ix) * (uint32_t)(xcs * 2) +
+                                    (uint32_t)(g.x_coff * 2) + (uint32_t)ch * 16u
+                              : OOB;
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xr, o, 0, 0);
+        *reinterpret_cast<uint4*>(lA + p * PIXB + ch * 16) = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+    // ---- weights of one tap: BN rows of CIN channels
+    uint4 rb[BI];
+    auto bload = [&](int tap) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int co = n_base + wn0 + j * 32 + col_l;
-        float csum = 0.f, csq = 0.f;
-        const float bco = bias ? bias[co < g.Cout ? co : 0] : 0.f;      // one load per column, not per element
+        for (int i = 0; i < BI; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / CPP, ch = idx - row * CPP;
+            const int co = n_base + row;
+            const uint32_t o = (row < BN && co < g.Cout)
+                                   ? ((uint32_t)co * 9u + (uint32_t)tap) * (uint32_t)(CIN * 2) + (uint32_t)ch * 16u
+                                   : OOB;
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wr, o, 0, 0);
+            rb[i] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    auto bstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / CPP, ch = idx - row * CPP;
+            if (row < BN) *reinterpret_cast<uint4*>(lB + buf * B_BYTES + row * PIXB + ch * 16) = rb[i];
+        }
+    };
+    bload(0);
+    bstore(0);
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    __syncthreads();
+
+    const int rl = lane & 31, hf = lane >> 5;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) bload(tap + 1);
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const unsigned char* ap[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            int hr, hc;
+            if (UPS) {
+                hr = ((2 * wid + i + ky - 1) >> 1) + 1;
+                hc = ((rl + kx - 1) >> 1) + 1;
+            } else {
+                hr = 2 * wid + i + ky;
+                hc = rl + kx;
+            }
+            ap[i] = lA + (hr * HC + hc) * PIXB + hf * 16;
+        }
+        const unsigned char* bp = lB + (tap & 1) * B_BYTES + rl * PIXB + hf * 16;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
-                float v = acc[i][j][r];
-                csum += v;
-                csq += v * v;
-                if (bias) v += bco;
-                if (g.relu) v = fmaxf(v, 0.f);
-                if (kStageOut) {
-                    // (the main loop's last barrier has passed: the staging buffers are free)
-                    *reinterpret_cast<T*>(lds_all + row * OROW + (wn0 + j * 32 + col_l) * 2) = from_f<T>(v);
-                } else {
-                    const int pix = rowoff[row];
-                    if (pix >= 0 && co < g.Cout) {
-                        const int64_t o = (int64_t)pix * ycs + g.y_coff + co;
-                        if (addend) v += to_f<T>(addend[o]);
-                        y[o] = from_f<T>(v);
-                    }
-                }
-            }
-        }
-        if (stats) {
-            csum += __shfl_xor(csum, 32, 64);
-            csq += __shfl_xor(csq, 32, 64);
-            if (lane < 32) {
-                atomicAdd(&s_stat[wn0 + j * 32 + col_l], csum);
-                atomicAdd(&s_stat[BN + wn0 + j * 32 + col_l], csq);
-            }
-        }
-    }
-    }
-    if (kStageOut || stats) __syncthreads();
-    if (kStageOut) {
-        constexpr int CPRO = BN / 8;                 // 16-byte chunks per output row
-        for (int idx = threadIdx.x; idx < BM * CPRO; idx += NTT) {
-            const int row = idx / CPRO, cc = idx - row * CPRO;
-            const int pix = rowoff[row];
-            const int co = n_base + cc * 8;
-            if (pix < 0 || co >= g.Cout) continue;
-            uint4 v = *reinterpret_cast<const uint4*>(lds_all + row * OROW + cc * 16);
-            const int64_t o = (int64_t)pix * ycs + g.y_coff + co;
-            if (co + 8 <= g.Cout) {
-                if (addend) {
-                    const uint4 a = *reinterpret_cast<const uint4*>(addend + o);
-                    v.x = add_bf16x2(v.x, a.x);
-                    v.y = add_bf16x2(v.y, a.y);
-                    v.z = add_bf16x2(v.z, a.z);
-                    v.w = add_bf16x2(v.w, a.w);
-                }
-                *reinterpret_cast<uint4*>(y + o) = v;
-            } else {                                  // ragged Cout tail: scalar
-                // (fully unrolled with static indices: a dynamically indexed private array would be
-                // promoted to LDS and make every wave read the AQL dispatch packet for its flat id)
-                const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+        for (int k16 = 0; k16 < CIN / 16; ++k16) {
+            bf16x8_t a[TM], b[TN];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (co + k < g.Cout) {
-                        float f = bf2f((bf16_t)((k & 1) ? (vw[k >> 1] >> 16) : (vw[k >> 1] & 0xffffu)));
-                        if (addend) f += to_f<T>(addend[o + k]);
-                        y[o + k] = from_f<T>(f);
-                    }
-                }
-            }
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(ap[i] + k16 * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(bp + j * 32 * PIXB + k16 * 32);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (tap + 1 < 9) bstore((tap + 1) & 1);
+        __syncthreads();
     }
-    if (stats) {
-        for (int c = threadIdx.x; c < BN; c += NTT) {
-            const int co = n_base + c;
-            if (co < g.Cout) {
-                atomicAdd(&stats[co], s_stat[c]);
-                atomicAdd(&stats[g.Cout + co], s_stat[BN + c]);
-            }
-        }
-    }
+    tile_epilogue<T, BM, BN, TM, TN, 256, STAGE>(acc, true, lds, rowoff, s_stat, wid * 64, 0, lane, n_base, ycs, g, y,
+                                                 addend, stats, bias);
 }
 
 // ---------------------------------------------------------------------------
@@ -1146,12 +1300,41 @@ static int forced_cfg() {
     return v;
 }
 
+// ---- halo-tile 3x3 path: which geometries qualify, and its launch
+static bool halo_ok(const sba_conv_geom& g) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("SBA_CONV_HALO"); enabled = (e && e[0] == '0') ? 0 : 1; }
+    if (!enabled) return false;
+    if (g.ntaps != 9 || g.sy != 1 || g.sx != 1 || g.osy != 1 || g.osx != 1 || g.ooy || g.oox) return false;
+    if (g.OHs != g.OH || g.OWs != g.OW || g.Cin != 64 || g.Cout % 64) return false;
+    if (g.OH % 8 || g.OW % 32) return false;
+    if (g.ups ? (g.IH * 2 != g.OH || g.IW * 2 != g.OW) : (g.IH != g.OH || g.IW != g.OW)) return false;
+    for (int t = 0; t < 9; ++t)
+        if (g.ty[t] != t / 3 - 1 || g.tx[t] != t % 3 - 1) return false;
+    const int64_t tiles = (int64_t)g.N * (g.OH / 8) * (g.OW / 32);
+    return tiles >= 128 && tiles <= 0x7fffffff;
+}
+
+static void launch_halo(const sba_conv_geom& g, const bf16_t* x, const bf16_t* w, bf16_t* y, const bf16_t* addend,
+                        float* stats, const float* bias, hipStream_t st) {
+    const int tiles = g.N * (g.OH / 8) * (g.OW / 32);
+    // BN = 64 for every Cout: the 128-wide variant needs 86 KB of LDS (one workgroup per CU) and
+    // measured slower; re-staging the halo tile for the second channel block is cheap
+    dim3 grid(tiles, g.Cout / 64);
+    if (g.ups) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 64, 1>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, bias);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 64, 0>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, bias);
+}
+
 template <typename T>
 int launch_igemm(const void* x, const void* w, void* y, const void* addend, float* stats,
                  const sba_conv_geom& g, void* workspace, int64_t ws_bytes, hipStream_t st,
                  const float* bias = nullptr) {
     const int M = g.N * g.OHs * g.OWs;
     const T* xp = (const T*)x; const T* wp = (const T*)w; T* yp = (T*)y; const T* ap = (const T*)addend;
+    if (sizeof(T) == 2 && halo_ok(g)) {
+        launch_halo(g, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, (const bf16_t*)addend, stats, bias, st);
+        return SBA_CHECK_LAUNCH();
+    }
     const int nslabs = g.ntaps * (g.Cin / (64 / (int)sizeof(T)));
     const bool can_split = workspace && g.Cout % 4 == 0 && (int64_t)M * g.Cout * 4 <= ws_bytes && nslabs >= 16;
     // Rule table calibrated with tools/bench_conv.py on the B=20 layer shapes (profiles/r01_conv_tiles.txt):
