@@ -111,11 +111,16 @@ int sba_pack_weights_multi(int dtype, const sba_pack_desc* descs, int ndesc, int
 int sba_pool2x2_sum(int dtype, const void* dup, void* dx, int N, int H, int W, int C, void* stream);
 
 /* ---- BatchNorm(train) + activation (model.py:43-44,62-65,543-544,553-554) ---- */
+/* BatchNorm batch statistics are accumulated in SBA_BN_STAT_SLOTS replicas ("slots") of the
+ * (sum[C], sumsq[C]) pair: a conv epilogue adds into slot (workgroup index mod SLOTS), which divides the
+ * same-address atomic contention of thousands of workgroups by SLOTS; readers add the slots up.  A
+ * statistics buffer is therefore stats[groups][SBA_BN_STAT_SLOTS][2C] floats, zeroed by the caller. */
+#define SBA_BN_STAT_SLOTS 8
 /* All BatchNorm entry points take `groups` >= 1 independent BatchNorm batches laid back to back
  * (`rows` NHWC rows each; the discriminator's real | fake passes of losses.py:139-140 share one conv
- * launch); per-group arrays are stats[groups][2C], aux[groups][4C] (= scale, shift, mean, rstd),
+ * launch); per-group arrays are stats[groups][SLOTS][2C], aux[groups][4C] (= scale, shift, mean, rstd),
  * red[groups][2C].  C a power of two <= 4096. */
-/* stats[g][0..C) += sum(y), stats[g][C..2C) += sum(y^2) (caller zeroes): only needed when the conv
+/* stats[g][slot][0..C) += sum(y), stats[g][slot][C..2C) += sum(y^2) (caller zeroes): only needed when the conv
  * epilogue could not produce them (groups > 1). */
 int sba_bn_stats(int dtype, const void* y, float* stats, int64_t rows, int groups, int C, void* stream);
 /* finalize + normalise + activation in one launch: scale/shift/mean/rstd from stats (training) or

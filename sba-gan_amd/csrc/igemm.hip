@@ -180,11 +180,13 @@ __device__ __forceinline__ void tile_epilogue(f32x16_t (&acc)[TM][TN], const boo
         }
     }
     if (stats) {
+        // one of SBA_BN_STAT_SLOTS replicas per workgroup: 1/SLOTS of the same-address atomic traffic
+        float* slot = stats + (int64_t)((blockIdx.x + blockIdx.z) & (SBA_BN_STAT_SLOTS - 1)) * 2 * g.Cout;
         for (int c = threadIdx.x; c < BN; c += NTT) {
             const int co = n_base + c;
             if (co < g.Cout) {
-                atomicAdd(&stats[co], s_stat[c]);
-                atomicAdd(&stats[g.Cout + co], s_stat[BN + c]);
+                atomicAdd(&slot[co], s_stat[c]);
+                atomicAdd(&slot[g.Cout + co], s_stat[BN + c]);
             }
         }
     }
@@ -1252,10 +1254,11 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ 
         }
     }
     if (stats) {
+        float* slot = stats + (int64_t)(blockIdx.y & (SBA_BN_STAT_SLOTS - 1)) * 2 * g.Cout;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            atomicAdd(&stats[c + k], s0[k]);
-            atomicAdd(&stats[g.Cout + c + k], s1[k]);
+            atomicAdd(&slot[c + k], s0[k]);
+            atomicAdd(&slot[g.Cout + c + k], s1[k]);
         }
     }
 }

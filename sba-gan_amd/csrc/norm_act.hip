@@ -15,8 +15,14 @@ struct BnCoef { float scale, shift, mean, rstd, var; };
 __device__ __forceinline__ BnCoef bn_coef(const float* __restrict__ stats, const float* __restrict__ gamma,
                                           const float* __restrict__ beta, int C, int c, float count, float eps) {
     BnCoef k;
-    k.mean = stats[c] / count;
-    k.var = fmaxf(stats[C + c] / count - k.mean * k.mean, 0.f);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < SBA_BN_STAT_SLOTS; ++sl) {            // add the replicas up
+        s0 += stats[sl * 2 * C + c];
+        s1 += stats[sl * 2 * C + C + c];
+    }
+    k.mean = s0 / count;
+    k.var = fmaxf(s1 / count - k.mean * k.mean, 0.f);
     k.rstd = rsqrtf(k.var + eps);
     k.scale = gamma[c] * k.rstd;
     k.shift = beta[c] - k.mean * k.scale;
@@ -29,7 +35,7 @@ template <typename T>
 __global__ void bn_stats_kernel(const T* __restrict__ y_all, float* __restrict__ stats_all, int64_t rows, int C) {
     constexpr int V = Vec16<T>::N;
     const T* y = y_all + (int64_t)blockIdx.y * rows * C;
-    float* stats = stats_all + (int64_t)blockIdx.y * 2 * C;
+    float* stats = stats_all + ((int64_t)blockIdx.y * SBA_BN_STAT_SLOTS + (blockIdx.x & (SBA_BN_STAT_SLOTS - 1))) * 2 * C;
     const int cv = C / V;
     extern __shared__ float s_acc[];                        // [2*C]
     for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.f;
@@ -78,7 +84,7 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y_all, const float* __re
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         BnCoef k;
         if (training) {
-            k = bn_coef(stats_all + (int64_t)g * 2 * C, gamma, beta, C, c, count, eps);
+            k = bn_coef(stats_all + (int64_t)g * SBA_BN_STAT_SLOTS * 2 * C, gamma, beta, C, c, count, eps);
         } else {                                            // inference: running statistics
             k.mean = rmean[c];
             k.rstd = rsqrtf(rvar[c] + eps);
@@ -93,7 +99,7 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y_all, const float* __re
         if (blockIdx.x == 0 && g == 0 && training && rmean) {
             float rm = rmean[c], rv = rvar[c];
             for (int gg = 0; gg < (int)gridDim.y; ++gg) {
-                const BnCoef q = bn_coef(stats_all + (int64_t)gg * 2 * C, gamma, beta, C, c, count, eps);
+                const BnCoef q = bn_coef(stats_all + (int64_t)gg * SBA_BN_STAT_SLOTS * 2 * C, gamma, beta, C, c, count, eps);
                 const float unb = count > 1.f ? q.var * count / (count - 1.f) : q.var;
                 rm = (1.f - momentum) * rm + momentum * q.mean;
                 rv = (1.f - momentum) * rv + momentum * unb;

@@ -337,13 +337,14 @@ def _igemm(dt, x, w, y, addend, stats, g, device):
 # raw (non-autograd) building blocks
 # ----------------------------------------------------------------------------
 def conv_forward(x, pw, kind, want_stats=True, addend=None):
-    """y = conv(x) in NHWC; returns (y, stats) with stats = per-channel (sum, sumsq)."""
+    """y = conv(x) in NHWC; returns (y, stats) with stats = BN_STAT_SLOTS replicas of the per-channel
+    (sum, sumsq) pair (add them up; see SBA_BN_STAT_SLOTS in sbagan_hip.h)."""
     _need_gpu(x)
     N, Cin, H, W = x.shape
     O = pw.param.shape[0]
     OH, OW = _conv_out_hw(kind, H, W)
     y = empty_act(N, O, OH, OW, x)
-    stats = zeros_f32(2 * O, x.device) if want_stats else None
+    stats = zeros_f32((BN_STAT_SLOTS, 2 * O), x.device) if want_stats else None
     g = _geom((kind, N, H, W, Cin, O, None))
     _igemm(_dt(x), _p(x), _p(pw.fwd(x.dtype)), _p(y), _p(addend), _p(stats), g, x.device)
     return y, stats
@@ -447,6 +448,9 @@ def wgrad_tail_stream():
     return comp
 
 
+BN_STAT_SLOTS = 8          # = SBA_BN_STAT_SLOTS (include/sbagan_hip.h)
+
+
 class BNState(object):
     """per-forward BatchNorm quantities: aux[g] = (scale, shift, mean, rstd) of group g."""
     __slots__ = ('aux', 'C', 'rows', 'groups')
@@ -485,7 +489,7 @@ def bn_act_backward(y, dout, st, bn, act, need_param_grad=True):
 def bn_stats(y, groups=1):
     """per-group, per-channel (sum, sumsq) of an NHWC tensor by a separate pass (grouped batches)."""
     N, C, H, W = y.shape
-    stats = zeros_f32((groups, 2 * C), y.device)
+    stats = zeros_f32((groups, BN_STAT_SLOTS, 2 * C), y.device)
     call('sba_bn_stats', _dt(y), _p(y), _p(stats), (N // groups) * H * W, groups, C, _stream())
     return stats
 

@@ -30,9 +30,12 @@ def main():
         g.OW = g.OWs = W
         g.sy = g.sx = g.osy = g.osx = 1
         g.ntaps = KH * KW
+        if os.environ.get('UPS') == '1':
+            g.ups = 1
+            g.IH, g.IW = H // 2, W // 2
         for t in range(KH * KW):
             g.ty[t], g.tx[t] = t // KW - KH // 2, t % KW - KW // 2
-        x = torch.randn(N, H, W, Cin, device=dev).bfloat16()
+        x = torch.randn(N, g.IH, g.IW, Cin, device=dev).bfloat16()
         w = (torch.randn(Cout, KH * KW, Cin, device=dev) / (Cin * KH * KW) ** 0.5).bfloat16()
         y = torch.empty(N, H, W, Cout, device=dev, dtype=torch.bfloat16)
         bias = torch.zeros(Cout, device=dev)
@@ -55,7 +58,7 @@ def main():
                                                                                  t[:, 6].max()))
         print('  start: p10 %.2f p50 %.2f p90 %.2f max %.2f' % tuple(np.percentile(t[:, 0], [10, 50, 90, 100])))
         d = t[:, 1:] - t[:, :-1]
-        for k, nm in enumerate(('prologue', 'main loop', 'stage->lds', 'store issue', 'store wait', 'barrier')):
+        for k, nm in enumerate(('phase 0->1', 'phase 1->2', 'phase 2->3', 'phase 3->4', 'phase 4->5', 'phase 5->6')):
             print('  %-9s: p10 %.2f p50 %.2f p90 %.2f max %.2f' % ((nm,) + tuple(np.percentile(d[:, k], [10, 50, 90, 100]))))
         print('  end  : p10 %.2f p50 %.2f p90 %.2f max %.2f' % tuple(np.percentile(t[:, 6], [10, 50, 90, 100])))
         print('  first 8 starts:', np.round(t[order[:8], 0], 2), ' last 4 starts:', np.round(t[order[-4:], 0], 2))
