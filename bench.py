@@ -91,9 +91,8 @@ def build(args, dev):
             with torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
                 f, c = enc_mod(x)
             return f.float(), c.float()
-    else:
-        from oracle import fill
-        enc = fill.StandInImageEncoder(cfg.TEXT.EMBEDDING_DIM, device=dev)
+    else:       # diagnostic only: the step without the Inception trunk (a 1x1 conv on a 17x17 average pool)
+        enc = _LightEncoder(cfg.TEXT.EMBEDDING_DIM, dev)
     step = GANStep(netG, netsD, enc, args.batch, distributed=(args.gpus > 1))
     return step
 
@@ -166,6 +165,21 @@ def cpu_baseline(args):
                       'torch CPU threads=%d' % (nsteps, args.branch, B, cores)}
 
 
+class _LightEncoder(object):
+    """--image-encoder standin: regions = conv1x1(avgpool -> 17x17), code = Linear(global mean).  Isolates the
+    cost of the hand-written Inception trunk; never the reported configuration."""
+
+    def __init__(self, nef, dev):
+        g = torch.Generator().manual_seed(7)
+        self.wr = (torch.rand((nef, 3, 1, 1), generator=g) * 1.6 - 0.8).to(dev)
+        self.wc = (torch.rand((nef, 3), generator=g) * 1.6 - 0.8).to(dev)
+        self.bc = (torch.rand((nef,), generator=g) * 0.2 - 0.1).to(dev)
+
+    def __call__(self, x):
+        import torch.nn.functional as F
+        return F.conv2d(F.adaptive_avg_pool2d(x, 17), self.wr), F.linear(x.mean((2, 3)), self.wc, self.bc)
+
+
 def supervise(args):
     """Single-GPU runs execute in a child process so that a failure of the optional hipGraph
     capture (a ROCm runtime crash cannot be caught in-process) degrades to eager launches instead
@@ -193,8 +207,12 @@ def main():
     if args.gpus > 1 or world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
+        # SBA_BENCH_BACKEND=gloo rehearses the multi-rank control flow with several ranks on ONE card
+        # (development aid; RCCL refuses duplicate devices).  The driver's runs use nccl = RCCL.
+        backend = os.environ.get('SBA_BENCH_BACKEND', 'nccl')
+        local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local)
