@@ -94,6 +94,9 @@ def build(args, dev):
     else:       # diagnostic only: the step without the Inception trunk (a 1x1 conv on a 17x17 average pool)
         enc = _LightEncoder(cfg.TEXT.EMBEDDING_DIM, dev)
     step = GANStep(netG, netsD, enc, args.batch, distributed=(args.gpus > 1))
+    step.overlap_wgrad_d = os.environ.get('SBA_OVERLAP_WGRAD_D', '0') == '1'
+    step.overlap_wgrad = os.environ.get('SBA_OVERLAP_WGRAD', '1') == '1'
+    step.concurrent_d = os.environ.get('SBA_CONCURRENT_D', '1') == '1'
     return step
 
 
@@ -246,16 +249,11 @@ def main():
     torch.cuda.synchronize()
     if args.graph and world == 1:
         try:
-            graph = torch.cuda.CUDAGraph()
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):          # warm the capture stream (per-stream workspaces exist)
-                one_step()
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-            with torch.cuda.graph(graph, stream=s):
-                out = one_step()
-            torch.cuda.synchronize()
+            from sbagan.trainer import GraphedStep
+            graph = GraphedStep(step, b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'],
+                                b['class_ids'], noise, prologue=lambda: noise.normal_(0, 1),
+                                single=os.environ.get('SBA_GRAPH_SINGLE', '0') == '1')
+            out = graph.out
             for _ in range(2):
                 graph.replay()
             torch.cuda.synchronize()

@@ -159,53 +159,45 @@ class GANStep(object):
     def _allreduce_wait(self, h):
         self.exchange.wait(h)
 
-    def step(self, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, eps=None):
-        """Returns a dict of DEVICE scalars (errD0.., errG_total, kl_loss, g_loss*, w_loss, s_loss)."""
-        netG, netsD = self.netG, self.netsD
-        out = {}
-        mark = self._mark
-        mark('start')
+    # The step is written as three phases so that a host can replay each from its own hipGraph
+    # (GraphedStep below): A = generator forward, D(i) = update of discriminator i, B = generator
+    # loss, backward, Adam + EMA.  step() composes them with the eager stream forks.
+    def phase_a(self, sent_emb, words_embs, mask, noise, eps=None):
         ops.SIDE_WGRAD = self.overlap_wgrad
         ops.ARENA.begin(self.device)          # one memset for all per-layer accumulators of the step
-        netG.ca_net.eps = eps
-        fake_imgs, _, mu, logvar = netG(noise, sent_emb, words_embs, mask)
-        mark('g_forward')
+        self.netG.ca_net.eps = eps
+        fake_imgs, _, mu, logvar = self.netG(noise, sent_emb, words_embs, mask)
+        self._ctx = (fake_imgs, mu, logvar)
+        self._out = {}
 
-        # The three discriminator updates are independent of each other (different networks, the
-        # same detached fakes): each runs on its own HIP stream so that the small launches of the
-        # 4x4 / 8x8 layers of one network fill CUs the others leave idle.  Under hipGraph capture
-        # the streams become parallel branches of the graph.
-        main = torch.cuda.current_stream()
-        streams = self._d_streams()[:len(netsD)] if self.concurrent_d else [main] * len(netsD)
-        tails = []
-        for i, netD in enumerate(netsD):
-            st = streams[i]
-            if st is not main:
-                st.wait_stream(main)
-            with torch.cuda.stream(st):
-                self.flatD[i].zero_grad()
-                errD = discriminator_loss(netD, imgs[i], fake_imgs[i], sent_emb, self.real_labels,
-                                          self.fake_labels)
-                errD.backward()
-                out['errD%d' % i] = errD.detach()
-                if st is main:
-                    ops.join_wgrads()
-                    tail = main
-                else:
-                    tail = ops.wgrad_tail_stream()
-                with torch.cuda.stream(tail):
-                    self._allreduce_wait(self._allreduce_start(self.flatD[i]))
-                    self.optD[i].step(1.0 / self.world)
-                tails.append(tail)
-        for st in streams + tails:
-            if st is not main:
-                main.wait_stream(st)
-        mark('d_steps')
+    def phase_d(self, i, imgs, sent_emb, forked):
+        """Update of discriminator i on the CURRENT stream; returns the stream its Adam step was issued
+        on (the weight-gradient companion when `forked`, see ops.wgrad_tail_stream)."""
+        fake_imgs = self._ctx[0]
+        ops.SIDE_WGRAD = self.overlap_wgrad and self.overlap_wgrad_d
+        self.flatD[i].zero_grad()
+        errD = discriminator_loss(self.netsD[i], imgs[i], fake_imgs[i], sent_emb, self.real_labels,
+                                  self.fake_labels)
+        errD.backward()
+        self._out['errD%d' % i] = errD.detach()
+        if forked:
+            tail = ops.wgrad_tail_stream()
+        else:
+            ops.join_wgrads()
+            tail = torch.cuda.current_stream()
+        with torch.cuda.stream(tail):
+            self._allreduce_wait(self._allreduce_start(self.flatD[i]))
+            self.optD[i].step(1.0 / self.world)
+        ops.SIDE_WGRAD = self.overlap_wgrad
+        return tail
 
+    def phase_b(self, sent_emb, words_embs, cap_lens, class_ids):
+        fake_imgs, mu, logvar = self._ctx
+        mark = self._mark
         for p in self._d_params:
             p.requires_grad_(False)
         self.flatG.zero_grad()
-        errG_total, logs = generator_loss(netsD, self.image_encoder, fake_imgs, self.real_labels, words_embs,
+        errG_total, logs = generator_loss(self.netsD, self.image_encoder, fake_imgs, self.real_labels, words_embs,
                                           sent_emb, self.match_labels, cap_lens, class_ids,
                                           streams=self._d_streams() if self.concurrent_d else None)
         kl = KL_loss(mu, logvar)
@@ -220,13 +212,40 @@ class GANStep(object):
         self._allreduce_wait(h)
         self.optG.step(1.0 / self.world)
         mark('g_adam')
+        out = self._out
         out['errG_total'] = errG_total.detach()
         out['kl_loss'] = kl.detach()
         out.update(logs)
         self.fake_imgs = [f.detach() for f in fake_imgs]
+        self._ctx = None
         ops.ARENA.end()
         ops.SIDE_WGRAD = False
         return out
+
+    def step(self, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, eps=None):
+        """Returns a dict of DEVICE scalars (errD0.., errG_total, kl_loss, g_loss*, w_loss, s_loss)."""
+        mark = self._mark
+        mark('start')
+        self.phase_a(sent_emb, words_embs, mask, noise, eps)
+        mark('g_forward')
+        # The three discriminator updates are independent of each other (different networks, the
+        # same detached fakes): each runs on its own HIP stream so that the small launches of the
+        # 4x4 / 8x8 layers of one network fill CUs the others leave idle.
+        main = torch.cuda.current_stream()
+        nD = len(self.netsD)
+        streams = self._d_streams()[:nD] if self.concurrent_d else [main] * nD
+        tails = []
+        for i in range(nD):
+            st = streams[i]
+            if st is not main:
+                st.wait_stream(main)
+            with torch.cuda.stream(st):
+                tails.append(self.phase_d(i, imgs, sent_emb, forked=st is not main))
+        for st in streams + tails:
+            if st is not main:
+                main.wait_stream(st)
+        mark('d_steps')
+        return self.phase_b(sent_emb, words_embs, cap_lens, class_ids)
 
     phase_events = None      # set to [] to record (name, cuda event) pairs per step (bench.py --phases)
 
@@ -238,6 +257,8 @@ class GANStep(object):
 
     concurrent_d = True
     overlap_wgrad = True
+    overlap_wgrad_d = False      # companion streams inside the (already concurrent) discriminator updates cost
+                                 # 1.5 ms under hipGraph replay: ROCm 7.2 runs graph branches nearly serially
 
     def _d_streams(self):
         if getattr(self, '_streams', None) is None:
@@ -246,3 +267,65 @@ class GANStep(object):
 
     def grad_norm(self, flat):
         return flat.grad.double().norm()
+
+
+class GraphedStep(object):
+    """GANStep replayed from captured hipGraphs: one graph for the generator forward, one PER
+    DISCRIMINATOR update -- replayed concurrently, each on its own stream -- and one for the generator
+    loss / backward / Adam.  (A single captured graph of the whole step runs its discriminator branches
+    almost back to back on ROCm 7.2: measured 8.5 ms for the three updates against ~4.5 ms here.)
+    Inputs are static tensors; `prologue` (e.g. drawing the noise in place) is captured with phase A.
+    Call after a few eager steps on the same GANStep (per-stream workspaces and packed buffers exist)."""
+
+    def __init__(self, gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, prologue=None,
+                 single=False):
+        self.gan = gan
+        self.single = single
+        dev = gan.device
+        nD = len(gan.netsD)
+        self.cap = torch.cuda.Stream(device=dev)
+        self.dstreams = gan._d_streams()[:nD]
+
+        def eager_on(stream):
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                if prologue is not None:
+                    prologue()
+                gan.step(imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise)
+            torch.cuda.current_stream().wait_stream(stream)
+        eager_on(self.cap)                       # warm the capture stream (its split-K workspace)
+        torch.cuda.synchronize()
+        self.gA, self.gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.gD = [torch.cuda.CUDAGraph() for _ in range(nD)]
+        if single:       # the whole step as ONE graph, discriminator updates as forked branches
+            with torch.cuda.graph(self.gA, stream=self.cap):
+                if prologue is not None:
+                    prologue()
+                self.out = gan.step(imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise)
+            torch.cuda.synchronize()
+            return
+        with torch.cuda.graph(self.gA, stream=self.cap):
+            if prologue is not None:
+                prologue()
+            gan.phase_a(sent_emb, words_embs, mask, noise)
+        for i in range(nD):
+            with torch.cuda.graph(self.gD[i], stream=self.dstreams[i]):
+                gan.phase_d(i, imgs, sent_emb, forked=False)
+        with torch.cuda.graph(self.gB, stream=self.cap):
+            self.out = gan.phase_b(sent_emb, words_embs, cap_lens, class_ids)
+        torch.cuda.synchronize()
+
+    def replay(self):
+        main = torch.cuda.current_stream()
+        self.gA.replay()
+        if self.single:
+            return self.out
+        for i, st in enumerate(self.dstreams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                self.gD[i].replay()
+        for st in self.dstreams:
+            main.wait_stream(st)
+        self.gB.replay()
+        return self.out
+
