@@ -384,6 +384,9 @@ __global__ __launch_bounds__(256) void logits_fwd_kernel(const T* __restrict__ h
     if (threadIdx.x == 0) prob[b] = 1.f / (1.f + expf(-(acc + bias[0])));
 }
 
+// blockIdx.y = chunk of LB samples: the per-sample loop was a chain of dependent 16-byte loads
+// (15 us for a 160 KB problem); LB independent samples per thread, weight gradient by f32 atomics
+constexpr int LOGITS_LB = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void logits_bwd_kernel(const T* __restrict__ h, const float* __restrict__ w,
                                                          const float* __restrict__ prob,
@@ -391,36 +394,46 @@ __global__ __launch_bounds__(256) void logits_bwd_kernel(const T* __restrict__ h
                                                          float* __restrict__ dw, float* __restrict__ dbias, int B,
                                                          int K, int accumulate) {
     constexpr int V = Vec16<T>::N;
-    extern __shared__ float s_dl[];      // [B]
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        const float p = prob[b];
-        s_dl[b] = dprob[b] * p * (1.f - p);
+    const int b0 = blockIdx.y * LOGITS_LB;
+    float dl[LOGITS_LB];
+#pragma unroll
+    for (int j = 0; j < LOGITS_LB; ++j) {
+        const int b = b0 + j;
+        const float p = b < B ? prob[b] : 0.f;
+        dl[j] = b < B ? dprob[b] * p * (1.f - p) : 0.f;
     }
-    __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x == 0 && dbias) {
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s += s_dl[b];
-        dbias[0] += s;
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < LOGITS_LB; ++j) sacc += dl[j];
+        atomicAdd(dbias, sacc);
     }
     const int k = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (k >= K) return;
     float wv[V], gw[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) { wv[i] = w[k + i]; gw[i] = 0.f; }
-    for (int b = 0; b < B; ++b) {
-        const float dl = s_dl[b];
-        Vec16<T> hv = ld16(h + (int64_t)b * K + k), o;
-        if (accumulate) o = ld16(dh + (int64_t)b * K + k);
+    Vec16<T> hv[LOGITS_LB], ov[LOGITS_LB];
+#pragma unroll
+    for (int j = 0; j < LOGITS_LB; ++j) {
+        const int b = b0 + j < B ? b0 + j : b0;
+        hv[j] = ld16(h + (int64_t)b * K + k);
+        if (accumulate) ov[j] = ld16(dh + (int64_t)b * K + k);
+    }
+#pragma unroll
+    for (int j = 0; j < LOGITS_LB; ++j) {
+        if (b0 + j >= B) break;
+        Vec16<T> o;
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            gw[i] += dl * hv.get(i);
-            o.set(i, dl * wv[i] + (accumulate ? o.get(i) : 0.f));
+            gw[i] += dl[j] * hv[j].get(i);
+            o.set(i, dl[j] * wv[i] + (accumulate ? ov[j].get(i) : 0.f));
         }
-        st16(dh + (int64_t)b * K + k, o);
+        st16(dh + (int64_t)(b0 + j) * K + k, o);
     }
     if (dw) {
 #pragma unroll
-        for (int i = 0; i < V; ++i) dw[k + i] += gw[i];
+        for (int i = 0; i < V; ++i) atomicAdd(&dw[k + i], gw[i]);
     }
 }
 
@@ -562,8 +575,8 @@ extern "C" int sba_logits_bwd(int dtype, const void* h, const float* w, const fl
                               void* dh, float* dw, float* dbias, int B, int K, int accumulate, void* stream) {
     if (!h || !w || !prob || !dprob || !dh || B <= 0 || B > 4096 || K <= 0 || K % 8) return SBA_E_ARG;
     const int V = dtype == SBA_BF16 ? 8 : 4;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((logits_bwd_kernel<T>), dim3(cdiv(K / V, 256)), dim3(256),
-                                           sizeof(float) * B, (hipStream_t)stream, (const T*)h, w, prob, dprob,
+    SBA_DISPATCH(dtype, hipLaunchKernelGGL((logits_bwd_kernel<T>), dim3(cdiv(K / V, 256), cdiv(B, LOGITS_LB)), dim3(256),
+                                           0, (hipStream_t)stream, (const T*)h, w, prob, dprob,
                                            (T*)dh, dw, dbias, B, K, accumulate));
     return SBA_CHECK_LAUNCH();
 }

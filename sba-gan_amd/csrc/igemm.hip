@@ -1271,10 +1271,11 @@ struct IgemmCfg { int bm, bn, ks, occ; float eff; bool split; };
 // G: the small tile with three stages of loads in flight
 // H: the small tile with two in-workgroup K-groups (8 waves = 2 per SIMD, so that one wave's
 //    ds_read -> MFMA -> barrier chain overlaps the other's)
-static const IgemmCfg kCfg[8] = {
+// I: 32 x 64 tile, two waves: twice the workgroups of D for latency-bound layers with few tiles
+static const IgemmCfg kCfg[9] = {
     {128, 128, 1, 3, 1.00f, false}, {256, 64, 1, 3, 1.00f, false}, {128, 64, 2, 2, 0.80f, false},
     {64, 64, 2, 3, 0.50f, true},    {320, 128, 2, 1, 0.90f, true},  {64, 64, 1, 1, 0.50f, true},
-    {64, 64, 2, 2, 0.50f, true},    {64, 64, 2, 1, 0.50f, true}};
+    {64, 64, 2, 2, 0.50f, true},    {64, 64, 2, 1, 0.50f, true},    {32, 64, 2, 4, 0.40f, true}};
 
 template <typename T, int BM, int BN, int WM, int WN, int KS, int KG = 1, int PF = 1>
 static void launch_cfg(const T* xp, const T* wp, T* yp, const T* ap, float* stats, const sba_conv_geom& g, int M,
@@ -1298,7 +1299,7 @@ static int forced_cfg() {
     static int v = -2;
     if (v == -2) {
         const char* e = getenv("SBA_IGEMM_CFG");       // tuning aid only: A..E
-        v = (e && e[0] >= 'A' && e[0] <= 'H') ? e[0] - 'A' : -1;
+        v = (e && e[0] >= 'A' && e[0] <= 'I') ? e[0] - 'A' : -1;
     }
     return v;
 }
@@ -1391,6 +1392,7 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
         case 5: launch_cfg<T, 64, 64, 32, 32, 1, 4>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
         case 6: launch_cfg<T, 64, 64, 32, 32, 2, 1, 3>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
         case 7: launch_cfg<T, 64, 64, 32, 32, 2, 2, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
+        case 8: launch_cfg<T, 32, 64, 32, 32, 2, 1, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
         default: launch_cfg<T, 320, 128, 64, 64, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
     }
     return SBA_CHECK_LAUNCH();
