@@ -130,8 +130,17 @@ def measure_dominant_kernel(args, dev):
     achieved = flops / (ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.dtype]
     kname = 'conv3x3_halo_kernel<64,64,ups>' if (args.dtype == 'bf16' and C == 64) else 'igemm_kernel<%s>' % args.dtype
+    # HBM traffic per launch: rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes) of
+    # tools/pmc_dominant.py, committed under profiles/ (cannot be collected from inside this process)
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_dominant_kernel.json')
+    if args.dtype == 'bf16' and args.branch == 3 and B == 20 and os.path.exists(pmc):
+        try:
+            traffic = int(json.load(open(pmc))['traffic_bytes_per_launch'])
+        except (KeyError, ValueError):
+            traffic = None
     return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
-            'frac': round(achieved / peak, 4), 'traffic': None,
+            'frac': round(achieved / peak, 4), 'traffic': traffic,
             'kernel': '%s upBlock conv3x3 %d->64 @%dpx B=%d (+BN statistics epilogue)' % (kname, C, S, B),
             'kernel_ms': round(ms, 4), 'algorithmic_gflop_per_launch': round(flops / 1e9, 2)}
 
