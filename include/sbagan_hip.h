@@ -75,10 +75,12 @@ int sba_conv_igemm(int dtype, const void* x, const void* w, void* y, const void*
                    float* stats, const sba_conv_geom* g, void* workspace, int64_t workspace_bytes,
                    void* stream);
 /* same with a per-output-channel f32 bias (may be NULL) added before the optional ReLU of g->relu
- * (frozen conv + folded BatchNorm(eval) + ReLU of the image encoder, model.py:170-199). */
+ * (frozen conv + folded BatchNorm(eval) + ReLU of the image encoder, model.py:170-199), and an optional
+ * relu_mask tensor laid out like y: after the addend, outputs are zeroed where relu_mask <= 0 -- used by
+ * the data-gradient that completes d(loss)/d(t) to apply the backward of the ReLU that produced t. */
 int sba_conv_igemm_bias(int dtype, const void* x, const void* w, void* y, const void* addend,
-                        float* stats, const float* bias, const sba_conv_geom* g, void* workspace,
-                        int64_t workspace_bytes, void* stream);
+                        float* stats, const float* bias, const void* relu_mask, const sba_conv_geom* g,
+                        void* workspace, int64_t workspace_bytes, void* stream);
 /* dw[co][t][ci] += sum_pixel dy[pixel][co] * x[gather(pixel,t)][ci]   (f32 accumulate/output).
  * ksplit > 1 splits the pixel range over that many workgroups (atomic accumulation). */
 int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* dw, const sba_conv_geom* g,

@@ -32,6 +32,17 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
 // ---------------------------------------------------------------------------
 // MFMA over one 64-byte K slab held in LDS as rows of ROWB bytes
 // ---------------------------------------------------------------------------
+// optional epilogue operands: per-channel bias, and a ReLU mask source (same layout as y): outputs are
+// zeroed where mask <= 0 -- the backward of the ReLU that produced the tensor whose gradient this is
+struct EpiX { const float* bias; const void* mask; };
+
+// keep the bf16 halves of v whose counterpart in m is > 0
+__device__ __forceinline__ uint32_t relu_mask_bf16x2(uint32_t v, uint32_t m) {
+    const uint32_t lo = ((m & 0x7fffu) != 0u && (m & 0x8000u) == 0u) ? 0x0000ffffu : 0u;
+    const uint32_t hi = ((m & 0x7fff0000u) != 0u && (m & 0x80000000u) == 0u) ? 0xffff0000u : 0u;
+    return v & (lo | hi);
+}
+
 // two packed bf16 values + two packed bf16 values, rounded back to bf16
 __device__ __forceinline__ uint32_t add_bf16x2(uint32_t p, uint32_t q) {
     const float lo = __uint_as_float(p << 16) + __uint_as_float(q << 16);
@@ -100,7 +111,9 @@ __device__ __forceinline__ void tile_epilogue(f32x16_t (&acc)[TM][TN], const boo
                                               const int lane, const int n_base, const int ycs,
                                               const sba_conv_geom& g, T* __restrict__ y,
                                               const T* __restrict__ addend, float* __restrict__ stats,
-                                              const float* __restrict__ bias) {
+                                              const EpiX ex) {
+    const float* __restrict__ bias = ex.bias;
+    const T* __restrict__ rmask = reinterpret_cast<const T*>(ex.mask);
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int col_l = lane & 31, rsel = 4 * (lane >> 5);
     constexpr bool kStageOut = sizeof(T) == 2;       // bf16: transpose through LDS -> 16-byte row stores
@@ -130,6 +143,7 @@ __device__ __forceinline__ void tile_epilogue(f32x16_t (&acc)[TM][TN], const boo
                     if (pix >= 0 && co < g.Cout) {
                         const int64_t o = (int64_t)pix * ycs + g.y_coff + co;
                         if (addend) v += to_f<T>(addend[o]);
+                        if (rmask && !(to_f<T>(rmask[o]) > 0.f)) v = 0.f;
                         y[o] = from_f<T>(v);
                     }
                 }
@@ -163,6 +177,13 @@ __device__ __forceinline__ void tile_epilogue(f32x16_t (&acc)[TM][TN], const boo
                     v.z = add_bf16x2(v.z, a.z);
                     v.w = add_bf16x2(v.w, a.w);
                 }
+                if (rmask) {
+                    const uint4 m = *reinterpret_cast<const uint4*>(rmask + o);
+                    v.x = relu_mask_bf16x2(v.x, m.x);
+                    v.y = relu_mask_bf16x2(v.y, m.y);
+                    v.z = relu_mask_bf16x2(v.z, m.z);
+                    v.w = relu_mask_bf16x2(v.w, m.w);
+                }
                 *reinterpret_cast<uint4*>(y + o) = v;
             } else {                                  // ragged Cout tail: scalar
                 // (fully unrolled with static indices: a dynamically indexed private array would be
@@ -173,6 +194,7 @@ __device__ __forceinline__ void tile_epilogue(f32x16_t (&acc)[TM][TN], const boo
                     if (co + k < g.Cout) {
                         float f = bf2f((bf16_t)((k & 1) ? (vw[k >> 1] >> 16) : (vw[k >> 1] & 0xffffu)));
                         if (addend) f += to_f<T>(addend[o + k]);
+                        if (rmask && !(to_f<T>(rmask[o + k]) > 0.f)) f = 0.f;
                         y[o + k] = from_f<T>(f);
                     }
                 }
@@ -206,7 +228,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KG) void igemm_kernel(
                                                     T* __restrict__ y, const T* __restrict__ addend,
                                                     float* __restrict__ stats, const sba_conv_geom g,
                                                     const int M, float* __restrict__ ws,
-                                                    const int slabs_per_split, const float* __restrict__ bias) {
+                                                    const int slabs_per_split, const EpiX ex) {
     constexpr int ROWB = 80;
     constexpr int KS_CH = 64 / (int)sizeof(T);   // channels per slab
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -470,7 +492,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KG) void igemm_kernel(
     }
 
     tile_epilogue<T, BM, BN, TM, TN, NTT, KG * GROUP_BYTES>(acc, lead, lds_all, rowoff, s_stat, wm0, wn0, lane, n_base,
-                                                            ycs, g, y, addend, stats, bias);
+                                                            ycs, g, y, addend, stats, ex);
 }
 
 // ---------------------------------------------------------------------------
@@ -488,7 +510,7 @@ template <int CIN, int BN, int UPS>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                            bf16_t* __restrict__ y, const bf16_t* __restrict__ addend,
                                                            float* __restrict__ stats, const sba_conv_geom g,
-                                                           const float* __restrict__ bias) {
+                                                           const EpiX ex) {
     typedef bf16_t T;
     constexpr int TH = 8, TW = 32, BM = TH * TW;
     constexpr int PIXB = CIN * 2 + 16;
@@ -608,7 +630,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const bf16_t* __restr
         __syncthreads();
     }
     tile_epilogue<T, BM, BN, TM, TN, 256, STAGE>(acc, true, lds, rowoff, s_stat, wid * 64, 0, lane, n_base, ycs, g, y,
-                                                 addend, stats, bias);
+                                                 addend, stats, ex);
 }
 
 // ---------------------------------------------------------------------------
@@ -1218,7 +1240,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ ws, T* __restrict__ y,
                                                             const T* __restrict__ addend,
                                                             float* __restrict__ stats, const sba_conv_geom g,
-                                                            const int M, const float* __restrict__ bias) {
+                                                            const int M, const EpiX ex) {
     const int ycs = g.y_cstride ? g.y_cstride : g.Cout;
     const int cq = g.Cout / 4;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1247,9 +1269,10 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ 
         for (int k = 0; k < 4; ++k) {
             s0[k] += v[k];
             s1[k] += v[k] * v[k];
-            if (bias) v[k] += bias[c + k];
+            if (ex.bias) v[k] += ex.bias[c + k];
             if (g.relu) v[k] = fmaxf(v[k], 0.f);
             if (addend) v[k] += to_f<T>(addend[o + k]);
+            if (ex.mask && !(to_f<T>(reinterpret_cast<const T*>(ex.mask)[o + k]) > 0.f)) v[k] = 0.f;
             y[o + k] = from_f<T>(v[k]);
         }
     }
@@ -1279,7 +1302,7 @@ static const IgemmCfg kCfg[9] = {
 
 template <typename T, int BM, int BN, int WM, int WN, int KS, int KG = 1, int PF = 1>
 static void launch_cfg(const T* xp, const T* wp, T* yp, const T* ap, float* stats, const sba_conv_geom& g, int M,
-                       int nslabs, int split, float* ws, hipStream_t st, const float* bias) {
+                       int nslabs, int split, float* ws, hipStream_t st, const EpiX ex) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64 * KG;
     int sps = nslabs;
     if (split > 1) {
@@ -1288,10 +1311,10 @@ static void launch_cfg(const T* xp, const T* wp, T* yp, const T* ap, float* stat
     }
     dim3 grid(cdiv(M, BM), cdiv(g.Cout, BN), split);
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KS, KG, PF>), grid, dim3(NT), 0, st, xp, wp, yp, ap, stats, g, M,
-                       split > 1 ? ws : (float*)nullptr, sps, bias);
+                       split > 1 ? ws : (float*)nullptr, sps, ex);
     if (split > 1) {
         dim3 fgrid(cdiv(g.Cout / 4, 256), cdiv(M, 8));
-        hipLaunchKernelGGL((splitk_finish_kernel<T>), fgrid, dim3(256), 0, st, ws, yp, ap, stats, g, M, bias);
+        hipLaunchKernelGGL((splitk_finish_kernel<T>), fgrid, dim3(256), 0, st, ws, yp, ap, stats, g, M, ex);
     }
 }
 
@@ -1320,23 +1343,23 @@ static bool halo_ok(const sba_conv_geom& g) {
 }
 
 static void launch_halo(const sba_conv_geom& g, const bf16_t* x, const bf16_t* w, bf16_t* y, const bf16_t* addend,
-                        float* stats, const float* bias, hipStream_t st) {
+                        float* stats, const EpiX ex, hipStream_t st) {
     const int tiles = g.N * (g.OH / 8) * (g.OW / 32);
     // BN = 64 for every Cout: the 128-wide variant needs 86 KB of LDS (one workgroup per CU) and
     // measured slower; re-staging the halo tile for the second channel block is cheap
     dim3 grid(tiles, g.Cout / 64);
-    if (g.ups) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 64, 1>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, bias);
-    else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 64, 0>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, bias);
+    if (g.ups) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 64, 1>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, ex);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 64, 0>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, ex);
 }
 
 template <typename T>
 int launch_igemm(const void* x, const void* w, void* y, const void* addend, float* stats,
                  const sba_conv_geom& g, void* workspace, int64_t ws_bytes, hipStream_t st,
-                 const float* bias = nullptr) {
+                 const EpiX ex = EpiX{nullptr, nullptr}) {
     const int M = g.N * g.OHs * g.OWs;
     const T* xp = (const T*)x; const T* wp = (const T*)w; T* yp = (T*)y; const T* ap = (const T*)addend;
     if (sizeof(T) == 2 && halo_ok(g)) {
-        launch_halo(g, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, (const bf16_t*)addend, stats, bias, st);
+        launch_halo(g, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, (const bf16_t*)addend, stats, ex, st);
         return SBA_CHECK_LAUNCH();
     }
     const int nslabs = g.ntaps * (g.Cin / (64 / (int)sizeof(T)));
@@ -1385,15 +1408,15 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
     }
     float* ws = (float*)workspace;
     switch (best) {
-        case 0: launch_cfg<T, 128, 128, 64, 64, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
-        case 1: launch_cfg<T, 256, 64, 64, 64, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
-        case 2: launch_cfg<T, 128, 64, 32, 64, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
-        case 3: launch_cfg<T, 64, 64, 32, 32, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
-        case 5: launch_cfg<T, 64, 64, 32, 32, 1, 4>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
-        case 6: launch_cfg<T, 64, 64, 32, 32, 2, 1, 3>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
-        case 7: launch_cfg<T, 64, 64, 32, 32, 2, 2, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
-        case 8: launch_cfg<T, 32, 64, 32, 32, 2, 1, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
-        default: launch_cfg<T, 320, 128, 64, 64, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, bias); break;
+        case 0: launch_cfg<T, 128, 128, 64, 64, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
+        case 1: launch_cfg<T, 256, 64, 64, 64, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
+        case 2: launch_cfg<T, 128, 64, 32, 64, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
+        case 3: launch_cfg<T, 64, 64, 32, 32, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
+        case 5: launch_cfg<T, 64, 64, 32, 32, 1, 4>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
+        case 6: launch_cfg<T, 64, 64, 32, 32, 2, 1, 3>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
+        case 7: launch_cfg<T, 64, 64, 32, 32, 2, 2, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
+        case 8: launch_cfg<T, 32, 64, 32, 32, 2, 1, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
+        default: launch_cfg<T, 320, 128, 64, 64, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
     }
     return SBA_CHECK_LAUNCH();
 }
@@ -1436,12 +1459,12 @@ extern "C" int sba_conv_igemm(int dtype, const void* x, const void* w, void* y, 
 }
 
 extern "C" int sba_conv_igemm_bias(int dtype, const void* x, const void* w, void* y, const void* addend,
-                                   float* stats, const float* bias, const sba_conv_geom* g, void* workspace,
-                                   int64_t workspace_bytes, void* stream) {
+                                   float* stats, const float* bias, const void* relu_mask,
+                                   const sba_conv_geom* g, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!x || !w || !y || !geom_ok(g, dtype)) return SBA_E_ARG;
     if (((uintptr_t)workspace & 15) != 0) return SBA_E_ARG;
     SBA_DISPATCH(dtype, return launch_igemm<T>(x, w, y, addend, stats, *g, workspace, workspace_bytes,
-                                               (hipStream_t)stream, bias));
+                                               (hipStream_t)stream, EpiX{bias, relu_mask}));
     return SBA_E_ARG;
 }
 

@@ -40,7 +40,7 @@ G = POINTER(ConvGeom)
 # name -> argtypes; mirrors include/sbagan_hip.h one to one
 SIGNATURES = {
     'sba_conv_igemm': [I, P, P, P, P, P, G, P, L, P],
-    'sba_conv_igemm_bias': [I, P, P, P, P, P, P, G, P, L, P],
+    'sba_conv_igemm_bias': [I, P, P, P, P, P, P, P, G, P, L, P],
     'sba_conv_wgrad': [I, P, P, P, G, I, P],
     'sba_pack_weight': [I, P, P, I, I, I, I, I, P],
     'sba_pack_weights_multi': [I, P, I, I, P],

@@ -130,11 +130,11 @@ class InceptionHIP(object):
     def _new(self, N, H, W, C):
         return torch.empty((N, H, W, C), dtype=self.dtype, device=self.device)
 
-    def _igemm(self, x_ptr, w, y_ptr, addend_ptr, bias, g):
+    def _igemm(self, x_ptr, w, y_ptr, addend_ptr, bias, g, mask_ptr=None):
         ws = ops.workspace(self.device)
         call('sba_conv_igemm_bias', self._dt(), x_ptr, w.data_ptr(), y_ptr, addend_ptr,
-             None, None if bias is None else bias.data_ptr(), ctypes.byref(g), ws.data_ptr(), ops.WORKSPACE_BYTES,
-             ops._stream())
+             None, None if bias is None else bias.data_ptr(), mask_ptr, ctypes.byref(g), ws.data_ptr(),
+             ops.WORKSPACE_BYTES, ops._stream())
 
     def conv(self, name, x, out=None):
         """y = relu(conv(x) + bias) written to `out` (an _Act slice) or a new tensor."""
@@ -151,10 +151,19 @@ class InceptionHIP(object):
                   yco=out.coff, relu=1 if L.relu else 0)
         self._igemm(x.t.data_ptr(), L.w_fwd, out.t.data_ptr(), None, L.bias, g)
         self._record(('conv', L, x, out))
+        self._consume(x)
+        if L.relu:
+            self._relu_tensors.add(id(out.t))
         return out
 
     def _record(self, op):
         (self._branch_ops if self._branch_ops is not None else self.tape).append(op)
+
+    def _consume(self, a):
+        """one more reader of tensor a.t: the backward of the LAST reader to run completes d(loss)/d(a.t)
+        and -- when it is a data-gradient conv and a.t came out of ReLU convs -- applies their ReLU mask in
+        its epilogue, so the producers skip the separate relu_bwd pass"""
+        self._readers[id(a.t)] = self._readers.get(id(a.t), 0) + 1
 
     def _grad_of(self, a):
         """gradient buffer of the tensor behind activation `a`, and whether it already holds a value"""
@@ -162,7 +171,7 @@ class InceptionHIP(object):
             key = id(a.t)
             holder = self._grads.get(key)
             if holder is None:
-                holder = [torch.empty_like(a.t), False]
+                holder = [torch.empty_like(a.t), False, False]      # gradient, holds a value, ReLU mask applied
                 self._grads[key] = holder
             a.grad = holder
         return a.grad
@@ -172,29 +181,36 @@ class InceptionHIP(object):
         assert gy[1], 'gradient of a conv output was never produced'
         N, OH, OW, Ct_o = out.shape
         dt = self._dt()
-        dpre = self._new(N, OH, OW, L.Op)
-        if L.relu:
+        if L.relu and not gy[2]:
+            dpre = self._new(N, OH, OW, L.Op)
             call('sba_relu_bwd', dt, out.t.data_ptr(), gy[0].data_ptr(), dpre.data_ptr(), N * OH * OW, L.Op, Ct_o,
                  out.coff, Ct_o, out.coff, ops._stream())
             dsrc, dcs, dco = dpre, L.Op, 0
-        else:
+        else:       # no ReLU, or its mask was already applied by the data-gradient that completed gy
             dsrc, dcs, dco = gy[0], Ct_o, out.coff
         gx = self._grad_of(x)
         _, H, W, Ct_x = x.shape
         addend = gx[0].data_ptr() if gx[1] else None
+        # last reader of x.t to run its backward: fold the ReLU mask of x.t's producers into this epilogue
+        self._readers[id(x.t)] -= 1
+        final = self._readers[id(x.t)] == 0 and id(x.t) in self._relu_tensors and x.coff == 0 and x.C == Ct_x
+        mask = x.t.data_ptr() if final else None
         if L.stride == 1:
             g = _geom(N, OH, OW, L.Op, H, W, L.Ip, L.dtaps[0], xcs=dcs, xco=dco, ycs=Ct_x, yco=x.coff)
-            self._igemm(dsrc.data_ptr(), L.w_dgrad[0], gx[0].data_ptr(), addend, None, g)
+            self._igemm(dsrc.data_ptr(), L.w_dgrad[0], gx[0].data_ptr(), addend, None, g, mask)
         else:
             for cls in range(4):
                 py, px = cls // 2, cls % 2
                 OHs, OWs = (H - py + 1) // 2, (W - px + 1) // 2
                 if OHs <= 0 or OWs <= 0 or not L.dtaps[cls]:
+                    final = False
                     continue
                 g = _geom(N, OH, OW, L.Op, H, W, L.Ip, L.dtaps[cls], OHs=OHs, OWs=OWs, osy=2, ooy=py, oox=px,
                           xcs=dcs, xco=dco, ycs=Ct_x, yco=x.coff)
-                self._igemm(dsrc.data_ptr(), L.w_dgrad[cls], gx[0].data_ptr(), addend, None, g)
+                self._igemm(dsrc.data_ptr(), L.w_dgrad[cls], gx[0].data_ptr(), addend, None, g, mask)
         gx[1] = True
+        if final:
+            gx[2] = True
 
     def maxpool(self, x, out=None):
         N, H, W, Ct = x.shape
@@ -204,6 +220,7 @@ class InceptionHIP(object):
         call('sba_maxpool3x3s2_fwd', self._dt(), x.t.data_ptr(), out.t.data_ptr(), N, H, W, x.C, Ct, x.coff,
              out.shape[3], out.coff, ops._stream())
         self._record(('maxpool', None, x, out))
+        self._consume(x)
         return out
 
     def _maxpool_bwd(self, x, out):
@@ -212,6 +229,7 @@ class InceptionHIP(object):
         call('sba_maxpool3x3s2_bwd', self._dt(), x.t.data_ptr(), gy[0].data_ptr(), gx[0].data_ptr(), N, H, W, x.C, Ct,
              x.coff, out.shape[3], out.coff, Ct, x.coff, 1 if gx[1] else 0, ops._stream())
         gx[1] = True
+        self._readers[id(x.t)] -= 1
 
     def avgpool(self, x):
         N, H, W, Ct = x.shape
@@ -219,6 +237,7 @@ class InceptionHIP(object):
         call('sba_avgpool3x3', self._dt(), x.t.data_ptr(), out.t.data_ptr(), N, H, W, x.C, Ct, x.coff, x.C, 0, 0,
              ops._stream())
         self._record(('avgpool', None, x, out))
+        self._consume(x)
         return out
 
     def _avgpool_bwd(self, x, out):
@@ -227,6 +246,7 @@ class InceptionHIP(object):
         call('sba_avgpool3x3', self._dt(), gy[0].data_ptr(), gx[0].data_ptr(), N, H, W, x.C, out.shape[3], out.coff,
              Ct, x.coff, 1 if gx[1] else 0, ops._stream())
         gx[1] = True
+        self._readers[id(x.t)] -= 1
 
     # ------------------------------------------------------------------ Inception blocks
     # The branches of a block are independent given its input: each runs on its own HIP stream
@@ -361,6 +381,7 @@ class InceptionHIP(object):
         N, _, S, _ = img.shape
         dt = self._dt()
         self.tape, self._grads = [], {}
+        self._readers, self._relu_tensors = {}, set()
         self.named = {}
         st = ops._stream()
         x299 = torch.empty((N, 3, 299, 299), dtype=torch.float32, device=self.device)
@@ -455,7 +476,9 @@ class InceptionHIP(object):
                 for k, ops_k in entry[1]:
                     if len(ops_k) > 1:
                         main.wait_stream(self._streams()[k])
-            for op in heads:
+            # pool heads first: the last accumulation into the block input is then a conv data-gradient,
+            # whose epilogue applies the input's ReLU mask
+            for op in sorted(heads, key=lambda o: 0 if o[0] != 'conv' else 1):
                 run(op)
         g0 = self._grad_of(a0)
         d299 = torch.empty_like(x299)

@@ -15,7 +15,7 @@ from sbagan._lib import ConvGeom, call  # noqa: E402
 
 if os.environ.get('BENCH_LIB'):           # experimental build of the library (tuning aid)
     _alt = ctypes.CDLL(os.path.join(ROOT, os.environ['BENCH_LIB']))
-    _alt.sba_conv_igemm_bias.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 6 + [
+    _alt.sba_conv_igemm_bias.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 7 + [
         ctypes.POINTER(ConvGeom), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
 
     def call(name, *a):    # noqa: F811
@@ -53,7 +53,7 @@ def main():
 
         def run():
             call('sba_conv_igemm_bias', 1, x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None,
-                 bias.data_ptr() if os.environ.get('BIAS', '1') == '1' else None,
+                 bias.data_ptr() if os.environ.get('BIAS', '1') == '1' else None, None,
                  ctypes.byref(g), ws.data_ptr(), ops.WORKSPACE_BYTES, st)
         for _ in range(3):
             run()

@@ -14,7 +14,7 @@ import numpy as np  # noqa: E402
 from sbagan._lib import ConvGeom  # noqa: E402
 
 lib = ctypes.CDLL(os.path.join(ROOT, 'tools', '_trace', 'libsbagan_trace.so'))
-lib.sba_conv_igemm_bias.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.POINTER(ConvGeom), ctypes.c_void_p,
+lib.sba_conv_igemm_bias.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.POINTER(ConvGeom), ctypes.c_void_p,
                                                                             ctypes.c_int64, ctypes.c_void_p]
 
 
@@ -46,7 +46,7 @@ def main():
         for _ in range(5):
             rc = lib.sba_conv_igemm_bias(1, x.data_ptr(), w.data_ptr(), y.data_ptr(), tr.data_ptr(),
                                          stats.data_ptr() if mode == 'stats' else None,
-                                         bias.data_ptr() if mode == 'bias' else None, ctypes.byref(g), ws.data_ptr(), ws.numel(), st)
+                                         bias.data_ptr() if mode == 'bias' else None, None, ctypes.byref(g), ws.data_ptr(), ws.numel(), st)
             assert rc == 0, rc
         torch.cuda.synchronize()
         t = tr.cpu().numpy().reshape(-1, 8)[:, :7]
