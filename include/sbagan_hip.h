@@ -143,6 +143,11 @@ int sba_bn_act_bwd_reduce(int dtype, const void* y, const void* dout, const floa
 int sba_bn_act_bwd_apply(int dtype, const void* y, const void* dout, const float* aux, const float* red,
                          void* dy, float* dgamma, float* dbeta, int64_t rows, int groups, int C, int act,
                          int dout_cstride, int dout_coff, void* stream);
+/* both passes in ONE launch for small maps (a workgroup owns a channel vector over all rows of a group):
+ * same results as reduce + apply; the host picks it when rows per group is at most a few thousand. */
+int sba_bn_act_bwd_fused(int dtype, const void* y, const void* dout, const float* aux, void* dy,
+                         float* dgamma, float* dbeta, int64_t rows, int groups, int C, int act,
+                         int dout_cstride, int dout_coff, void* stream);
 /* Linear(no bias)+BatchNorm1d(train)+GLU on [B][F] f32, output permuted to NHWC [B][4*4][F/2/16]
  * (INIT_STAGE_G.fc + view, model.py:353-356,372-373). */
 int sba_bn1d_glu_fwd(int dtype, const float* y, const float* gamma, const float* beta,

@@ -298,6 +298,106 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ y_all, const T* __rest
     }
 }
 
+// ---- backward of BatchNorm + activation for SMALL tensors in ONE launch (the 4x4 .. 16x16 maps of
+// the discriminator tails and the generator's first stage): a workgroup owns V channels (and, for GLU,
+// their V gate channels) over ALL rows of one group, so both the reduction and the apply pass are
+// workgroup-local -- no global accumulator, no second launch.  blockIdx.x = channel vector, .y = group.
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const T* __restrict__ y_all, const T* __restrict__ dout_all,
+                                                           const float* __restrict__ aux_all, T* __restrict__ dy_all,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           int64_t rows, int C, int dcs, int dco) {
+    constexpr int V = Vec16<T>::N;
+    constexpr int NV = ACT == SBA_ACT_GLU ? 2 : 1;          // channel vectors owned (value [+ gate])
+    __shared__ float s_red[4][2 * NV * V];
+    __shared__ float s_tot[2 * NV * V];
+    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int Co = ACT == SBA_ACT_GLU ? C / 2 : C;
+    const int c = blockIdx.x * V;                           // first owned (value) channel
+    const T* y = y_all + (int64_t)g * rows * C;
+    const T* dout = dout_all + (int64_t)g * rows * dcs;
+    T* dy = dy_all + (int64_t)g * rows * C;
+    const float* aux = aux_all + (int64_t)g * 4 * C;
+    float sc[NV][V], sh[NV][V], mn[NV][V], rs[NV][V];
+#pragma unroll
+    for (int h = 0; h < NV; ++h)
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int ch = c + h * Co + k;
+            sc[h][k] = aux[ch]; sh[h][k] = aux[C + ch]; mn[h][k] = aux[2 * C + ch]; rs[h][k] = aux[3 * C + ch];
+        }
+    float s0[NV][V], s1[NV][V];
+#pragma unroll
+    for (int h = 0; h < NV; ++h)
+#pragma unroll
+        for (int k = 0; k < V; ++k) { s0[h][k] = 0.f; s1[h][k] = 0.f; }
+    // dz of one row for the owned channels
+    auto dz_row = [&](int64_t row, float (&dz)[NV][V], float (&xh)[NV][V]) {
+        Vec16<T> a = ld16(y + row * C + c);
+        Vec16<T> d = ld16(dout + row * dcs + dco + c);
+        if (ACT == SBA_ACT_GLU) {
+            Vec16<T> gt = ld16(y + row * C + Co + c);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float n = a.get(k) * sc[0][k] + sh[0][k];
+                const float gp = gt.get(k) * sc[NV - 1][k] + sh[NV - 1][k];
+                const float sg = sigmoidf_(gp), dd = d.get(k);
+                dz[0][k] = dd * sg;
+                dz[NV - 1][k] = dd * n * sg * (1.f - sg);
+                xh[0][k] = (a.get(k) - mn[0][k]) * rs[0][k];
+                xh[NV - 1][k] = (gt.get(k) - mn[NV - 1][k]) * rs[NV - 1][k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float z = d.get(k);
+                if (ACT == SBA_ACT_LRELU) {
+                    const float n = a.get(k) * sc[0][k] + sh[0][k];
+                    z = n > 0.f ? z : LRELU_SLOPE * z;
+                }
+                dz[0][k] = z;
+                xh[0][k] = (a.get(k) - mn[0][k]) * rs[0][k];
+            }
+        }
+    };
+    for (int64_t row = tid; row < rows; row += 256) {
+        float dz[NV][V], xh[NV][V];
+        dz_row(row, dz, xh);
+#pragma unroll
+        for (int h = 0; h < NV; ++h)
+#pragma unroll
+            for (int k = 0; k < V; ++k) { s0[h][k] += dz[h][k]; s1[h][k] += dz[h][k] * xh[h][k]; }
+    }
+#pragma unroll
+    for (int h = 0; h < NV; ++h)
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float a0 = wave_sum(s0[h][k]), a1 = wave_sum(s1[h][k]);
+            if (lane == 0) { s_red[wid][(h * V + k) * 2] = a0; s_red[wid][(h * V + k) * 2 + 1] = a1; }
+        }
+    __syncthreads();
+    if (tid < 2 * NV * V) s_tot[tid] = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+    __syncthreads();
+    if (tid < NV * V && dgamma) {                           // groups accumulate into the same parameter
+        const int h = tid / V, k = tid - h * V;
+        atomicAdd(&dgamma[c + h * Co + k], s_tot[tid * 2 + 1]);
+        atomicAdd(&dbeta[c + h * Co + k], s_tot[tid * 2]);
+    }
+    const float inv = 1.f / (float)rows;
+    for (int64_t row = tid; row < rows; row += 256) {
+        float dz[NV][V], xh[NV][V];
+        dz_row(row, dz, xh);
+#pragma unroll
+        for (int h = 0; h < NV; ++h) {
+            Vec16<T> o;
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+                o.set(k, sc[h][k] * (dz[h][k] - s_tot[(h * V + k) * 2] * inv - xh[h][k] * s_tot[(h * V + k) * 2 + 1] * inv));
+            st16(dy + row * C + c + h * Co, o);
+        }
+    }
+}
+
 // ---- BatchNorm1d + GLU on [B][F] f32 with the NCHW->NHWC view permutation ----
 // feature f' in [0,F/2) pairs with gate f'+F/2; view(B, F/2/16, 4, 4): f' = c*16 + s
 template <typename T>
@@ -611,6 +711,21 @@ extern "C" int sba_bn_act_bwd_apply(int dtype, const void* y, const void* dout, 
                                                            dim3(256), sh, (hipStream_t)stream, (const T*)y,
                                                            (const T*)dout, aux, red, (T*)dy, dgamma, dbeta, rows, C,
                                                            dcs, dco)));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_bn_act_bwd_fused(int dtype, const void* y, const void* dout, const float* aux, void* dy,
+                                    float* dgamma, float* dbeta, int64_t rows, int groups, int C, int act, int dcs,
+                                    int dco, void* stream) {
+    if (!y || !dout || !aux || !dy || !bn_shape_ok(dtype, rows, groups, C, act)) return SBA_E_ARG;
+    if ((dgamma == nullptr) != (dbeta == nullptr)) return SBA_E_ARG;
+    const int Co = act == SBA_ACT_GLU ? C / 2 : C;
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    if (dcs < Co + dco || dcs % V || dco % V) return SBA_E_ARG;
+    SBA_DISPATCH(dtype, ACT_SWITCH(act, hipLaunchKernelGGL((bn_bwd_fused_kernel<T, ACT>), dim3(Co / V, groups),
+                                                           dim3(256), 0, (hipStream_t)stream, (const T*)y,
+                                                           (const T*)dout, aux, (T*)dy, dgamma, dbeta, rows, C, dcs,
+                                                           dco)));
     return SBA_CHECK_LAUNCH();
 }
 

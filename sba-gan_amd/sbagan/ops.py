@@ -471,16 +471,23 @@ def bn_act_forward(y, stats, bn, act, residual=None, groups=1):
     return out, st
 
 
+BN_FUSED_BWD_ROWS = 2560       # rows per group up to which the one-launch backward is used
+
+
 def bn_act_backward(y, dout, st, bn, act, need_param_grad=True):
     N, C, H, W = y.shape
     Co = C // 2 if act == ACT_GLU else C
-    red = zeros_f32((st.groups, 2 * C), y.device)
-    call('sba_bn_act_bwd_reduce', _dt(y), _p(y), _p(dout), _p(st.aux), _p(red), st.rows, st.groups, C, act, Co, 0,
-         _stream())
     dy = torch.empty_like(y)
     dg = db = None
     if need_param_grad:
         dg, db = param_grad(bn.weight), param_grad(bn.bias)
+    if st.rows <= BN_FUSED_BWD_ROWS:
+        call('sba_bn_act_bwd_fused', _dt(y), _p(y), _p(dout), _p(st.aux), _p(dy), _p(dg), _p(db), st.rows, st.groups,
+             C, act, Co, 0, _stream())
+        return dy
+    red = zeros_f32((st.groups, 2 * C), y.device)
+    call('sba_bn_act_bwd_reduce', _dt(y), _p(y), _p(dout), _p(st.aux), _p(red), st.rows, st.groups, C, act, Co, 0,
+         _stream())
     call('sba_bn_act_bwd_apply', _dt(y), _p(y), _p(dout), _p(st.aux), _p(red), _p(dy), _p(dg), _p(db), st.rows,
          st.groups, C, act, Co, 0, _stream())
     return dy
