@@ -143,6 +143,13 @@ int sba_bn_act_bwd_reduce(int dtype, const void* y, const void* dout, const floa
 int sba_bn_act_bwd_apply(int dtype, const void* y, const void* dout, const float* aux, const float* red,
                          void* dy, float* dgamma, float* dbeta, int64_t rows, int groups, int C, int act,
                          int dout_cstride, int dout_coff, void* stream);
+/* training-mode forward for small maps WITHOUT conv-epilogue statistics (grouped passes): batch statistics,
+ * finalize (aux, running stats per group in order, num_batches_tracked += groups) and normalise + activation
+ * in ONE launch; no residual. */
+int sba_bn_act_fwd_fused(int dtype, const void* y, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, int64_t* num_batches_tracked, float* aux, void* out, int64_t rows,
+                         int groups, int C, int act, int out_cstride, int out_coff, float eps, float momentum,
+                         void* stream);
 /* both passes in ONE launch for small maps (a workgroup owns a channel vector over all rows of a group):
  * same results as reduce + apply; the host picks it when rows per group is at most a few thousand. */
 int sba_bn_act_bwd_fused(int dtype, const void* y, const void* dout, const float* aux, void* dy,

@@ -298,6 +298,93 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ y_all, const T* __rest
     }
 }
 
+// ---- forward of BatchNorm(train) + activation for SMALL tensors whose statistics are not available from
+// a conv epilogue (grouped real|fake passes): statistics, finalize, running-stat update and normalise in
+// ONE launch.  A workgroup owns V channels (+ their V gate channels for GLU) over all rows and walks
+// the groups in order, so the running statistics see the same sequence as consecutive module calls.
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void bn_fwd_fused_kernel(const T* __restrict__ y_all, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ rmean,
+                                                           float* __restrict__ rvar, int64_t* __restrict__ nbt,
+                                                           float* __restrict__ aux_all, T* __restrict__ out_all,
+                                                           int64_t rows, int groups, int C, int out_cstride,
+                                                           int out_coff, float eps, float momentum) {
+    constexpr int V = Vec16<T>::N;
+    constexpr int NV = ACT == SBA_ACT_GLU ? 2 : 1;
+    __shared__ float s_red[4][2 * NV * V];
+    __shared__ float s_co[2 * NV * V];                      // scale, shift per owned channel
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int Co = ACT == SBA_ACT_GLU ? C / 2 : C;
+    const int c = blockIdx.x * V;
+    const float count = (float)rows;
+    if (blockIdx.x == 0 && tid == 0 && nbt) *nbt += groups;
+    for (int g = 0; g < groups; ++g) {
+        const T* y = y_all + (int64_t)g * rows * C;
+        T* out = out_all + (int64_t)g * rows * out_cstride;
+        float* aux = aux_all + (int64_t)g * 4 * C;
+        float s0[NV][V], s1[NV][V];
+#pragma unroll
+        for (int h = 0; h < NV; ++h)
+#pragma unroll
+            for (int k = 0; k < V; ++k) { s0[h][k] = 0.f; s1[h][k] = 0.f; }
+        for (int64_t row = tid; row < rows; row += 256) {
+#pragma unroll
+            for (int h = 0; h < NV; ++h) {
+                Vec16<T> a = ld16(y + row * C + c + h * Co);
+#pragma unroll
+                for (int k = 0; k < V; ++k) { const float v = a.get(k); s0[h][k] += v; s1[h][k] += v * v; }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NV; ++h)
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float a0 = wave_sum(s0[h][k]), a1 = wave_sum(s1[h][k]);
+                if (lane == 0) { s_red[wid][(h * V + k) * 2] = a0; s_red[wid][(h * V + k) * 2 + 1] = a1; }
+            }
+        __syncthreads();
+        if (tid < NV * V) {
+            const int h = tid / V, k = tid - h * V, ch = c + h * Co + k;
+            const float t0 = s_red[0][tid * 2] + s_red[1][tid * 2] + s_red[2][tid * 2] + s_red[3][tid * 2];
+            const float t1 = s_red[0][tid * 2 + 1] + s_red[1][tid * 2 + 1] + s_red[2][tid * 2 + 1] + s_red[3][tid * 2 + 1];
+            const float mean = t0 / count;
+            const float var = fmaxf(t1 / count - mean * mean, 0.f);
+            const float rstd = rsqrtf(var + eps);
+            const float scale = gamma[ch] * rstd, shift = beta[ch] - mean * scale;
+            s_co[tid * 2] = scale;
+            s_co[tid * 2 + 1] = shift;
+            aux[ch] = scale; aux[C + ch] = shift; aux[2 * C + ch] = mean; aux[3 * C + ch] = rstd;
+            if (rmean) {
+                const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+                rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * mean;
+                rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * unb;
+            }
+        }
+        __syncthreads();
+        for (int64_t row = tid; row < rows; row += 256) {
+            Vec16<T> a = ld16(y + row * C + c), o;
+            if (ACT == SBA_ACT_GLU) {
+                Vec16<T> gt = ld16(y + row * C + Co + c);
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const float n = a.get(k) * s_co[k * 2] + s_co[k * 2 + 1];
+                    const float gp = gt.get(k) * s_co[(V + k) * 2] + s_co[(V + k) * 2 + 1];
+                    o.set(k, n * sigmoidf_(gp));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    float n = a.get(k) * s_co[k * 2] + s_co[k * 2 + 1];
+                    if (ACT == SBA_ACT_LRELU) n = n > 0.f ? n : LRELU_SLOPE * n;
+                    o.set(k, n);
+                }
+            }
+            st16(out + row * out_cstride + out_coff + c, o);
+        }
+        __syncthreads();                                    // s_red / s_co reused by the next group
+    }
+}
+
 // ---- backward of BatchNorm + activation for SMALL tensors in ONE launch (the 4x4 .. 16x16 maps of
 // the discriminator tails and the generator's first stage): a workgroup owns V channels (and, for GLU,
 // their V gate channels) over ALL rows of one group, so both the reduction and the apply pass are
@@ -711,6 +798,23 @@ extern "C" int sba_bn_act_bwd_apply(int dtype, const void* y, const void* dout, 
                                                            dim3(256), sh, (hipStream_t)stream, (const T*)y,
                                                            (const T*)dout, aux, red, (T*)dy, dgamma, dbeta, rows, C,
                                                            dcs, dco)));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_bn_act_fwd_fused(int dtype, const void* y, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                    float* aux, void* out, int64_t rows, int groups, int C, int act,
+                                    int out_cstride, int out_coff, float eps, float momentum, void* stream) {
+    if (!y || !gamma || !beta || !aux || !out || !bn_shape_ok(dtype, rows, groups, C, act)) return SBA_E_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return SBA_E_ARG;
+    const int Co = act == SBA_ACT_GLU ? C / 2 : C;
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    if (out_cstride < Co + out_coff || out_cstride % V || out_coff % V) return SBA_E_ARG;
+    SBA_DISPATCH(dtype, ACT_SWITCH(act, hipLaunchKernelGGL((bn_fwd_fused_kernel<T, ACT>), dim3(Co / V), dim3(256), 0,
+                                                           (hipStream_t)stream, (const T*)y, gamma, beta,
+                                                           running_mean, running_var, num_batches_tracked, aux,
+                                                           (T*)out, rows, groups, C, out_cstride, out_coff, eps,
+                                                           momentum)));
     return SBA_CHECK_LAUNCH();
 }
 

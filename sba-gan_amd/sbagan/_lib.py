@@ -48,6 +48,7 @@ SIGNATURES = {
     'sba_bn_stats': [I, P, P, L, I, I, P],
     'sba_bn_act_fwd': [I, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, F, F, I, P],
     'sba_bn_act_bwd_reduce': [I, P, P, P, P, L, I, I, I, I, I, P],
+    'sba_bn_act_fwd_fused': [I, P, P, P, P, P, P, P, P, L, I, I, I, I, I, F, F, P],
     'sba_bn_act_bwd_fused': [I, P, P, P, P, P, P, L, I, I, I, I, I, P],
     'sba_bn_act_bwd_apply': [I, P, P, P, P, P, P, P, L, I, I, I, I, I, P],
     'sba_bn1d_glu_fwd': [I, P, P, P, P, P, P, P, P, P, I, I, F, F, P],

@@ -12,6 +12,7 @@ trainer.py:269-297); the autograd Functions therefore return None for
 parameters.
 """
 import ctypes
+import os
 
 import torch
 
@@ -471,7 +472,7 @@ def bn_act_forward(y, stats, bn, act, residual=None, groups=1):
     return out, st
 
 
-BN_FUSED_BWD_ROWS = 2560       # rows per group up to which the one-launch backward is used
+BN_FUSED_BWD_ROWS = int(os.environ.get('SBA_BN_FUSED_ROWS', '2560'))       # rows per group up to which the one-launch backward is used
 
 
 def bn_act_backward(y, dout, st, bn, act, need_param_grad=True):
@@ -491,6 +492,19 @@ def bn_act_backward(y, dout, st, bn, act, need_param_grad=True):
     call('sba_bn_act_bwd_apply', _dt(y), _p(y), _p(dout), _p(st.aux), _p(red), _p(dy), _p(dg), _p(db), st.rows,
          st.groups, C, act, Co, 0, _stream())
     return dy
+
+
+def bn_act_forward_fused(y, bn, act, groups):
+    """training-mode BatchNorm + activation of a small grouped map: statistics, finalize and normalise in one launch"""
+    N, C, H, W = y.shape
+    Co = C // 2 if act == ACT_GLU else C
+    st = BNState()
+    st.C, st.rows, st.groups = C, (N // groups) * H * W, groups
+    st.aux = torch.empty((groups, 4, C), dtype=torch.float32, device=y.device)
+    out = empty_act(N, Co, H, W, y)
+    call('sba_bn_act_fwd_fused', _dt(y), _p(y), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
+         _p(bn.num_batches_tracked), _p(st.aux), _p(out), st.rows, groups, C, act, Co, 0, BN_EPS, BN_MOMENTUM, _stream())
+    return out, st
 
 
 def bn_stats(y, groups=1):
@@ -528,6 +542,13 @@ class ConvBNActFn(torch.autograd.Function):
         else:
             assert residual is None and x.shape[0] % groups == 0
             y, _ = conv_forward(x, layer.pw, kind, want_stats=False)
+            rows_g = (y.shape[0] // groups) * y.shape[2] * y.shape[3]
+            if layer.bn.training and rows_g <= BN_FUSED_BWD_ROWS:
+                out, sts = bn_act_forward_fused(y, layer.bn, act, groups)
+                ctx.layer, ctx.kind, ctx.act, ctx.sts, ctx.groups = layer, kind, act, sts, groups
+                ctx.has_res = False
+                ctx.save_for_backward(x, y)
+                return out
             stats = bn_stats(y, groups) if layer.bn.training else None
         out, sts = bn_act_forward(y, stats, layer.bn, act, residual, groups)
         ctx.layer, ctx.kind, ctx.act, ctx.sts, ctx.groups = layer, kind, act, sts, groups
