@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -1257,6 +1258,11 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ 
         rows[r] = *wp;
         if (m < m1) *wp = make_float4(0.f, 0.f, 0.f, 0.f);      // leave the workspace zero-filled for its next user
     }
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ex.bias) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bv[k] = ex.bias[c + k];
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int m = m0 + r;
@@ -1265,16 +1271,22 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ 
         const int n = m / sub, rem = m - n * sub;
         const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
         const int64_t o = ((int64_t)(n * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox) * ycs + g.y_coff + c;
+        // 4 consecutive channels: one 8-byte (bf16) / 16-byte (f32) access for y, addend and the ReLU mask
+        typedef typename std::conditional<sizeof(T) == 2, uint2, uint4>::type V4;
+        T av[4], mv[4], ov[4];
+        if (addend) *reinterpret_cast<V4*>(av) = *reinterpret_cast<const V4*>(addend + o);
+        if (ex.mask) *reinterpret_cast<V4*>(mv) = *reinterpret_cast<const V4*>(reinterpret_cast<const T*>(ex.mask) + o);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             s0[k] += v[k];
             s1[k] += v[k] * v[k];
-            if (ex.bias) v[k] += ex.bias[c + k];
+            v[k] += bv[k];
             if (g.relu) v[k] = fmaxf(v[k], 0.f);
-            if (addend) v[k] += to_f<T>(addend[o + k]);
-            if (ex.mask && !(to_f<T>(reinterpret_cast<const T*>(ex.mask)[o + k]) > 0.f)) v[k] = 0.f;
-            y[o + k] = from_f<T>(v[k]);
+            if (addend) v[k] += to_f<T>(av[k]);
+            if (ex.mask && !(to_f<T>(mv[k]) > 0.f)) v[k] = 0.f;
+            ov[k] = from_f<T>(v[k]);
         }
+        *reinterpret_cast<V4*>(y + o) = *reinterpret_cast<const V4*>(ov);
     }
     if (stats) {
         float* slot = stats + (int64_t)(blockIdx.y & (SBA_BN_STAT_SLOTS - 1)) * 2 * g.Cout;
@@ -1478,7 +1490,9 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
     const int co_tiles = cdiv(g->Cout, 64), items = cdiv(g->Cin, 64) * g->ntaps;
     const FastDiv dsub = make_fastdiv((uint32_t)(g->OHs * g->OWs), (int64_t)M + 64);
     const FastDiv dow = make_fastdiv((uint32_t)g->OWs, (int64_t)M + 64);
-    if (M <= 2048 && co_tiles * items >= 256) {
+    static int small_m = -1;
+    if (small_m < 0) { const char* e = getenv("SBA_WGRAD_SMALL_M"); small_m = e ? atoi(e) : 12000; }
+    if (M <= small_m && co_tiles * items >= 256) {
         // GEMM-like layer: one tile per wave, all pixels (ksplit re-derived for this decomposition)
         const int total_chunks = cdiv(M, 16);
         const int wgs = co_tiles * cdiv(items, 4);

@@ -381,10 +381,16 @@ def conv_dgrad(dy, pw, kind, in_hw, addend=None):
     raise ValueError(kind)
 
 
+_KSPLIT_TARGET = int(os.environ.get('SBA_WGRAD_WGS', '640'))
+_KSPLIT_MIN_CHUNKS = int(os.environ.get('SBA_WGRAD_MIN_CHUNKS', '24'))
+
+
 def _ksplit(tiles, M):
     chunks = (M + 63) // 64
-    want = max(1, (640 + tiles - 1) // tiles)       # ~2.5 workgroups per CU ...
-    return max(1, min(want, chunks // 4 if chunks >= 8 else 1))   # ... each with >= 4 pixel chunks
+    want = max(1, (_KSPLIT_TARGET + tiles - 1) // tiles)       # ~2.5 workgroups per CU ...
+    # ... but every split adds a full copy of the tile's outputs to the f32 atomics: keep >= 24 pixel
+    # chunks (1536 pixels) of MFMA work per workgroup behind each copy
+    return max(1, min(want, chunks // _KSPLIT_MIN_CHUNKS if chunks >= 2 * _KSPLIT_MIN_CHUNKS else 1))
 
 
 def conv_wgrad(x, dy, param, kind):
