@@ -78,6 +78,24 @@ class _Conv(object):
                     self.dtaps.append([((py - kh) // 2, (px - kw) // 2) for kh, kw in sel])
 
 
+class _FusedHeads(object):
+    """The 1x1 BasicConv2d layers at the head of several branches of one Inception block read the same
+    input: ONE conv with their output channels concatenated forward, and ONE data-gradient with their
+    output-gradients concatenated along K backward (the per-branch gradients add up inside the GEMM)."""
+
+    def __init__(self, parts):
+        assert all(c.KH == 1 and c.KW == 1 and c.stride == 1 and c.relu and c.Ip == parts[0].Ip for c in parts)
+        self.parts = parts
+        self.I, self.Ip = parts[0].I, parts[0].Ip
+        self.O = self.Op = sum(c.Op for c in parts)
+        self.KH = self.KW = 1
+        self.stride, self.ph, self.pw, self.relu = 1, 0, 0, True
+        self.bias = torch.cat([c.bias for c in parts]).contiguous()
+        self.w_fwd = torch.cat([c.w_fwd for c in parts], 0).contiguous()               # [sum Op][1][Ip]
+        self.w_dgrad = [torch.cat([c.w_dgrad[0] for c in parts], 2).contiguous()]      # [Ip][1][sum Op]
+        self.dtaps = [[(0, 0)]]
+
+
 def _geom(N, IH, IW, Cin, OH, OW, Cout, taps, sy=1, OHs=None, OWs=None, osy=1, ooy=0, oox=0, xcs=0, xco=0, ycs=0,
           yco=0, relu=0):
     g = ConvGeom()
@@ -100,6 +118,7 @@ class InceptionHIP(object):
         self.dtype = dtype or ops.compute_dtype()
         self.nef = enc.nef
         self._convs = {}
+        self._fused = {}
         self._geoms = {}
         self._side, self._branch_ops, self._block = None, None, None
         self.parallel = os.environ.get('SBA_ENC_PARALLEL', '1') == '1'      # Inception branches on side streams
@@ -138,7 +157,16 @@ class InceptionHIP(object):
 
     def conv(self, name, x, out=None):
         """y = relu(conv(x) + bias) written to `out` (an _Act slice) or a new tensor."""
-        L = self._convs[name]
+        return self.conv_L(self._convs[name], x, out, name)
+
+    def fused(self, names):
+        key = tuple(names)
+        f = self._fused.get(key)
+        if f is None:
+            f = self._fused[key] = _FusedHeads([self._convs[n] for n in names])
+        return f
+
+    def conv_L(self, L, x, out=None, name='fused'):
         N, H, W, Ct = x.shape
         assert x.C == L.Ip, (name, x.C, L.Ip)
         OH = (H + 2 * L.ph - L.KH) // L.stride + 1
@@ -153,7 +181,7 @@ class InceptionHIP(object):
         self._record(('conv', L, x, out))
         self._consume(x)
         if L.relu:
-            self._relu_tensors.add(id(out.t))
+            self._relu_slices.add(self._key(out))
         return out
 
     def _record(self, op):
@@ -163,7 +191,31 @@ class InceptionHIP(object):
         """one more reader of tensor a.t: the backward of the LAST reader to run completes d(loss)/d(a.t)
         and -- when it is a data-gradient conv and a.t came out of ReLU convs -- applies their ReLU mask in
         its epilogue, so the producers skip the separate relu_bwd pass"""
-        self._readers[id(a.t)] = self._readers.get(id(a.t), 0) + 1
+        k = self._key(a)
+        self._readers[k] = self._readers.get(k, 0) + 1
+
+    @staticmethod
+    def _key(a):
+        return (id(a.t), a.coff, a.C)
+
+    @staticmethod
+    def _covered(keys, a):
+        """True when the channel range of view `a` is covered by the union of the views in `keys`"""
+        tid, lo, hi = id(a.t), a.coff, a.coff + a.C
+        for c0, c1 in sorted((c0, c0 + n) for (t, c0, n) in keys if t == tid):
+            if c0 <= lo < c1:
+                lo = c1
+        return lo >= hi
+
+    def _is_masked(self, a):
+        """the ReLU mask was already applied to every channel of view `a` of its gradient"""
+        return self._covered(self._masked, a)
+
+    def _has_grad(self, a):
+        """every channel of view `a` of the gradient tensor holds a value.  Tracked per VIEW: several views
+        of one tensor (fused-head temps, the concat proper) are written by different ops, and the first
+        write into each must not accumulate onto uninitialised memory"""
+        return self._covered(self._filled, a)
 
     def _grad_of(self, a):
         """gradient buffer of the tensor behind activation `a`, and whether it already holds a value"""
@@ -171,29 +223,31 @@ class InceptionHIP(object):
             key = id(a.t)
             holder = self._grads.get(key)
             if holder is None:
-                holder = [torch.empty_like(a.t), False, False]      # gradient, holds a value, ReLU mask applied
+                holder = [torch.empty_like(a.t)]             # gradient of the whole tensor
                 self._grads[key] = holder
             a.grad = holder
         return a.grad
 
     def _conv_bwd(self, L, x, out):
         gy = self._grad_of(out)
-        assert gy[1], 'gradient of a conv output was never produced'
+        assert self._has_grad(out), 'gradient of a conv output was never produced'
         N, OH, OW, Ct_o = out.shape
         dt = self._dt()
-        if L.relu and not gy[2]:
+        if L.relu and not self._is_masked(out):
             dpre = self._new(N, OH, OW, L.Op)
             call('sba_relu_bwd', dt, out.t.data_ptr(), gy[0].data_ptr(), dpre.data_ptr(), N * OH * OW, L.Op, Ct_o,
                  out.coff, Ct_o, out.coff, ops._stream())
             dsrc, dcs, dco = dpre, L.Op, 0
-        else:       # no ReLU, or its mask was already applied by the data-gradient that completed gy
+        else:       # no ReLU, or its mask was already applied by the data-gradient(s) that completed gy
             dsrc, dcs, dco = gy[0], Ct_o, out.coff
         gx = self._grad_of(x)
         _, H, W, Ct_x = x.shape
-        addend = gx[0].data_ptr() if gx[1] else None
-        # last reader of x.t to run its backward: fold the ReLU mask of x.t's producers into this epilogue
-        self._readers[id(x.t)] -= 1
-        final = self._readers[id(x.t)] == 0 and id(x.t) in self._relu_tensors and x.coff == 0 and x.C == Ct_x
+        addend = gx[0].data_ptr() if self._has_grad(x) else None
+        # last reader of this view of x.t to run its backward: fold the ReLU mask of its producers into
+        # this epilogue (the mask tensor is indexed exactly like the output, so slices work unchanged)
+        kx = self._key(x)
+        self._readers[kx] -= 1
+        final = self._readers[kx] == 0 and kx in self._relu_slices
         mask = x.t.data_ptr() if final else None
         if L.stride == 1:
             g = _geom(N, OH, OW, L.Op, H, W, L.Ip, L.dtaps[0], xcs=dcs, xco=dco, ycs=Ct_x, yco=x.coff)
@@ -208,9 +262,9 @@ class InceptionHIP(object):
                 g = _geom(N, OH, OW, L.Op, H, W, L.Ip, L.dtaps[cls], OHs=OHs, OWs=OWs, osy=2, ooy=py, oox=px,
                           xcs=dcs, xco=dco, ycs=Ct_x, yco=x.coff)
                 self._igemm(dsrc.data_ptr(), L.w_dgrad[cls], gx[0].data_ptr(), addend, None, g, mask)
-        gx[1] = True
+        self._filled.add(kx)
         if final:
-            gx[2] = True
+            self._masked.add(kx)
 
     def maxpool(self, x, out=None):
         N, H, W, Ct = x.shape
@@ -227,9 +281,9 @@ class InceptionHIP(object):
         gy, gx = self._grad_of(out), self._grad_of(x)
         N, H, W, Ct = x.shape
         call('sba_maxpool3x3s2_bwd', self._dt(), x.t.data_ptr(), gy[0].data_ptr(), gx[0].data_ptr(), N, H, W, x.C, Ct,
-             x.coff, out.shape[3], out.coff, Ct, x.coff, 1 if gx[1] else 0, ops._stream())
-        gx[1] = True
-        self._readers[id(x.t)] -= 1
+             x.coff, out.shape[3], out.coff, Ct, x.coff, 1 if self._has_grad(x) else 0, ops._stream())
+        self._filled.add(self._key(x))
+        self._readers[self._key(x)] -= 1
 
     def avgpool(self, x):
         N, H, W, Ct = x.shape
@@ -244,9 +298,9 @@ class InceptionHIP(object):
         gy, gx = self._grad_of(out), self._grad_of(x)
         N, H, W, Ct = x.shape
         call('sba_avgpool3x3', self._dt(), gy[0].data_ptr(), gx[0].data_ptr(), N, H, W, x.C, out.shape[3], out.coff,
-             Ct, x.coff, 1 if gx[1] else 0, ops._stream())
-        gx[1] = True
-        self._readers[id(x.t)] -= 1
+             Ct, x.coff, 1 if self._has_grad(x) else 0, ops._stream())
+        self._filled.add(self._key(x))
+        self._readers[self._key(x)] -= 1
 
     # ------------------------------------------------------------------ Inception blocks
     # The branches of a block are independent given its input: each runs on its own HIP stream
@@ -278,38 +332,60 @@ class InceptionHIP(object):
             r._block.append((self.k, r._branch_ops))
             r._branch_ops = None
 
-    def _begin_block(self):
+    def _begin_block(self, x):
         self._main = torch.cuda.current_stream()
         self._block = []
+        self._block_x = x
+        self._block_pre = []
 
-    def _end_block(self):
+    def _heads(self, names, x, ext):
+        """the fused 1x1 head convs of a block: outputs occupy channels [0, sum Op) of `ext`; returns the
+        per-branch views in the order of `names`"""
+        f = self.fused(names)
+        self._branch_ops = self._block_pre                 # recorded as a main-stream op of the block
+        self.conv_L(f, x, _Act(ext, 0, f.Op))
+        self._branch_ops = None
+        views, off = [], 0
+        for c in f.parts:
+            v = _Act(ext, off, c.Op)
+            self._relu_slices.add(self._key(v))
+            views.append(v)
+            off += c.Op
+        return views
+
+    def _end_block(self, cat_view):
         if self.parallel:
             for k, _ in self._block:
                 self._main.wait_stream(self._streams()[k])
-        self.tape.append(('block', self._block))
+        self._relu_slices.add(self._key(cat_view))          # every slice of the concat is a ReLU (or max-pool of ReLU) output
+        self.tape.append(('block', self._block, self._block_x, self._block_pre))
         self._block = None
+        return cat_view
 
+    # Layout of a block's output tensor `ext`: [temps of the fused heads | branch1x1 | other branches ...];
+    # the concat proper is the channel slice behind the temps (the next block reads it through
+    # x_cstride / x_coff), so that the fused head conv writes ONE contiguous channel range.
     def _A(self, p, x, pf):
         N, H, W, _ = x.shape
-        cat = self._new(N, H, W, 64 + 64 + 96 + pf)
-        self._begin_block()
-        with self._Branch(self, 0):
-            self.conv(p + '.branch1x1', x, _Act(cat, 0, 64))
+        names = [p + '.branch5x5_1', p + '.branch3x3dbl_1', p + '.branch1x1']
+        T = sum(self._convs[n].Op for n in names[:-1])
+        ext = self._new(N, H, W, T + 64 + 64 + 96 + pf)
+        self._begin_block(x)
+        t5, t3, _b1 = self._heads(names, x, ext)
         with self._Branch(self, 1):
-            self.conv(p + '.branch5x5_2', self.conv(p + '.branch5x5_1', x), _Act(cat, 64, 64))
+            self.conv(p + '.branch5x5_2', t5, _Act(ext, T + 64, 64))
         with self._Branch(self, 2):
-            t = self.conv(p + '.branch3x3dbl_2', self.conv(p + '.branch3x3dbl_1', x))
-            self.conv(p + '.branch3x3dbl_3', t, _Act(cat, 128, 96))
+            t = self.conv(p + '.branch3x3dbl_2', t3)
+            self.conv(p + '.branch3x3dbl_3', t, _Act(ext, T + 128, 96))
         with self._Branch(self, 3):
-            self.conv(p + '.branch_pool', self.avgpool(x), _Act(cat, 224, pf))
-        self._end_block()
-        return _Act(cat)
+            self.conv(p + '.branch_pool', self.avgpool(x), _Act(ext, T + 224, pf))
+        return self._end_block(_Act(ext, T, 64 + 64 + 96 + pf))
 
     def _B(self, p, x):
         N, H, W, _ = x.shape
         OH = (H - 3) // 2 + 1
         cat = self._new(N, OH, OH, 384 + 96 + x.C)
-        self._begin_block()
+        self._begin_block(x)
         with self._Branch(self, 0):
             self.conv(p + '.branch3x3', x, _Act(cat, 0, 384))
         with self._Branch(self, 1):
@@ -317,63 +393,75 @@ class InceptionHIP(object):
             self.conv(p + '.branch3x3dbl_3', t, _Act(cat, 384, 96))
         with self._Branch(self, 2):
             self.maxpool(x, _Act(cat, 480, x.C))
-        self._end_block()
-        return _Act(cat)
+        return self._end_block(_Act(cat))
 
     def _C(self, p, x):
         N, H, W, _ = x.shape
-        cat = self._new(N, H, W, 768)
-        self._begin_block()
-        with self._Branch(self, 0):
-            self.conv(p + '.branch1x1', x, _Act(cat, 0, 192))
+        names = [p + '.branch7x7_1', p + '.branch7x7dbl_1', p + '.branch1x1']
+        T = sum(self._convs[n].Op for n in names[:-1])
+        ext = self._new(N, H, W, T + 768)
+        self._begin_block(x)
+        t7, t7d, _b1 = self._heads(names, x, ext)
         with self._Branch(self, 1):
-            t = self.conv(p + '.branch7x7_2', self.conv(p + '.branch7x7_1', x))
-            self.conv(p + '.branch7x7_3', t, _Act(cat, 192, 192))
+            t = self.conv(p + '.branch7x7_2', t7)
+            self.conv(p + '.branch7x7_3', t, _Act(ext, T + 192, 192))
         with self._Branch(self, 2):
-            t = self.conv(p + '.branch7x7dbl_1', x)
+            t = t7d
             for k in (2, 3, 4):
                 t = self.conv(p + '.branch7x7dbl_%d' % k, t)
-            self.conv(p + '.branch7x7dbl_5', t, _Act(cat, 384, 192))
+            self.conv(p + '.branch7x7dbl_5', t, _Act(ext, T + 384, 192))
         with self._Branch(self, 3):
-            self.conv(p + '.branch_pool', self.avgpool(x), _Act(cat, 576, 192))
-        self._end_block()
-        return _Act(cat)
+            self.conv(p + '.branch_pool', self.avgpool(x), _Act(ext, T + 576, 192))
+        return self._end_block(_Act(ext, T, 768))
 
     def _D(self, p, x):
         N, H, W, _ = x.shape
         OH = (H - 3) // 2 + 1
         cat = self._new(N, OH, OH, 320 + 192 + x.C)
-        self._begin_block()
+        names = [p + '.branch3x3_1', p + '.branch7x7x3_1']
+        tmp = self._new(N, H, W, sum(self._convs[n].Op for n in names))
+        self._begin_block(x)
+        t3, t7 = self._heads(names, x, tmp)
         with self._Branch(self, 0):
-            self.conv(p + '.branch3x3_2', self.conv(p + '.branch3x3_1', x), _Act(cat, 0, 320))
+            self.conv(p + '.branch3x3_2', t3, _Act(cat, 0, 320))
         with self._Branch(self, 1):
-            t = self.conv(p + '.branch7x7x3_1', x)
+            t = t7
             for k in (2, 3):
                 t = self.conv(p + '.branch7x7x3_%d' % k, t)
             self.conv(p + '.branch7x7x3_4', t, _Act(cat, 320, 192))
         with self._Branch(self, 2):
             self.maxpool(x, _Act(cat, 512, x.C))
-        self._end_block()
-        return _Act(cat)
+        return self._end_block(_Act(cat))
 
-    def _E(self, p, x):
+    def _E(self, p, x, dense_out=False):
+        """dense_out: the concat is its own tensor (the global average pool after Mixed_7c reads it densely),
+        so only the two temp-producing heads are fused"""
         N, H, W, _ = x.shape
-        cat = self._new(N, H, W, 2048)
-        self._begin_block()
-        with self._Branch(self, 0):
-            self.conv(p + '.branch1x1', x, _Act(cat, 0, 320))
+        if dense_out:
+            names = [p + '.branch3x3_1', p + '.branch3x3dbl_1']
+            ext = self._new(N, H, W, 2048)
+            tmp = self._new(N, H, W, sum(self._convs[n].Op for n in names))
+            T = 0
+        else:
+            names = [p + '.branch3x3_1', p + '.branch3x3dbl_1', p + '.branch1x1']
+            T = sum(self._convs[n].Op for n in names[:-1])
+            ext = tmp = self._new(N, H, W, T + 2048)
+        self._begin_block(x)
+        views = self._heads(names, x, tmp)
+        t3, t3d = views[0], views[1]
+        if dense_out:
+            with self._Branch(self, 0):
+                self.conv(p + '.branch1x1', x, _Act(ext, 0, 320))
         with self._Branch(self, 1):
-            t = self.conv(p + '.branch3x3_1', x)
-            self.conv(p + '.branch3x3_2a', t, _Act(cat, 320, 384))
-            self.conv(p + '.branch3x3_2b', t, _Act(cat, 704, 384))
+            self.conv(p + '.branch3x3_2a', t3, _Act(ext, T + 320, 384))
+            self.conv(p + '.branch3x3_2b', t3, _Act(ext, T + 704, 384))
         with self._Branch(self, 2):
-            t = self.conv(p + '.branch3x3dbl_2', self.conv(p + '.branch3x3dbl_1', x))
-            self.conv(p + '.branch3x3dbl_3a', t, _Act(cat, 1088, 384))
-            self.conv(p + '.branch3x3dbl_3b', t, _Act(cat, 1472, 384))
+            t = self.conv(p + '.branch3x3dbl_2', t3d)
+            self.conv(p + '.branch3x3dbl_3a', t, _Act(ext, T + 1088, 384))
+            self.conv(p + '.branch3x3dbl_3b', t, _Act(ext, T + 1472, 384))
         with self._Branch(self, 3):
-            self.conv(p + '.branch_pool', self.avgpool(x), _Act(cat, 1856, 192))
-        self._end_block()
-        return _Act(cat)
+            self.conv(p + '.branch_pool', self.avgpool(x), _Act(ext, T + 1856, 192))
+        return self._end_block(_Act(ext, T, 2048))
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, img):
@@ -381,7 +469,7 @@ class InceptionHIP(object):
         N, _, S, _ = img.shape
         dt = self._dt()
         self.tape, self._grads = [], {}
-        self._readers, self._relu_tensors = {}, set()
+        self._readers, self._relu_slices, self._masked, self._filled = {}, set(), set(), set()
         self.named = {}
         st = ops._stream()
         x299 = torch.empty((N, 3, 299, 299), dtype=torch.float32, device=self.device)
@@ -407,7 +495,7 @@ class InceptionHIP(object):
         f = self.conv('emb_features', feat_in)                       # [N,17,17,nef_p]
         a = nm['Mixed_7a'] = self._D('Mixed_7a', a)
         a = nm['Mixed_7b'] = self._E('Mixed_7b', a)
-        a = nm['Mixed_7c'] = self._E('Mixed_7c', a)
+        a = nm['Mixed_7c'] = self._E('Mixed_7c', a, dense_out=True)
         pooled = torch.empty((N, 2048), dtype=torch.float32, device=self.device)
         call('sba_global_avgpool', dt, a.t.data_ptr(), pooled.data_ptr(), N, 64, 2048, 0, st)
         pooled_t = _Act(pooled.to(self.dtype).view(N, 1, 1, 2048))
@@ -430,12 +518,12 @@ class InceptionHIP(object):
             call('sba_layout_nhwc_nchw', dt, gf[0].data_ptr(), df.data_ptr(), N, 289, f.C, 1, st)
         else:
             gf[0].zero_()
-        gf[1] = True
+        self._filled.add(self._key(f))
         gc = self._grad_of(code)
         gc[0].zero_()
         if dcode is not None:
             gc[0].view(N, -1)[:, :self.nef] = dcode.to(self.dtype)
-        gc[1] = True
+        self._filled.add(self._key(code))
         def run(op):
             kind, L, x, out = op
             if kind == 'conv':
@@ -444,7 +532,7 @@ class InceptionHIP(object):
                     gp = self._grad_of(pooled_t)[0].view(N, 2048).float().contiguous()
                     gl = self._grad_of(last)
                     call('sba_global_avgpool', dt, gl[0].data_ptr(), gp.data_ptr(), N, 64, 2048, 1, st)
-                    gl[1] = True
+                    self._filled.add(self._key(last))
             elif kind == 'maxpool':
                 self._maxpool_bwd(x, out)
             else:
@@ -454,31 +542,34 @@ class InceptionHIP(object):
             if entry[0] != 'block':
                 run(entry)
                 continue
-            # a block: every branch back-propagates on its own stream down to (excluding) its first
-            # op, the one that accumulates into the shared block-input gradient; those run in order
-            # on the main stream after the join
+            # a block: every branch back-propagates on its own stream; ops that read the block INPUT (they
+            # accumulate into its shared gradient) are held back and run in order on the main stream after
+            # the join -- pools first, convs next, the fused head conv last: the last accumulation is then
+            # a conv data-gradient, whose epilogue applies the input's ReLU mask
             main = torch.cuda.current_stream()
-            heads = []
-            for k, ops_k in entry[1]:
-                heads.append(ops_k[0])
-                if len(ops_k) == 1:
+            _, branches, bx, pre = entry
+            held = []
+            used = []
+            for k, ops_k in branches:
+                rest = list(ops_k)
+                if rest and rest[0][2].t is bx.t:
+                    held.append(rest.pop(0))
+                if not rest:
                     continue
+                used.append(k)
                 if self.parallel:
                     sk = self._streams()[k]
                     sk.wait_stream(main)
                     with torch.cuda.stream(sk):
-                        for op in reversed(ops_k[1:]):
+                        for op in reversed(rest):
                             run(op)
                 else:
-                    for op in reversed(ops_k[1:]):
+                    for op in reversed(rest):
                         run(op)
             if self.parallel:
-                for k, ops_k in entry[1]:
-                    if len(ops_k) > 1:
-                        main.wait_stream(self._streams()[k])
-            # pool heads first: the last accumulation into the block input is then a conv data-gradient,
-            # whose epilogue applies the input's ReLU mask
-            for op in sorted(heads, key=lambda o: 0 if o[0] != 'conv' else 1):
+                for k in used:
+                    main.wait_stream(self._streams()[k])
+            for op in sorted(held, key=lambda o: 0 if o[0] != 'conv' else 1) + list(reversed(pre)):
                 run(op)
         g0 = self._grad_of(a0)
         d299 = torch.empty_like(x299)
