@@ -89,16 +89,19 @@ int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* dw, const sb
  * parameter) -> packed `dtype` weights.  mode 0: same order (cast).  mode 1: data-gradient
  * weights of a stride-1 'same' conv: out[ci][KH-1-kh][KW-1-kw][co].  mode 2: data-gradient of
  * the 4x4 stride-2 pad-1 conv, four parity classes: out[(py*2+px)][ci][j*2+i][co] with
- * kh = (1-py) + 2j, kw = (1-px) + 2i. */
+ * kh = (1-py) + 2j, kw = (1-px) + 2i.  mode 3 (3x3 only): data-gradient of (nearest x2 -> conv3x3)
+ * collapsed into ONE 4x4 stride-2 pad-1 conv over dy (16/36 of the FLOPs of the conv at the upsampled
+ * resolution + 2x2 sum pooling): out[ci][dd*4+ee][co] = sum_{kh in S(dd), kw in S(ee)} w[co][kh][kw][ci]
+ * with S(0)={2}, S(1)={1,2}, S(2)={0,1}, S(3)={0}; 16*Cin*Cout elements. */
 int sba_pack_weight(int dtype, const float* w, void* out, int Cout, int KH, int KW, int Cin,
                     int mode, void* stream);
 /* All packed copies of ONE network's conv weights in one launch (after its optimizer step, cf.
  * trainer.py:275,296): per tensor the forward operand (mode-0 cast, skipped when fwd is NULL)
- * and the data-gradient operand (mode 1 or 2 as above, skipped when tr is NULL) are written from a
+ * and the data-gradient operand (mode 1, 2 or 3 as above, skipped when tr is NULL) are written from a
  * single read of the f32 master.  `descs` is a DEVICE array; workgroup b serves the tensor d with
  * tile_begin[d] <= b < tile_begin[d+1] (tiles: tap-major, then 64-row Cout tiles, then 64-column
  * Cin tiles; co_tiles = ceil(Cout/64), ci_tiles = ceil(Cin/64)); total_tiles = sum over tensors
- * of KH*KW*co_tiles*ci_tiles.  Cin must be a multiple of 4. */
+ * of slots*co_tiles*ci_tiles with slots = KH*KW (16 for mode 3).  Cin must be a multiple of 4. */
 typedef struct sba_pack_desc {
     const float* w;
     void* fwd;

@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(192) void wgrad_rows_kernel(const T* __restrict__ x
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int KH,
                                    int KW, int Cin, int mode) {
-    const int64_t n = (int64_t)Cout * KH * KW * Cin;
+    const int64_t n = (int64_t)Cout * (mode == 3 ? 16 : KH * KW) * Cin;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         // i indexes the OUTPUT (so that writes are coalesced)
@@ -1085,6 +1085,21 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
             const int kh = (int)(t % KH);
             const int ci = (int)(t / KH);
             v = w[(((int64_t)co * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * Cin + ci];
+        } else if (mode == 3) {
+            // data-gradient of (nearest x2 -> conv3x3) as ONE 4x4 stride-2 pad-1 conv over dy:
+            // out[ci][dd*4+ee][co] = sum_{kh in S(dd)} sum_{kw in S(ee)} w[co][kh][kw][ci],
+            // S(0) = {2}, S(1) = {1,2}, S(2) = {0,1}, S(3) = {0}
+            const int co = (int)(i % Cout);
+            int64_t t = i / Cout;
+            const int sl = (int)(t % 16);
+            const int ci = (int)(t / 16);
+            const int dd = sl >> 2, ee = sl & 3;
+            const int kh0 = dd == 0 ? 2 : (dd == 1 ? 1 : 0), khn = (dd == 1 || dd == 2) ? 2 : 1;
+            const int kw0 = ee == 0 ? 2 : (ee == 1 ? 1 : 0), kwn = (ee == 1 || ee == 2) ? 2 : 1;
+            v = 0.f;
+            for (int a = 0; a < khn; ++a)
+                for (int b2 = 0; b2 < kwn; ++b2)
+                    v += w[(((int64_t)co * 3 + kh0 + a) * 3 + kw0 + b2) * Cin + ci];
         } else {
             // out[cls][ci][j*2+i2][co], cls = py*2+px, kh = (1-py)+2j, kw = (1-px)+2*i2  (KH=KW=4)
             const int co = (int)(i % Cout);
@@ -1154,25 +1169,45 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const sba_pack_desc* __
     const sba_pack_desc d = descs[lo];
     const int local = b - d.tile_begin;
     const int per_tap = d.co_tiles * d.ci_tiles;
-    const int src_tap = local / per_tap;
+    const int src_tap = local / per_tap;                 // mode 3: the destination tap slot (0..15)
     const int rem = local - src_tap * per_tap;
     const int co0 = (rem / d.ci_tiles) * 64, ci0 = (rem % d.ci_tiles) * 64;
     const int taps = d.KH * d.KW;
-    if (src_tap >= taps) return;
+    const int slots = d.mode == 3 ? 16 : taps;
+    if (src_tap >= slots) return;
     const int tid = threadIdx.x;
     const int c4 = (tid & 15) * 4;
     T* fwd = reinterpret_cast<T*>(d.fwd);
+    // mode 3 (data-gradient of nearest x2 -> conv3x3 as one 4x4/s2 conv): slot (dd, ee) sums the source
+    // taps kh in S(dd), kw in S(ee);  S(0) = {2}, S(1) = {1,2}, S(2) = {0,1}, S(3) = {0}
+    int kh0 = 0, khn = 1, kw0 = 0, kwn = 1;
+    if (d.mode == 3) {
+        const int dd = src_tap >> 2, ee = src_tap & 3;
+        kh0 = dd == 0 ? 2 : (dd == 1 ? 1 : 0); khn = (dd == 1 || dd == 2) ? 2 : 1;
+        kw0 = ee == 0 ? 2 : (ee == 1 ? 1 : 0); kwn = (ee == 1 || ee == 2) ? 2 : 1;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (tid >> 4) + 16 * i;
         const int co = co0 + r, ci = ci0 + c4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (co < d.Cout && ci < d.Cin) {
-            const int64_t o = ((int64_t)co * taps + src_tap) * d.Cin + ci;
-            v = *reinterpret_cast<const float4*>(d.w + o);
-            if (fwd) {
-                fwd[o] = from_f<T>(v.x); fwd[o + 1] = from_f<T>(v.y);
-                fwd[o + 2] = from_f<T>(v.z); fwd[o + 3] = from_f<T>(v.w);
+            if (d.mode != 3 || src_tap < taps) {           // forward copy of source tap `src_tap`
+                const int64_t o = ((int64_t)co * taps + src_tap) * d.Cin + ci;
+                const float4 f = *reinterpret_cast<const float4*>(d.w + o);
+                if (fwd) {
+                    fwd[o] = from_f<T>(f.x); fwd[o + 1] = from_f<T>(f.y);
+                    fwd[o + 2] = from_f<T>(f.z); fwd[o + 3] = from_f<T>(f.w);
+                }
+                if (d.mode != 3) v = f;
+            }
+            if (d.mode == 3) {
+                for (int a = 0; a < khn; ++a)
+                    for (int b2 = 0; b2 < kwn; ++b2) {
+                        const float4 f = *reinterpret_cast<const float4*>(
+                            d.w + ((int64_t)co * 9 + (kh0 + a) * 3 + kw0 + b2) * d.Cin + ci);
+                        v.x += f.x; v.y += f.y; v.z += f.z; v.w += f.w;
+                    }
             }
         }
         tile[r][c4] = v.x; tile[r][c4 + 1] = v.y; tile[r][c4 + 2] = v.z; tile[r][c4 + 3] = v.w;
@@ -1185,6 +1220,9 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const sba_pack_desc* __
         const int kh = src_tap / d.KW, kw = src_tap - kh * d.KW;
         dst_tap = (d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw);
         dtaps = taps;
+    } else if (d.mode == 3) {
+        dst_tap = src_tap;
+        dtaps = 16;
     } else {
         const int kh = src_tap >> 2, kw = src_tap & 3;      // kh = (1-py) + 2j, kw = (1-px) + 2i
         const int py = 1 - (kh & 1), px = 1 - (kw & 1);
@@ -1541,16 +1579,17 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
 
 extern "C" int sba_pack_weight(int dtype, const float* w, void* out, int Cout, int KH, int KW, int Cin,
                                int mode, void* stream) {
-    if (!w || !out || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || mode < 0 || mode > 2) return SBA_E_ARG;
+    if (!w || !out || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || mode < 0 || mode > 3) return SBA_E_ARG;
+    if (mode == 3 && (KH != 3 || KW != 3)) return SBA_E_ARG;
     if (mode == 2 && (KH != 4 || KW != 4)) return SBA_E_ARG;
-    if (mode != 0) {
+    if (mode == 1 || mode == 2) {
         dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), mode == 1 ? KH * KW : 16);
         if (grid.y > 65535) return SBA_E_ARG;
         SBA_DISPATCH(dtype, hipLaunchKernelGGL((pack_weight_tr_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
                                                w, (T*)out, Cout, KH, KW, Cin, mode));
         return SBA_CHECK_LAUNCH();
     }
-    const int64_t n = (int64_t)Cout * KH * KW * Cin;
+    const int64_t n = (int64_t)Cout * (mode == 3 ? 16 : KH * KW) * Cin;
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     SBA_DISPATCH(dtype, hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(blocks), dim3(256), 0,
                                            (hipStream_t)stream, w, (T*)out, Cout, KH, KW, Cin, mode));

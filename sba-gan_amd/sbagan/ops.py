@@ -153,6 +153,11 @@ def _conv_out_hw(kind, H, W):
     raise ValueError(kind)
 
 
+# data-gradient operand layouts (sba_pack_weight modes): flipped 3x3, four parity classes of the 4x4/s2
+# conv, and the 4x4/s2 collapse of (nearest x2 -> conv3x3)
+_DGRAD_MODE = {'3x3': 1, '4x4s2': 2, '3x3up': 3}
+
+
 class PackedWeight(object):
     """Packed copies of one OIHW conv parameter (stored channels_last, i.e.
     [O][KH][KW][I] f32 in memory): the forward operand in the compute dtype and
@@ -200,9 +205,10 @@ class PackedWeight(object):
                 return self._dgrad
             p = self._master()
             O, I, KH, KW = p.shape
-            if self._dgrad is None or self._dgrad.dtype != dtype:
-                self._dgrad = torch.empty(O * KH * KW * I, dtype=dtype, device=p.device)
-            mode = 2 if kind == '4x4s2' else 1
+            mode = _DGRAD_MODE[kind]
+            n = O * I * (16 if mode == 3 else KH * KW)
+            if self._dgrad is None or self._dgrad.dtype != dtype or self._dgrad.numel() != n:
+                self._dgrad = torch.empty(n, dtype=dtype, device=p.device)
             dcode = _lib.SBA_BF16 if dtype == torch.bfloat16 else _lib.SBA_F32
             call('sba_pack_weight', dcode, _p(p), _p(self._dgrad), O, KH, KW, I, mode, _stream())
             self._kd = k
@@ -228,12 +234,18 @@ class PackGroup(object):
         import numpy as np
         dev = self.layers[0][0].param.device
         sizes = [pw.param.numel() for pw, _ in self.layers]
+        tsizes = [pw.param.shape[0] * pw.param.shape[1] * (16 if kind == '3x3up' else pw.param.shape[2] * pw.param.shape[3])
+                  for pw, kind in self.layers]
         offs, n = [], 0
         for k in sizes:
             offs.append(n)
             n += (k + 7) // 8 * 8
+        toffs, tn = [], 0
+        for k in tsizes:
+            toffs.append(tn)
+            tn += (k + 7) // 8 * 8
         st = {'fwd': torch.empty(n, dtype=dtype, device=dev) if dtype != torch.float32 else None,
-              'tr': torch.empty(n, dtype=dtype, device=dev)}
+              'tr': torch.empty(tn, dtype=dtype, device=dev)}
         esz = st['tr'].element_size()
         desc = np.zeros(len(self.layers), dtype=np.dtype(self._DESC, align=True))
         assert desc.dtype.itemsize == 56
@@ -243,15 +255,15 @@ class PackGroup(object):
             d = desc[i]
             d['w'] = pw.param.data_ptr()
             d['fwd'] = st['fwd'].data_ptr() + o * esz if st['fwd'] is not None else 0
-            d['tr'] = st['tr'].data_ptr() + o * esz
+            d['tr'] = st['tr'].data_ptr() + toffs[i] * esz
             d['Cout'], d['KH'], d['KW'], d['Cin'] = O, KH, KW, I
-            d['mode'] = 2 if kind == '4x4s2' else 1
+            d['mode'] = _DGRAD_MODE[kind]
             d['tile_begin'] = tiles
             d['co_tiles'], d['ci_tiles'] = (O + 63) // 64, (I + 63) // 64
-            tiles += KH * KW * d['co_tiles'] * d['ci_tiles']
+            tiles += (16 if d['mode'] == 3 else KH * KW) * d['co_tiles'] * d['ci_tiles']
             if st['fwd'] is not None:
                 pw._fwd = st['fwd'][o:o + sizes[i]]
-            pw._dgrad = st['tr'][o:o + sizes[i]]
+            pw._dgrad = st['tr'][toffs[i]:toffs[i] + tsizes[i]]
         st['descs'] = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
         st['ptrs'] = [pw.param.data_ptr() for pw, _ in self.layers]
         st['tiles'] = tiles
@@ -357,18 +369,17 @@ def conv_dgrad(dy, pw, kind, in_hw, addend=None):
     I = pw.param.shape[1]
     H, W = in_hw
     wd = pw.dgrad(dy.dtype, kind)
-    if kind in ('3x3', '3x3up'):
+    if kind == '3x3':
         g = _geom(('3x3', N, OH, OW, O, I, None))
-        if kind == '3x3':
-            dx = empty_act(N, I, H, W, dy)
-            _igemm(_dt(dy), _p(dy), _p(wd), _p(dx), _p(addend), None, g, dy.device)
-            return dx
-        dup = empty_act(N, I, OH, OW, dy)
-        _igemm(_dt(dy), _p(dy), _p(wd), _p(dup), None, None, g, dy.device)
         dx = empty_act(N, I, H, W, dy)
-        call('sba_pool2x2_sum', _dt(dy), _p(dup), _p(dx), N, H, W, I, _stream())
-        if addend is not None:
-            dx += addend
+        _igemm(_dt(dy), _p(dy), _p(wd), _p(dx), _p(addend), None, g, dy.device)
+        return dx
+    if kind == '3x3up':
+        # every source pixel collects a 4x4 window of dy with the tap sums packed by mode 3: one stride-2
+        # conv at the SOURCE resolution instead of a conv at the upsampled resolution + 2x2 sum pooling
+        g = _geom(('4x4s2', N, OH, OW, O, I, None))
+        dx = empty_act(N, I, H, W, dy)
+        _igemm(_dt(dy), _p(dy), _p(wd), _p(dx), _p(addend), None, g, dy.device)
         return dx
     if kind == '4x4s2':
         dx = empty_act(N, I, H, W, dy)
