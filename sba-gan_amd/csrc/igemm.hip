@@ -1340,15 +1340,12 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ 
 struct IgemmCfg { int bm, bn, ks, occ; float eff; bool split; };
 // A: big square tile, B: wide-M tile for Cout = 64, C: mid tile, D: small tile (+split-K),
 // E: skinny GEMM tile for the 4x4 / 8x8 maps with thousands of channels (+split-K)
-// F: the small tile with 4 in-workgroup K-groups (16 waves): latency-bound layers with too few tiles
-// G: the small tile with three stages of loads in flight
-// H: the small tile with two in-workgroup K-groups (8 waves = 2 per SIMD, so that one wave's
-//    ds_read -> MFMA -> barrier chain overlaps the other's)
-// I: 32 x 64 tile, two waves: twice the workgroups of D for latency-bound layers with few tiles
-static const IgemmCfg kCfg[9] = {
+// (The kernel also instantiates with KG > 1 in-workgroup K-groups and PF = 3 stages of loads in flight;
+// on the latency-bound small layers neither beat D -- 1 KB of LDS fragments per MFMA and one wave per
+// SIMD bound them, not the K loop -- so no shipped configuration uses them.)
+static const IgemmCfg kCfg[5] = {
     {128, 128, 1, 3, 1.00f, false}, {256, 64, 1, 3, 1.00f, false}, {128, 64, 2, 2, 0.80f, false},
-    {64, 64, 2, 3, 0.50f, true},    {320, 128, 2, 1, 0.90f, true},  {64, 64, 1, 1, 0.50f, true},
-    {64, 64, 2, 2, 0.50f, true},    {64, 64, 2, 1, 0.50f, true},    {32, 64, 2, 4, 0.40f, true}};
+    {64, 64, 2, 3, 0.50f, true},    {320, 128, 2, 1, 0.90f, true}};
 
 template <typename T, int BM, int BN, int WM, int WN, int KS, int KG = 1, int PF = 1>
 static void launch_cfg(const T* xp, const T* wp, T* yp, const T* ap, float* stats, const sba_conv_geom& g, int M,
@@ -1372,7 +1369,7 @@ static int forced_cfg() {
     static int v = -2;
     if (v == -2) {
         const char* e = getenv("SBA_IGEMM_CFG");       // tuning aid only: A..E
-        v = (e && e[0] >= 'A' && e[0] <= 'I') ? e[0] - 'A' : -1;
+        v = (e && e[0] >= 'A' && e[0] <= 'E') ? e[0] - 'A' : -1;
     }
     return v;
 }
@@ -1436,14 +1433,6 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
     }
     if (forced_cfg() >= 0) best = forced_cfg();
     {
-        static int d2f = -1;
-        if (d2f < 0) { const char* e = getenv("SBA_IGEMM_D2F"); d2f = (e && e[0] == '1') ? 1 : 0; }
-        if (d2f && best == 3) best = 5;
-        static int d2g = -1;
-        if (d2g < 0) { const char* e = getenv("SBA_IGEMM_D2G"); d2g = (e && e[0] == '1') ? 1 : 0; }
-        if (d2g && best == 3) best = 6;
-    }
-    {
         const IgemmCfg& k = kCfg[best];
         const int tiles = cdiv(M, k.bm) * cdiv(g.Cout, k.bn);
         const int slots = 256 * k.occ;
@@ -1462,10 +1451,6 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
         case 1: launch_cfg<T, 256, 64, 64, 64, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
         case 2: launch_cfg<T, 128, 64, 32, 64, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
         case 3: launch_cfg<T, 64, 64, 32, 32, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
-        case 5: launch_cfg<T, 64, 64, 32, 32, 1, 4>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
-        case 6: launch_cfg<T, 64, 64, 32, 32, 2, 1, 3>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
-        case 7: launch_cfg<T, 64, 64, 32, 32, 2, 2, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
-        case 8: launch_cfg<T, 32, 64, 32, 32, 2, 1, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
         default: launch_cfg<T, 320, 128, 64, 64, 2>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
     }
     return SBA_CHECK_LAUNCH();

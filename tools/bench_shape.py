@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of sba_conv_igemm on arbitrary (kh x kw, stride 1, same-padded) shapes, e.g. the
-Inception trunk's 17x17 factorised convs (tuning aid; SBA_IGEMM_CFG=A..F forces one configuration).
+Inception trunk's 17x17 factorised convs (tuning aid; SBA_IGEMM_CFG=A..E forces one configuration).
 usage: bench_shape.py N H W Cin Cout KH KW [N H W Cin Cout KH KW ...]"""
 import ctypes
 import os
