@@ -279,7 +279,7 @@ template <typename T, int IDF>
 int launch_fwd(const void* h, const float* src, const uint8_t* mask, void* ctx, float* att, int B, int Q, int L,
                int mode, int ocs, int oco, hipStream_t st) {
     dim3 grid(cdiv(Q, 256), B);
-    hipLaunchKernelGGL((word_attn_fwd_kernel<T, IDF>), grid, dim3(256), 0, st, (const T*)h, src, mask, (T*)ctx, att,
+    SBA_LAUNCH((word_attn_fwd_kernel<T, IDF>), grid, dim3(256), 0, st, (const T*)h, src, mask, (T*)ctx, att,
                        B, Q, L, mode, ocs, oco);
     return SBA_CHECK_LAUNCH();
 }
@@ -290,7 +290,7 @@ int launch_bwd(const void* h, const float* src, const uint8_t* mask, const void*
     constexpr int NT = AttnMma<T>::NW * 64;
     int chunks = Q >= 16384 ? 4 : (Q >= 4096 ? 2 : 1);           // NT-query chunks per workgroup
     dim3 grid(cdiv(Q, NT * chunks), B);
-    hipLaunchKernelGGL((word_attn_bwd_kernel<T, IDF>), grid, dim3(NT), 0, st, (const T*)h, src, mask,
+    SBA_LAUNCH((word_attn_bwd_kernel<T, IDF>), grid, dim3(NT), 0, st, (const T*)h, src, mask,
                        (const T*)dctx, (T*)dh, dsrc, B, Q, L, mode, dcs, dco, acc, chunks);
     return SBA_CHECK_LAUNCH();
 }

@@ -83,6 +83,10 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// hipGetLastError() is per-thread and STICKY across unrelated runtime calls of the host framework (an
+// event query that returned hipErrorNotReady is enough): clear it before every launch so that
+// SBA_CHECK_LAUNCH reports this launch only.
+#define SBA_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 #define SBA_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? SBA_OK : SBA_E_LAUNCH)
 #define SBA_DISPATCH(dtype, CALL)                       \
     do {                                                \

@@ -391,12 +391,12 @@ extern "C" int sba_damsm_words_fwd(const float* feat, const float* words, const 
     if (LP == 20) {
         (void)hipFuncSetAttribute((const void*)damsm_words_fwd_kernel<20>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL(damsm_words_fwd_kernel<20>, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words,
+        SBA_LAUNCH(damsm_words_fwd_kernel<20>, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words,
                            cap_lens, sim, attn, attn1, wctx, B, nef, R, L, gamma1, gamma2);
     } else {
         (void)hipFuncSetAttribute((const void*)damsm_words_fwd_kernel<32>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL(damsm_words_fwd_kernel<32>, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words,
+        SBA_LAUNCH(damsm_words_fwd_kernel<32>, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words,
                            cap_lens, sim, attn, attn1, wctx, B, nef, R, L, gamma1, gamma2);
     }
     return SBA_CHECK_LAUNCH();
@@ -414,12 +414,12 @@ extern "C" int sba_damsm_words_bwd(const float* feat, const float* words, const 
     if (LP == 20) {
         (void)hipFuncSetAttribute((const void*)damsm_words_bwd_kernel<20>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL(damsm_words_bwd_kernel<20>, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words,
+        SBA_LAUNCH(damsm_words_bwd_kernel<20>, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words,
                            cap_lens, sim, attn, attn1, wctx, dsim, dfeat, dwords, B, nef, R, L, gamma1, gamma2);
     } else {
         (void)hipFuncSetAttribute((const void*)damsm_words_bwd_kernel<32>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        hipLaunchKernelGGL(damsm_words_bwd_kernel<32>, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words,
+        SBA_LAUNCH(damsm_words_bwd_kernel<32>, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words,
                            cap_lens, sim, attn, attn1, wctx, dsim, dfeat, dwords, B, nef, R, L, gamma1, gamma2);
     }
     return SBA_CHECK_LAUNCH();
@@ -428,7 +428,7 @@ extern "C" int sba_damsm_words_bwd(const float* feat, const float* words, const 
 extern "C" int sba_damsm_sent_fwd(const float* cnn, const float* rnn, float* s, int B, int nef, float gamma3,
                                   float eps, void* stream) {
     if (!cnn || !rnn || !s || B <= 0 || B > 1024 || nef <= 0) return SBA_E_ARG;
-    hipLaunchKernelGGL(damsm_sent_fwd_kernel, dim3(B, B), dim3(64), 0, (hipStream_t)stream, cnn, rnn, s, B, nef,
+    SBA_LAUNCH(damsm_sent_fwd_kernel, dim3(B, B), dim3(64), 0, (hipStream_t)stream, cnn, rnn, s, B, nef,
                        gamma3, eps);
     return SBA_CHECK_LAUNCH();
 }
@@ -436,7 +436,7 @@ extern "C" int sba_damsm_sent_fwd(const float* cnn, const float* rnn, float* s, 
 extern "C" int sba_damsm_sent_bwd(const float* cnn, const float* rnn, const float* ds, float* dcnn, float* drnn,
                                   int B, int nef, float gamma3, float eps, void* stream) {
     if (!cnn || !rnn || !ds || B <= 0 || B > 1024 || nef <= 0) return SBA_E_ARG;
-    hipLaunchKernelGGL(damsm_sent_bwd_kernel, dim3(B, B), dim3(64), 0, (hipStream_t)stream, cnn, rnn, ds, dcnn, drnn,
+    SBA_LAUNCH(damsm_sent_bwd_kernel, dim3(B, B), dim3(64), 0, (hipStream_t)stream, cnn, rnn, ds, dcnn, drnn,
                        B, nef, gamma3, eps);
     return SBA_CHECK_LAUNCH();
 }
@@ -445,7 +445,7 @@ extern "C" int sba_ce_pair(const float* score, const uint8_t* mask, float scale,
                            float* dscore1, int B, void* stream) {
     if (!score || !loss || !dscore0 || !dscore1 || B <= 0 || B > 96) return SBA_E_ARG;
     const size_t sh = sizeof(float) * ((size_t)B * B + 2 * B);
-    hipLaunchKernelGGL(ce_pair_kernel, dim3(1), dim3(256), sh, (hipStream_t)stream, score, mask, scale, loss,
+    SBA_LAUNCH(ce_pair_kernel, dim3(1), dim3(256), sh, (hipStream_t)stream, score, mask, scale, loss,
                        dscore0, dscore1, B);
     return SBA_CHECK_LAUNCH();
 }
@@ -453,6 +453,6 @@ extern "C" int sba_ce_pair(const float* score, const uint8_t* mask, float scale,
 extern "C" int sba_combine2(float* out, const float* a, const float* ga, const float* b, const float* gb, int n,
                             void* stream) {
     if (!out || !a || !ga || !b || !gb || n <= 0) return SBA_E_ARG;
-    hipLaunchKernelGGL(combine2_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out, a, ga, b, gb, n);
+    SBA_LAUNCH(combine2_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, out, a, ga, b, gb, n);
     return SBA_CHECK_LAUNCH();
 }

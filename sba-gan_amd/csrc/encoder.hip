@@ -328,9 +328,9 @@ extern "C" int sba_resize_bilinear(const float* in, float* out, int NC, int S, i
     if (!in || !out || NC <= 0 || S < 2 || D < 2) return SBA_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (!backward) {
-        hipLaunchKernelGGL(resize_fwd_kernel, dim3(grid_for((int64_t)NC * D * D)), dim3(256), 0, st, in, out, NC, S, D);
+        SBA_LAUNCH(resize_fwd_kernel, dim3(grid_for((int64_t)NC * D * D)), dim3(256), 0, st, in, out, NC, S, D);
     } else {     // in = d(out) [NC][D][D], out = d(in) [NC][S][S]
-        hipLaunchKernelGGL(resize_bwd_kernel, dim3(grid_for((int64_t)NC * S * S)), dim3(256), 0, st, in, out, NC, S, D);
+        SBA_LAUNCH(resize_bwd_kernel, dim3(grid_for((int64_t)NC * S * S)), dim3(256), 0, st, in, out, NC, S, D);
     }
     return SBA_CHECK_LAUNCH();
 }
@@ -339,7 +339,7 @@ extern "C" int sba_enc_stem_fwd(int dtype, const float* img, const float* w, con
                                 int S, int C, void* stream) {
     if (!img || !w || !bias || !out || N <= 0 || S < 3 || C <= 0 || C % 8 || C > 256) return SBA_E_ARG;
     const int O = (S - 3) / 2 + 1, V = dtype == SBA_BF16 ? 8 : 4;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((enc_stem_fwd_kernel<T>), dim3(grid_for((int64_t)N * O * O * (C / V), 4096)),
+    SBA_DISPATCH(dtype, SBA_LAUNCH((enc_stem_fwd_kernel<T>), dim3(grid_for((int64_t)N * O * O * (C / V), 4096)),
                                            dim3(256), sizeof(float) * 27 * C, (hipStream_t)stream, img, w, bias,
                                            (T*)out, N, S, O, C));
     return SBA_CHECK_LAUNCH();
@@ -349,7 +349,7 @@ extern "C" int sba_enc_stem_bwd(int dtype, const float* w, const void* out, cons
                                 int S, int C, void* stream) {
     if (!w || !out || !dout || !dimg || N <= 0 || S < 3 || C <= 0 || C % 8 || C > 256) return SBA_E_ARG;
     const int O = (S - 3) / 2 + 1;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((enc_stem_bwd_kernel<T>), dim3(grid_for((int64_t)N * S * S, 4096)), dim3(256),
+    SBA_DISPATCH(dtype, SBA_LAUNCH((enc_stem_bwd_kernel<T>), dim3(grid_for((int64_t)N * S * S, 4096)), dim3(256),
                                            sizeof(float) * 27 * C, (hipStream_t)stream, w, (const T*)out,
                                            (const T*)dout, dimg, N, S, O, C));
     return SBA_CHECK_LAUNCH();
@@ -360,7 +360,7 @@ extern "C" int sba_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int N, in
     if (!x || !y || N <= 0 || H < 3 || W < 3 || !slice_ok(dtype, C, xcs, xco) || !slice_ok(dtype, C, ycs, yco))
         return SBA_E_ARG;
     const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1, V = dtype == SBA_BF16 ? 8 : 4;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for((int64_t)N * OH * OW * (C / V))),
+    SBA_DISPATCH(dtype, SBA_LAUNCH((maxpool_fwd_kernel<T>), dim3(grid_for((int64_t)N * OH * OW * (C / V))),
                                            dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, N, H, W, C, xcs, xco,
                                            ycs, yco));
     return SBA_CHECK_LAUNCH();
@@ -373,7 +373,7 @@ extern "C" int sba_maxpool3x3s2_bwd(int dtype, const void* x, const void* dy, vo
         !slice_ok(dtype, C, dycs, dyco) || !slice_ok(dtype, C, dxcs, dxco))
         return SBA_E_ARG;
     const int V = dtype == SBA_BF16 ? 8 : 4;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for((int64_t)N * H * W * (C / V))),
+    SBA_DISPATCH(dtype, SBA_LAUNCH((maxpool_bwd_kernel<T>), dim3(grid_for((int64_t)N * H * W * (C / V))),
                                            dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, N, H,
                                            W, C, xcs, xco, dycs, dyco, dxcs, dxco, accumulate));
     return SBA_CHECK_LAUNCH();
@@ -384,7 +384,7 @@ extern "C" int sba_avgpool3x3(int dtype, const void* x, void* y, int N, int H, i
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || !slice_ok(dtype, C, xcs, xco) || !slice_ok(dtype, C, ycs, yco))
         return SBA_E_ARG;
     const int V = dtype == SBA_BF16 ? 8 : 4;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((avgpool3_kernel<T>), dim3(grid_for((int64_t)N * H * W * (C / V))), dim3(256),
+    SBA_DISPATCH(dtype, SBA_LAUNCH((avgpool3_kernel<T>), dim3(grid_for((int64_t)N * H * W * (C / V))), dim3(256),
                                            0, (hipStream_t)stream, (const T*)x, (T*)y, N, H, W, C, xcs, xco, ycs, yco,
                                            accumulate));
     return SBA_CHECK_LAUNCH();
@@ -395,7 +395,7 @@ extern "C" int sba_relu_bwd(int dtype, const void* out, const void* dout, void* 
     if (!out || !dout || !dpre || rows <= 0 || !slice_ok(dtype, C, ocs, oco) || !slice_ok(dtype, C, dcs, dco))
         return SBA_E_ARG;
     const int V = dtype == SBA_BF16 ? 8 : 4;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((relu_bwd_kernel<T>), dim3(grid_for(rows * (C / V))), dim3(256), 0,
+    SBA_DISPATCH(dtype, SBA_LAUNCH((relu_bwd_kernel<T>), dim3(grid_for(rows * (C / V))), dim3(256), 0,
                                            (hipStream_t)stream, (const T*)out, (const T*)dout, (T*)dpre, rows, C, ocs,
                                            oco, dcs, dco));
     return SBA_CHECK_LAUNCH();
@@ -404,10 +404,10 @@ extern "C" int sba_relu_bwd(int dtype, const void* out, const void* dout, void* 
 extern "C" int sba_global_avgpool(int dtype, void* x, float* y, int N, int HW, int C, int backward, void* stream) {
     if (!x || !y || N <= 0 || HW <= 0 || C <= 0) return SBA_E_ARG;
     if (!backward) {
-        SBA_DISPATCH(dtype, hipLaunchKernelGGL((gap_fwd_kernel<T>), dim3(cdiv((int64_t)N * C, 256)), dim3(256), 0,
+        SBA_DISPATCH(dtype, SBA_LAUNCH((gap_fwd_kernel<T>), dim3(cdiv((int64_t)N * C, 256)), dim3(256), 0,
                                                (hipStream_t)stream, (const T*)x, y, N, HW, C));
     } else {     // x = dx (output, T), y = dy (input, f32)
-        SBA_DISPATCH(dtype, hipLaunchKernelGGL((gap_bwd_kernel<T>), dim3(grid_for((int64_t)N * HW * C)), dim3(256), 0,
+        SBA_DISPATCH(dtype, SBA_LAUNCH((gap_bwd_kernel<T>), dim3(grid_for((int64_t)N * HW * C)), dim3(256), 0,
                                                (hipStream_t)stream, (const float*)y, (T*)x, N, HW, C));
     }
     return SBA_CHECK_LAUNCH();
@@ -416,10 +416,10 @@ extern "C" int sba_global_avgpool(int dtype, void* x, float* y, int N, int HW, i
 extern "C" int sba_layout_nhwc_nchw(int dtype, void* nhwc, float* nchw, int N, int HW, int C, int to_nhwc, void* stream) {
     if (!nhwc || !nchw || N <= 0 || HW <= 0 || C <= 0) return SBA_E_ARG;
     if (!to_nhwc) {
-        SBA_DISPATCH(dtype, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(grid_for((int64_t)N * HW * C)), dim3(256), 0,
+        SBA_DISPATCH(dtype, SBA_LAUNCH((nhwc_to_nchw_kernel<T>), dim3(grid_for((int64_t)N * HW * C)), dim3(256), 0,
                                                (hipStream_t)stream, (const T*)nhwc, nchw, N, HW, C));
     } else {
-        SBA_DISPATCH(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for((int64_t)N * HW * C)), dim3(256), 0,
+        SBA_DISPATCH(dtype, SBA_LAUNCH((nchw_to_nhwc_kernel<T>), dim3(grid_for((int64_t)N * HW * C)), dim3(256), 0,
                                                (hipStream_t)stream, (const float*)nchw, (T*)nhwc, N, HW, C));
     }
     return SBA_CHECK_LAUNCH();

@@ -501,7 +501,7 @@ extern "C" int sba_img_head_fwd(int dtype, const void* h, const float* w, float*
     if (!h || !w || !img || N <= 0 || H <= 0 || W <= 0) return SBA_E_ARG;
     const int64_t total = (int64_t)N * H * W;
     if (total > 0x7fffffffLL * 64) return SBA_E_ARG;
-    SBA_DISPATCH(dtype, CH_SWITCH(C_, hipLaunchKernelGGL((img_head_fwd_kernel<T, C>), dim3(cdiv(total, 256)),
+    SBA_DISPATCH(dtype, CH_SWITCH(C_, SBA_LAUNCH((img_head_fwd_kernel<T, C>), dim3(cdiv(total, 256)),
                                                         dim3(256), 0, (hipStream_t)stream, (const T*)h, w, img, N,
                                                         H, W)));
     return SBA_CHECK_LAUNCH();
@@ -515,7 +515,7 @@ extern "C" int sba_img_head_bwd(int dtype, const void* h, const float* w, const 
     SBA_DISPATCH(dtype, CH_SWITCH(C_, {
         const size_t sh = sizeof(float) * (27 * C + 256 * ((C % 64 == 32) ? C : C + 32) + 256 * 32 + 32 * C);
         set_lds(img_head_bwd_kernel<T, C>, sh);
-        hipLaunchKernelGGL((img_head_bwd_kernel<T, C>), dim3(cdiv(total, 256)), dim3(256), sh, (hipStream_t)stream,
+        SBA_LAUNCH((img_head_bwd_kernel<T, C>), dim3(cdiv(total, 256)), dim3(256), sh, (hipStream_t)stream,
                            (const T*)h, w, img, dimg, (T*)dh, dw, N, H, W, accumulate);
     }));
     return SBA_CHECK_LAUNCH();
@@ -527,7 +527,7 @@ extern "C" int sba_d_stem_fwd(int dtype, const float* img, const float* w, void*
     const int64_t pix = (int64_t)N * (S / 2) * (S / 2);
     if ((pix + 255) / 256 > 0x7fffffff) return SBA_E_ARG;
     SBA_DISPATCH(dtype, {
-        hipLaunchKernelGGL((d_stem_fwd_kernel<T>), dim3((unsigned)((pix + 255) / 256), C / STEM_CB), dim3(256), 0,
+        SBA_LAUNCH((d_stem_fwd_kernel<T>), dim3((unsigned)((pix + 255) / 256), C / STEM_CB), dim3(256), 0,
                            (hipStream_t)stream, img, w, (T*)out, N, S, C);
     });
     return SBA_CHECK_LAUNCH();
@@ -546,7 +546,7 @@ extern "C" int sba_d_stem_bwd(int dtype, const float* img, const float* w, const
         const size_t sh = sizeof(float) * (64 * (C + (C % 64 == 0 ? 32 : 0)) + 64 * 96);
         SBA_DISPATCH(dtype, {
             set_lds(d_stem_wgrad_kernel<T>, sh);
-            hipLaunchKernelGGL((d_stem_wgrad_kernel<T>), dim3(blocks), dim3(256), sh, st, img, (const T*)out,
+            SBA_LAUNCH((d_stem_wgrad_kernel<T>), dim3(blocks), dim3(256), sh, st, img, (const T*)out,
                                (const T*)dout, dw, N, S, C, tpb);
         });
     }
@@ -556,7 +556,7 @@ extern "C" int sba_d_stem_bwd(int dtype, const float* img, const float* w, const
         if (N > 65535) return SBA_E_ARG;
         SBA_DISPATCH(dtype, {
             set_lds(d_stem_dgrad_kernel<T>, sh);
-            hipLaunchKernelGGL((d_stem_dgrad_kernel<T>), dim3(tiles, N), dim3(256), sh, st, w, (const T*)out,
+            SBA_LAUNCH((d_stem_dgrad_kernel<T>), dim3(tiles, N), dim3(256), sh, st, w, (const T*)out,
                                (const T*)dout, dimg, N, S, C);
         });
     }
@@ -566,7 +566,7 @@ extern "C" int sba_d_stem_bwd(int dtype, const float* img, const float* w, const
 extern "C" int sba_logits_fwd(int dtype, const void* h, const float* w, const float* bias, float* prob, int B,
                               int K, void* stream) {
     if (!h || !w || !bias || !prob || B <= 0 || K <= 0 || K % 8) return SBA_E_ARG;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((logits_fwd_kernel<T>), dim3(B), dim3(256), 0, (hipStream_t)stream,
+    SBA_DISPATCH(dtype, SBA_LAUNCH((logits_fwd_kernel<T>), dim3(B), dim3(256), 0, (hipStream_t)stream,
                                            (const T*)h, w, bias, prob, K));
     return SBA_CHECK_LAUNCH();
 }
@@ -575,7 +575,7 @@ extern "C" int sba_logits_bwd(int dtype, const void* h, const float* w, const fl
                               void* dh, float* dw, float* dbias, int B, int K, int accumulate, void* stream) {
     if (!h || !w || !prob || !dprob || !dh || B <= 0 || B > 4096 || K <= 0 || K % 8) return SBA_E_ARG;
     const int V = dtype == SBA_BF16 ? 8 : 4;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((logits_bwd_kernel<T>), dim3(cdiv(K / V, 256), cdiv(B, LOGITS_LB)), dim3(256),
+    SBA_DISPATCH(dtype, SBA_LAUNCH((logits_bwd_kernel<T>), dim3(cdiv(K / V, 256), cdiv(B, LOGITS_LB)), dim3(256),
                                            0, (hipStream_t)stream, (const T*)h, w, prob, dprob,
                                            (T*)dh, dw, dbias, B, K, accumulate));
     return SBA_CHECK_LAUNCH();
@@ -584,7 +584,7 @@ extern "C" int sba_logits_bwd(int dtype, const void* h, const float* w, const fl
 extern "C" int sba_cond_cat_fwd(int dtype, const void* h, const float* sent, void* out, int B, int C, int E,
                                 void* stream) {
     if (!h || !sent || !out || B <= 0 || C <= 0 || E <= 0) return SBA_E_ARG;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((cond_cat_fwd_kernel<T>), dim3(grid_for((int64_t)B * 16 * (C + E))),
+    SBA_DISPATCH(dtype, SBA_LAUNCH((cond_cat_fwd_kernel<T>), dim3(grid_for((int64_t)B * 16 * (C + E))),
                                            dim3(256), 0, (hipStream_t)stream, (const T*)h, sent, (T*)out, B, C, E));
     return SBA_CHECK_LAUNCH();
 }
@@ -592,7 +592,7 @@ extern "C" int sba_cond_cat_fwd(int dtype, const void* h, const float* sent, voi
 extern "C" int sba_cond_cat_bwd(int dtype, const void* dout, void* dh, float* dsent, int B, int C, int E,
                                 int accumulate, void* stream) {
     if (!dout || !dh || B <= 0 || C <= 0 || E <= 0) return SBA_E_ARG;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((cond_cat_bwd_kernel<T>), dim3(grid_for((int64_t)B * 16 * C + B * E)),
+    SBA_DISPATCH(dtype, SBA_LAUNCH((cond_cat_bwd_kernel<T>), dim3(grid_for((int64_t)B * 16 * C + B * E)),
                                            dim3(256), 0, (hipStream_t)stream, (const T*)dout, (T*)dh, dsent, B, C, E,
                                            accumulate));
     return SBA_CHECK_LAUNCH();

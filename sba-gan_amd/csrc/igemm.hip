@@ -1357,11 +1357,11 @@ static void launch_cfg(const T* xp, const T* wp, T* yp, const T* ap, float* stat
         split = cdiv(nslabs, sps);
     }
     dim3 grid(cdiv(M, BM), cdiv(g.Cout, BN), split);
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, KS, KG, PF>), grid, dim3(NT), 0, st, xp, wp, yp, ap, stats, g, M,
+    SBA_LAUNCH((igemm_kernel<T, BM, BN, WM, WN, KS, KG, PF>), grid, dim3(NT), 0, st, xp, wp, yp, ap, stats, g, M,
                        split > 1 ? ws : (float*)nullptr, sps, ex);
     if (split > 1) {
         dim3 fgrid(cdiv(g.Cout / 4, 256), cdiv(M, 8));
-        hipLaunchKernelGGL((splitk_finish_kernel<T>), fgrid, dim3(256), 0, st, ws, yp, ap, stats, g, M, ex);
+        SBA_LAUNCH((splitk_finish_kernel<T>), fgrid, dim3(256), 0, st, ws, yp, ap, stats, g, M, ex);
     }
 }
 
@@ -1395,8 +1395,8 @@ static void launch_halo(const sba_conv_geom& g, const bf16_t* x, const bf16_t* w
     // BN = 64 for every Cout: the 128-wide variant needs 86 KB of LDS (one workgroup per CU) and
     // measured slower; re-staging the halo tile for the second channel block is cheap
     dim3 grid(tiles, g.Cout / 64);
-    if (g.ups) hipLaunchKernelGGL((conv3x3_halo_kernel<64, 64, 1>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, ex);
-    else hipLaunchKernelGGL((conv3x3_halo_kernel<64, 64, 0>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, ex);
+    if (g.ups) SBA_LAUNCH((conv3x3_halo_kernel<64, 64, 1>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, ex);
+    else SBA_LAUNCH((conv3x3_halo_kernel<64, 64, 0>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, ex);
 }
 
 template <typename T>
@@ -1525,7 +1525,7 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
         split = cdiv(total_chunks, cps);
         dim3 grid(co_tiles, cdiv(items, 4), split);
         if (grid.y > 65535 || grid.z > 65535) return SBA_E_ARG;
-        SBA_DISPATCH(dtype, hipLaunchKernelGGL((wgrad_small_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
+        SBA_DISPATCH(dtype, SBA_LAUNCH((wgrad_small_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
                                                (const T*)x, (const T*)dy, dw, *g, M, cps, split > 1 ? 1 : 0, dsub,
                                                dow));
         return SBA_CHECK_LAUNCH();
@@ -1546,7 +1546,7 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
         nz = cdiv(total_segs, spw);
         dim3 grid(co_tiles, ci_t, nz);
         if (grid.z > 65535) return SBA_E_ARG;
-        SBA_DISPATCH(dtype, hipLaunchKernelGGL((wgrad_rows_kernel<T>), grid, dim3(192), 0, (hipStream_t)stream,
+        SBA_DISPATCH(dtype, SBA_LAUNCH((wgrad_rows_kernel<T>), grid, dim3(192), 0, (hipStream_t)stream,
                                                (const T*)x, (const T*)dy, dw, *g, total_segs, spw));
         return SBA_CHECK_LAUNCH();
     }
@@ -1556,7 +1556,7 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
     ksplit = cdiv(total_chunks, cps);
     dim3 grid(co_tiles, items, ksplit);
     if (grid.y > 65535 || grid.z > 65535) return SBA_E_ARG;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((wgrad_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
+    SBA_DISPATCH(dtype, SBA_LAUNCH((wgrad_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
                                            (const T*)x, (const T*)dy, dw, *g, M, cps, ksplit > 1 ? 1 : 0, dsub,
                                            dow));
     return SBA_CHECK_LAUNCH();
@@ -1570,13 +1570,13 @@ extern "C" int sba_pack_weight(int dtype, const float* w, void* out, int Cout, i
     if (mode == 1 || mode == 2) {
         dim3 grid(cdiv(Cin, 32), cdiv(Cout, 32), mode == 1 ? KH * KW : 16);
         if (grid.y > 65535) return SBA_E_ARG;
-        SBA_DISPATCH(dtype, hipLaunchKernelGGL((pack_weight_tr_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
+        SBA_DISPATCH(dtype, SBA_LAUNCH((pack_weight_tr_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
                                                w, (T*)out, Cout, KH, KW, Cin, mode));
         return SBA_CHECK_LAUNCH();
     }
     const int64_t n = (int64_t)Cout * (mode == 3 ? 16 : KH * KW) * Cin;
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((pack_weight_kernel<T>), dim3(blocks), dim3(256), 0,
+    SBA_DISPATCH(dtype, SBA_LAUNCH((pack_weight_kernel<T>), dim3(blocks), dim3(256), 0,
                                            (hipStream_t)stream, w, (T*)out, Cout, KH, KW, Cin, mode));
     return SBA_CHECK_LAUNCH();
 }
@@ -1585,7 +1585,7 @@ extern "C" int sba_pack_weights_multi(int dtype, const sba_pack_desc* descs, int
                                       void* stream) {
     if (!descs || ndesc <= 0 || total_tiles <= 0) return SBA_E_ARG;
     if (((uintptr_t)descs & 7) != 0) return SBA_E_ARG;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((pack_multi_kernel<T>), dim3(total_tiles), dim3(256), 0,
+    SBA_DISPATCH(dtype, SBA_LAUNCH((pack_multi_kernel<T>), dim3(total_tiles), dim3(256), 0,
                                            (hipStream_t)stream, descs, ndesc));
     return SBA_CHECK_LAUNCH();
 }
@@ -1594,7 +1594,7 @@ extern "C" int sba_pool2x2_sum(int dtype, const void* dup, void* dx, int N, int 
     if (!dup || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0) return SBA_E_ARG;
     const int64_t total = (int64_t)N * H * W * (C / (dtype == SBA_BF16 ? 8 : 4));
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((pool2x2_kernel<T>), dim3(blocks), dim3(256), 0,
+    SBA_DISPATCH(dtype, SBA_LAUNCH((pool2x2_kernel<T>), dim3(blocks), dim3(256), 0,
                                            (hipStream_t)stream, (const T*)dup, (T*)dx, N, H, W, C));
     return SBA_CHECK_LAUNCH();
 }

@@ -137,7 +137,7 @@ extern "C" int sba_linear_fwd(const float* x, const float* w, const float* bias,
     if (sh > 64 * 1024) return SBA_E_ARG;
     int blocks = cdiv(N, 4);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3(blocks), dim3(256), sh, (hipStream_t)stream, x, w, bias, y, B, K, N);
+    SBA_LAUNCH(linear_fwd_kernel, dim3(blocks), dim3(256), sh, (hipStream_t)stream, x, w, bias, y, B, K, N);
     return SBA_CHECK_LAUNCH();
 }
 
@@ -150,12 +150,12 @@ extern "C" int sba_linear_bwd(const float* x, const float* w, const float* dy, f
     if (dw) {
         int blocks = cdiv(N, 4);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(blocks), dim3(256), sh, st, x, dy, dw, dbias, B, K, N);
+        SBA_LAUNCH(linear_bwd_w_kernel, dim3(blocks), dim3(256), sh, st, x, dy, dw, dbias, B, K, N);
     }
     if (dx) {
         if (hipMemsetAsync(dx, 0, sizeof(float) * B * K, st) != hipSuccess) return SBA_E_LAUNCH;
         const int nper = N >= 4096 ? 64 : (N >= 512 ? 16 : 4);
-        hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(cdiv(N, nper)), dim3(256), 0, st, w, dy, dx, B, K, N, nper);
+        SBA_LAUNCH(linear_bwd_x_kernel, dim3(cdiv(N, nper)), dim3(256), 0, st, w, dy, dx, B, K, N, nper);
     }
     return SBA_CHECK_LAUNCH();
 }
@@ -163,7 +163,7 @@ extern "C" int sba_linear_bwd(const float* x, const float* w, const float* dy, f
 extern "C" int sba_ca_fwd(const float* h, const float* eps, float* c, float* mu, float* logvar, int B, int C,
                           void* stream) {
     if (!h || !eps || !c || !mu || !logvar || B <= 0 || C <= 0) return SBA_E_ARG;
-    hipLaunchKernelGGL(ca_fwd_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, h, eps, c, mu,
+    SBA_LAUNCH(ca_fwd_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, h, eps, c, mu,
                        logvar, B, C);
     return SBA_CHECK_LAUNCH();
 }
@@ -171,7 +171,7 @@ extern "C" int sba_ca_fwd(const float* h, const float* eps, float* c, float* mu,
 extern "C" int sba_ca_bwd(const float* h, const float* eps, const float* dc, const float* dmu, const float* dlogvar,
                           float* dh, int B, int C, void* stream) {
     if (!h || !eps || !dh || B <= 0 || C <= 0) return SBA_E_ARG;
-    hipLaunchKernelGGL(ca_bwd_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, h, eps, dc, dmu,
+    SBA_LAUNCH(ca_bwd_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, h, eps, dc, dmu,
                        dlogvar, dh, B, C);
     return SBA_CHECK_LAUNCH();
 }
@@ -179,7 +179,7 @@ extern "C" int sba_ca_bwd(const float* h, const float* eps, const float* dc, con
 extern "C" int sba_ctx_proj_fwd(const float* words, const float* W, float* src, int B, int idf, int cdf, int L,
                                 void* stream) {
     if (!words || !W || !src || B <= 0 || idf <= 0 || cdf <= 0 || L <= 0) return SBA_E_ARG;
-    hipLaunchKernelGGL(ctx_proj_fwd_kernel, dim3(cdiv((int64_t)B * idf * L, 256)), dim3(256), 0,
+    SBA_LAUNCH(ctx_proj_fwd_kernel, dim3(cdiv((int64_t)B * idf * L, 256)), dim3(256), 0,
                        (hipStream_t)stream, words, W, src, B, idf, cdf, L);
     return SBA_CHECK_LAUNCH();
 }
@@ -188,7 +188,7 @@ extern "C" int sba_ctx_proj_bwd(const float* words, const float* W, const float*
                                 int B, int idf, int cdf, int L, void* stream) {
     if (!words || !W || !dsrc || !dW || B <= 0 || idf <= 0 || cdf <= 0 || L <= 0) return SBA_E_ARG;
     const int total = idf * cdf + (dwords ? B * cdf * L : 0);
-    hipLaunchKernelGGL(ctx_proj_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, words, W,
+    SBA_LAUNCH(ctx_proj_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, words, W,
                        dsrc, dW, dwords, B, idf, cdf, L);
     return SBA_CHECK_LAUNCH();
 }

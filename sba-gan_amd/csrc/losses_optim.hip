@@ -121,7 +121,7 @@ extern "C" const char* sba_version(void) { return "sbagan_hip 0.1 (gfx950)"; }
 extern "C" int sba_bce_multi(const float* prob, const int32_t* offsets, const float* target, const float* weight,
                              int nseg, float* loss, float* dprob, void* stream) {
     if (!prob || !offsets || !target || !weight || !loss || nseg <= 0 || nseg > 64) return SBA_E_ARG;
-    hipLaunchKernelGGL(bce_multi_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, prob, offsets, target, weight,
+    SBA_LAUNCH(bce_multi_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, prob, offsets, target, weight,
                        nseg, loss, dprob);
     return SBA_CHECK_LAUNCH();
 }
@@ -129,13 +129,13 @@ extern "C" int sba_bce_multi(const float* prob, const int32_t* offsets, const fl
 extern "C" int sba_kl_loss(const float* mu, const float* logvar, float* loss, float* dmu, float* dlogvar, int n,
                            void* stream) {
     if (!mu || !logvar || !loss || n <= 0) return SBA_E_ARG;
-    hipLaunchKernelGGL(kl_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mu, logvar, loss, dmu, dlogvar, n);
+    SBA_LAUNCH(kl_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mu, logvar, loss, dmu, dlogvar, n);
     return SBA_CHECK_LAUNCH();
 }
 
 extern "C" int sba_adam_prepare(void* state, float lr, float beta1, float beta2, void* stream) {
     if (!state) return SBA_E_ARG;
-    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (AdamState*)state, lr, beta1,
+    SBA_LAUNCH(adam_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (AdamState*)state, lr, beta1,
                        beta2);
     return SBA_CHECK_LAUNCH();
 }
@@ -149,7 +149,7 @@ extern "C" int sba_adam_step(float* p, const float* g, float* m, float* v, float
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adam_step_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, avg,
+    SBA_LAUNCH(adam_step_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, avg,
                        (bf16_t*)shadow, (const AdamState*)state, n, beta1, beta2, eps, grad_scale);
     return SBA_CHECK_LAUNCH();
 }
@@ -160,13 +160,13 @@ extern "C" int sba_cast(int dtype_dst, void* dst, int dtype_src, const void* src
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
     if (dtype_dst == SBA_BF16 && dtype_src == SBA_F32)
-        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3((int)blocks), dim3(256), 0, st, (bf16_t*)dst,
+        SBA_LAUNCH((cast_kernel<bf16_t, float>), dim3((int)blocks), dim3(256), 0, st, (bf16_t*)dst,
                            (const float*)src, n);
     else if (dtype_dst == SBA_F32 && dtype_src == SBA_BF16)
-        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3((int)blocks), dim3(256), 0, st, (float*)dst,
+        SBA_LAUNCH((cast_kernel<float, bf16_t>), dim3((int)blocks), dim3(256), 0, st, (float*)dst,
                            (const bf16_t*)src, n);
     else if (dtype_dst == SBA_F32 && dtype_src == SBA_F32)
-        hipLaunchKernelGGL((cast_kernel<float, float>), dim3((int)blocks), dim3(256), 0, st, (float*)dst,
+        SBA_LAUNCH((cast_kernel<float, float>), dim3((int)blocks), dim3(256), 0, st, (float*)dst,
                            (const float*)src, n);
     else
         return SBA_E_ARG;

@@ -723,7 +723,7 @@ extern "C" int sba_bn_stats(int dtype, const void* y, float* stats, int64_t rows
     int blocks = cdiv(rows, (int64_t)rpi * 8);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((bn_stats_kernel<T>), dim3(blocks, groups), dim3(256),
+    SBA_DISPATCH(dtype, SBA_LAUNCH((bn_stats_kernel<T>), dim3(blocks, groups), dim3(256),
                                            2 * (size_t)C * sizeof(float), (hipStream_t)stream, (const T*)y, stats,
                                            rows, C));
     return SBA_CHECK_LAUNCH();
@@ -757,7 +757,7 @@ extern "C" int sba_bn_act_fwd(int dtype, const void* y, const float* stats, cons
     if (out_cstride < Co + out_coff || out_cstride % V || out_coff % V) return SBA_E_ARG;
     const int blocks = grid_for(rows * (Co / V));
     const size_t sh = 2 * (size_t)C * sizeof(float);
-    SBA_DISPATCH(dtype, ACT_SWITCH(act, hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACT>), dim3(blocks, groups),
+    SBA_DISPATCH(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_act_fwd_kernel<T, ACT>), dim3(blocks, groups),
                                                            dim3(256), sh, (hipStream_t)stream, (const T*)y, stats,
                                                            gamma, beta, running_mean, running_var,
                                                            num_batches_tracked, aux, (const T*)residual, (T*)out,
@@ -778,7 +778,7 @@ extern "C" int sba_bn_act_bwd_reduce(int dtype, const void* y, const void* dout,
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     const size_t sh = 2 * (size_t)C * sizeof(float);
-    SBA_DISPATCH(dtype, ACT_SWITCH(act, hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, ACT>), dim3(blocks, groups),
+    SBA_DISPATCH(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_reduce_kernel<T, ACT>), dim3(blocks, groups),
                                                            dim3(256), sh, (hipStream_t)stream, (const T*)y,
                                                            (const T*)dout, aux, red, rows, C, dcs, dco)));
     return SBA_CHECK_LAUNCH();
@@ -794,7 +794,7 @@ extern "C" int sba_bn_act_bwd_apply(int dtype, const void* y, const void* dout, 
     if (dcs < Co + dco || dcs % V || dco % V) return SBA_E_ARG;
     const int blocks = grid_for(rows * (Co / V));
     const size_t sh = 6 * (size_t)C * sizeof(float);
-    SBA_DISPATCH(dtype, ACT_SWITCH(act, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, ACT>), dim3(blocks, groups),
+    SBA_DISPATCH(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_apply_kernel<T, ACT>), dim3(blocks, groups),
                                                            dim3(256), sh, (hipStream_t)stream, (const T*)y,
                                                            (const T*)dout, aux, red, (T*)dy, dgamma, dbeta, rows, C,
                                                            dcs, dco)));
@@ -810,7 +810,7 @@ extern "C" int sba_bn_act_fwd_fused(int dtype, const void* y, const float* gamma
     const int Co = act == SBA_ACT_GLU ? C / 2 : C;
     const int V = dtype == SBA_BF16 ? 8 : 4;
     if (out_cstride < Co + out_coff || out_cstride % V || out_coff % V) return SBA_E_ARG;
-    SBA_DISPATCH(dtype, ACT_SWITCH(act, hipLaunchKernelGGL((bn_fwd_fused_kernel<T, ACT>), dim3(Co / V), dim3(256), 0,
+    SBA_DISPATCH(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_fwd_fused_kernel<T, ACT>), dim3(Co / V), dim3(256), 0,
                                                            (hipStream_t)stream, (const T*)y, gamma, beta,
                                                            running_mean, running_var, num_batches_tracked, aux,
                                                            (T*)out, rows, groups, C, out_cstride, out_coff, eps,
@@ -826,7 +826,7 @@ extern "C" int sba_bn_act_bwd_fused(int dtype, const void* y, const void* dout, 
     const int Co = act == SBA_ACT_GLU ? C / 2 : C;
     const int V = dtype == SBA_BF16 ? 8 : 4;
     if (dcs < Co + dco || dcs % V || dco % V) return SBA_E_ARG;
-    SBA_DISPATCH(dtype, ACT_SWITCH(act, hipLaunchKernelGGL((bn_bwd_fused_kernel<T, ACT>), dim3(Co / V, groups),
+    SBA_DISPATCH(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_fused_kernel<T, ACT>), dim3(Co / V, groups),
                                                            dim3(256), 0, (hipStream_t)stream, (const T*)y,
                                                            (const T*)dout, aux, (T*)dy, dgamma, dbeta, rows, C, dcs,
                                                            dco)));
@@ -837,7 +837,7 @@ extern "C" int sba_bn1d_glu_fwd(int dtype, const float* y, const float* gamma, c
                                 float* running_mean, float* running_var, int64_t* nbt, float* mean, float* rstd,
                                 void* out, int B, int F, float eps, float momentum, void* stream) {
     if (!y || !gamma || !beta || !mean || !rstd || !out || B <= 0 || F <= 0 || F % 32 != 0) return SBA_E_ARG;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((bn1d_glu_fwd_kernel<T>), dim3(cdiv(F / 2, 256)), dim3(256), 0,
+    SBA_DISPATCH(dtype, SBA_LAUNCH((bn1d_glu_fwd_kernel<T>), dim3(cdiv(F / 2, 256)), dim3(256), 0,
                                            (hipStream_t)stream, y, gamma, beta, running_mean, running_var, nbt,
                                            mean, rstd, (T*)out, B, F, eps, momentum));
     return SBA_CHECK_LAUNCH();
@@ -849,7 +849,7 @@ extern "C" int sba_bn1d_glu_bwd(int dtype, const float* y, const void* dout, con
     if (!y || !dout || !gamma || !beta || !mean || !rstd || !dy || !dgamma || !dbeta || B <= 0 || F <= 0 ||
         F % 32 != 0)
         return SBA_E_ARG;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((bn1d_glu_bwd_kernel<T>), dim3(cdiv(F / 2, 256)), dim3(256), 0,
+    SBA_DISPATCH(dtype, SBA_LAUNCH((bn1d_glu_bwd_kernel<T>), dim3(cdiv(F / 2, 256)), dim3(256), 0,
                                            (hipStream_t)stream, y, (const T*)dout, gamma, beta, mean, rstd, dy,
                                            dgamma, dbeta, B, F));
     return SBA_CHECK_LAUNCH();
@@ -870,9 +870,9 @@ extern "C" int sba_instnorm_stats(int dtype, const void* h, float* mean, float* 
     const int rpi = 256 / (C / V);
     int splits = cdiv(HW, rpi * 16);
     if (splits > 256) splits = 256;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((instnorm_accum_kernel<T>), dim3(N, splits), dim3(256),
+    SBA_DISPATCH(dtype, SBA_LAUNCH((instnorm_accum_kernel<T>), dim3(N, splits), dim3(256),
                                            2 * C * sizeof(float), st, (const T*)h, mean, rstd, HW, C));
-    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, st, mean, rstd, N * C,
+    SBA_LAUNCH(instnorm_finalize_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, st, mean, rstd, N * C,
                        (float)HW, eps);
     return SBA_CHECK_LAUNCH();
 }
@@ -883,7 +883,7 @@ extern "C" int sba_adain_fwd(int dtype, const void* h, const float* mean, const 
     const int V = dtype == SBA_BF16 ? 8 : 4;
     if (ocs < C + oco || ocs % V || oco % V) return SBA_E_ARG;
     const int blocks = grid_for((int64_t)N * HW * (C / V));
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((adain_fwd_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+    SBA_DISPATCH(dtype, SBA_LAUNCH((adain_fwd_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                                            (const T*)h, mean, rstd, style, (T*)out, N, HW, C, ocs, oco));
     return SBA_CHECK_LAUNCH();
 }
@@ -897,7 +897,7 @@ extern "C" int sba_adain_bwd_reduce(int dtype, const void* h, const void* dout, 
     const int rpi = 256 / (C / V);
     int splits = cdiv(HW, rpi * 16);
     if (splits > 256) splits = 256;
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((adain_bwd_reduce_kernel<T>), dim3(N, splits), dim3(256),
+    SBA_DISPATCH(dtype, SBA_LAUNCH((adain_bwd_reduce_kernel<T>), dim3(N, splits), dim3(256),
                                            2 * C * sizeof(float), (hipStream_t)stream, (const T*)h,
                                            (const T*)dout, mean, rstd, red, HW, C, dcs, dco));
     return SBA_CHECK_LAUNCH();
@@ -911,7 +911,7 @@ extern "C" int sba_adain_bwd_apply(int dtype, const void* h, const void* dout, c
     const int V = dtype == SBA_BF16 ? 8 : 4;
     if (dcs < C + dco || dcs % V || dco % V) return SBA_E_ARG;
     const int blocks = grid_for((int64_t)N * HW * (C / V));
-    SBA_DISPATCH(dtype, hipLaunchKernelGGL((adain_bwd_apply_kernel<T>), dim3(blocks), dim3(256), 0,
+    SBA_DISPATCH(dtype, SBA_LAUNCH((adain_bwd_apply_kernel<T>), dim3(blocks), dim3(256), 0,
                                            (hipStream_t)stream, (const T*)h, (const T*)dout, mean, rstd, style,
                                            red, (T*)dh, dstyle, N, HW, C, dcs, dco, accumulate));
     return SBA_CHECK_LAUNCH();

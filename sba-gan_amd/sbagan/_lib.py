@@ -6,6 +6,10 @@ no CPU or PyTorch fallback behind these calls.
 """
 import ctypes
 import os
+
+import torch  # noqa: F401  -- FIRST: PyTorch-ROCm brings its own libamdhip64; if this library is loaded before
+#                     it, it binds /opt/rocm's copy and its kernels are registered with a HIP runtime that does
+#                     not own torch's streams (every launch then fails)
 from ctypes import (POINTER, Structure, byref, c_char_p, c_float, c_int, c_int8, c_int32, c_int64,
                     c_void_p)
 
