@@ -256,7 +256,7 @@ def main():
     for _ in range(n_eager):
         out = one_step()
     torch.cuda.synchronize()
-    if args.graph and world == 1:
+    if args.graph:
         try:
             from sbagan.trainer import GraphedStep
             graph = GraphedStep(step, b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'],
@@ -267,7 +267,7 @@ def main():
                 graph.replay()
             torch.cuda.synchronize()
             mode = 'hipgraph'
-            if args.graph == 2:
+            if args.graph == 2 and world == 1:
                 def probe(fn, n=4):
                     torch.cuda.synchronize()
                     t = time.perf_counter()
@@ -284,6 +284,11 @@ def main():
             sys.stderr.write('graph capture failed (%s: %s); timing eager launches\n' % (type(e).__name__, e))
             graph = None
             torch.cuda.synchronize()
+        if world > 1:       # every rank must issue the same sequence of collectives: graphs only if ALL captured
+            ok = torch.tensor([1 if graph is not None else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok) == 0:
+                graph, mode = None, 'eager'
 
     def sync_all():
         torch.cuda.synchronize()

@@ -170,9 +170,9 @@ class GANStep(object):
         self._ctx = (fake_imgs, mu, logvar)
         self._out = {}
 
-    def phase_d(self, i, imgs, sent_emb, forked):
-        """Update of discriminator i on the CURRENT stream; returns the stream its Adam step was issued
-        on (the weight-gradient companion when `forked`, see ops.wgrad_tail_stream)."""
+    def phase_d_bwd(self, i, imgs, sent_emb, forked):
+        """loss + backward of discriminator i on the CURRENT stream; returns the stream on which the update
+        must continue (the weight-gradient companion when `forked`, see ops.wgrad_tail_stream)."""
         fake_imgs = self._ctx[0]
         ops.SIDE_WGRAD = self.overlap_wgrad and self.overlap_wgrad_d
         self.flatD[i].zero_grad()
@@ -185,13 +185,21 @@ class GANStep(object):
         else:
             ops.join_wgrads()
             tail = torch.cuda.current_stream()
-        with torch.cuda.stream(tail):
-            self._allreduce_wait(self._allreduce_start(self.flatD[i]))
-            self.optD[i].step(1.0 / self.world)
         ops.SIDE_WGRAD = self.overlap_wgrad
         return tail
 
-    def phase_b(self, sent_emb, words_embs, cap_lens, class_ids):
+    def phase_d_opt(self, i):
+        """Adam step of discriminator i (its averaged gradient must be in place)."""
+        self.optD[i].step(1.0 / self.world)
+
+    def phase_d(self, i, imgs, sent_emb, forked):
+        tail = self.phase_d_bwd(i, imgs, sent_emb, forked)
+        with torch.cuda.stream(tail):
+            self._allreduce_wait(self._allreduce_start(self.flatD[i]))
+            self.phase_d_opt(i)
+        return tail
+
+    def phase_b_bwd(self, sent_emb, words_embs, cap_lens, class_ids):
         fake_imgs, mu, logvar = self._ctx
         mark = self._mark
         for p in self._d_params:
@@ -208,19 +216,24 @@ class GANStep(object):
         mark('g_backward')
         for p in self._d_params:
             p.requires_grad_(True)
-        h = self._allreduce_start(self.flatG)
-        self._allreduce_wait(h)
-        self.optG.step(1.0 / self.world)
-        mark('g_adam')
         out = self._out
         out['errG_total'] = errG_total.detach()
         out['kl_loss'] = kl.detach()
         out.update(logs)
         self.fake_imgs = [f.detach() for f in fake_imgs]
         self._ctx = None
+
+    def phase_b_opt(self):
+        self.optG.step(1.0 / self.world)
+        self._mark('g_adam')
         ops.ARENA.end()
         ops.SIDE_WGRAD = False
-        return out
+        return self._out
+
+    def phase_b(self, sent_emb, words_embs, cap_lens, class_ids):
+        self.phase_b_bwd(sent_emb, words_embs, cap_lens, class_ids)
+        self._allreduce_wait(self._allreduce_start(self.flatG))
+        return self.phase_b_opt()
 
     def step(self, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, eps=None):
         """Returns a dict of DEVICE scalars (errD0.., errG_total, kl_loss, g_loss*, w_loss, s_loss)."""
@@ -269,6 +282,11 @@ class GANStep(object):
         return flat.grad.double().norm()
 
 
+# "thread_local": only the capturing thread is policed -- the process group's watchdog thread polls events
+# concurrently and would otherwise invalidate a capture in multi-rank runs
+_CAPTURE_MODE = 'thread_local'
+
+
 class GraphedStep(object):
     """GANStep replayed from captured hipGraphs: one graph for the generator forward, one PER
     DISCRIMINATOR update -- replayed concurrently, each on its own stream -- and one for the generator
@@ -280,7 +298,7 @@ class GraphedStep(object):
     def __init__(self, gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, prologue=None,
                  single=False):
         self.gan = gan
-        self.single = single
+        self.single = single and not gan.distributed
         dev = gan.device
         nD = len(gan.netsD)
         self.cap = torch.cuda.Stream(device=dev)
@@ -297,21 +315,37 @@ class GraphedStep(object):
         torch.cuda.synchronize()
         self.gA, self.gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         self.gD = [torch.cuda.CUDAGraph() for _ in range(nD)]
-        if single:       # the whole step as ONE graph, discriminator updates as forked branches
-            with torch.cuda.graph(self.gA, stream=self.cap):
+        if single and not gan.distributed:       # the whole step as ONE graph, discriminator updates as forked branches
+            with torch.cuda.graph(self.gA, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
                 if prologue is not None:
                     prologue()
                 self.out = gan.step(imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise)
             torch.cuda.synchronize()
             return
-        with torch.cuda.graph(self.gA, stream=self.cap):
+        with torch.cuda.graph(self.gA, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
             if prologue is not None:
                 prologue()
             gan.phase_a(sent_emb, words_embs, mask, noise)
+        if gan.distributed:
+            # the gradient exchange (RCCL) stays OUTSIDE the graphs: per network one graph for loss +
+            # backward and one for the Adam step, the all-reduce issued eagerly between them
+            self.gDo = [torch.cuda.CUDAGraph() for _ in range(nD)]
+            self.gBo = torch.cuda.CUDAGraph()
+            for i in range(nD):
+                with torch.cuda.graph(self.gD[i], stream=self.cap, capture_error_mode=_CAPTURE_MODE):
+                    gan.phase_d_bwd(i, imgs, sent_emb, forked=False)
+                with torch.cuda.graph(self.gDo[i], stream=self.cap, capture_error_mode=_CAPTURE_MODE):
+                    gan.phase_d_opt(i)
+            with torch.cuda.graph(self.gB, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
+                gan.phase_b_bwd(sent_emb, words_embs, cap_lens, class_ids)
+            with torch.cuda.graph(self.gBo, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
+                self.out = gan.phase_b_opt()
+            torch.cuda.synchronize()
+            return
         for i in range(nD):
-            with torch.cuda.graph(self.gD[i], stream=self.dstreams[i]):
+            with torch.cuda.graph(self.gD[i], stream=self.dstreams[i], capture_error_mode=_CAPTURE_MODE):
                 gan.phase_d(i, imgs, sent_emb, forked=False)
-        with torch.cuda.graph(self.gB, stream=self.cap):
+        with torch.cuda.graph(self.gB, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
             self.out = gan.phase_b(sent_emb, words_embs, cap_lens, class_ids)
         torch.cuda.synchronize()
 
@@ -319,6 +353,21 @@ class GraphedStep(object):
         main = torch.cuda.current_stream()
         self.gA.replay()
         if self.single:
+            return self.out
+        gan = self.gan
+        if gan.distributed:
+            # largest network first: its all-reduce (D256: 287 MB) then runs under the other updates
+            order = sorted(range(len(self.gD)), key=lambda i: -gan.flatD[i].n)
+            handles = {}
+            for i in order:
+                self.gD[i].replay()
+                handles[i] = gan._allreduce_start(gan.flatD[i])
+            for i in order:
+                gan._allreduce_wait(handles[i])
+                self.gDo[i].replay()
+            self.gB.replay()
+            gan._allreduce_wait(gan._allreduce_start(gan.flatG))
+            self.gBo.replay()
             return self.out
         for i, st in enumerate(self.dstreams):
             st.wait_stream(main)
