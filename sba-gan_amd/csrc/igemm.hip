@@ -1342,7 +1342,8 @@ struct IgemmCfg { int bm, bn, ks, occ; float eff; bool split; };
 // E: skinny GEMM tile for the 4x4 / 8x8 maps with thousands of channels (+split-K)
 // (The kernel also instantiates with KG > 1 in-workgroup K-groups and PF = 3 stages of loads in flight;
 // on the latency-bound small layers neither beat D -- 1 KB of LDS fragments per MFMA and one wave per
-// SIMD bound them, not the K loop -- so no shipped configuration uses them.)
+// SIMD bound them, not the K loop -- so no shipped configuration uses them.  A 256x128 tile with 128x64
+// per-wave tiles (less LDS traffic per MFMA, but 4 waves and one workgroup per CU) lost to E everywhere.)
 static const IgemmCfg kCfg[5] = {
     {128, 128, 1, 3, 1.00f, false}, {256, 64, 1, 3, 1.00f, false}, {128, 64, 2, 2, 0.80f, false},
     {64, 64, 2, 3, 0.50f, true},    {320, 128, 2, 1, 0.90f, true}};
@@ -1420,7 +1421,7 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
     const int wgA = (g.Cout % 128 == 0) ? cdiv(M, 128) * (g.Cout / 128) : 0;
     if (M <= 2048) {
         best = (g.Cout >= 1024 && (nslabs >= 512 || (M >= 1280 && nslabs >= 256))) ? 4 : 3;
-    } else if (g.Cout == 128 && M >= 40000) {
+    } else if ((g.Cout == 128 && M >= 40000) || (g.Cout == 256 && M >= 40000 && nslabs >= 48)) {
         best = 4;
     } else if (wgA >= 320) {
         best = 0;
