@@ -123,16 +123,40 @@ __global__ __launch_bounds__(NT) void damsm_words_fwd_kernel(
         }
     }
     __syncthreads();
-    // phase 3: wctx[c][t] = sum_r f[c][r] A[t][r], feature staged CCH channels at a time
-    for (int c0 = 0; c0 < nef; c0 += CCH) {
-        for (int k = tid; k < CCH * R; k += NT) L.f[k] = fj[(int64_t)c0 * R + k];
-        __syncthreads();
-        for (int o = tid; o < CCH * T; o += NT) {
-            const int cl = o / T, t = o - cl * T;
-            float acc = 0.f;
-            for (int r = 0; r < R; ++r) acc += L.f[cl * R + r] * L.z[t * R + r];
-            L.w[(c0 + cl) * LP + t] = acc;
-            wctx_o[(pair * Lw + t) * nef + c0 + cl] = acc;
+    // phase 3: wctx[c][t] = sum_r f[c][r] A[t][r] on the f32 matrix cores: M = 32 channels per tile, N = words
+    // (32 columns, T valid), K = regions.  The feature rows are read straight from L2 (296 KB per image,
+    // shared by the B workgroups of that image), the attention from LDS; 8 loads per lane in flight.
+    // (As a VALU loop with two LDS reads per FMA this phase was 78 % of the kernel.)
+    {
+        const int rl = lane & 31, hf = lane >> 5;
+        const bool tv = rl < T;
+        const int steps = (R + 1) / 2;
+        for (int ct = wid; ct < nef / 32; ct += nw) {
+            f32x16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* fr = fj + (int64_t)(ct * 32 + rl) * R + hf;
+            const float* zr = L.z + rl * R + hf;
+            for (int kk0 = 0; kk0 < steps; kk0 += 8) {
+                float av[8], bv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int kk = kk0 + u;
+                    const bool ok = kk < steps && 2 * kk + hf < R;
+                    av[u] = ok ? fr[2 * kk] : 0.f;
+                    bv[u] = (ok && tv) ? zr[2 * kk] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+            }
+            if (tv) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                    L.w[c * LP + rl] = acc[r];
+                    wctx_o[(pair * Lw + rl) * nef + c] = acc[r];
+                }
+            }
         }
         __syncthreads();
     }
@@ -267,20 +291,44 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
             ds[t] = t < T ? dA[t] * (ds[t] - dot1) : 0.f;
             if (t < T) L.z[t * R + tid] = ds[t];
         }
-        // pass B: dfeat[c][r] += sum_t dwctx[c][t] A[t][r] + dS[r][t] q[c][t]  (padding columns are zero)
-        for (int c = 0; c < nef; ++c) {
-            const float4* wr = reinterpret_cast<const float4*>(&L.w[c * LP]);
-            const float4* qr = reinterpret_cast<const float4*>(&L.q[c * LP]);
-            float acc = 0.f;
+    }
+    __syncthreads();
+    // pass B: dfeat[c][r] += sum_t dwctx[c][t] A[t][r] + q[c][t] dS[t][r] on the f32 matrix cores: 32 x 32
+    // (channel x region) tiles, K = the (<= LP) words, two MFMA chains per step.  A[t][r] comes from the
+    // attention the forward stored (L2-resident, coalesced over regions), dS from LDS.
+    {
+        const int rl = lane & 31, hf = lane >> 5;
+        const int rtiles = (R + 31) / 32;
+        for (int tl = wid; tl < (nef / 32) * rtiles; tl += nw) {
+            const int ct = tl / rtiles, rt = tl - ct * rtiles;
+            const int r = rt * 32 + rl;
+            const bool rv = r < R;
+            f32x16_t acc;
 #pragma unroll
-            for (int t4 = 0; t4 < LP / 4; ++t4) {
-                const float4 wv = wr[t4], qv = qr[t4];
-                acc += wv.x * av[4 * t4] + ds[4 * t4] * qv.x;
-                acc += wv.y * av[4 * t4 + 1] + ds[4 * t4 + 1] * qv.y;
-                acc += wv.z * av[4 * t4 + 2] + ds[4 * t4 + 2] * qv.z;
-                acc += wv.w * av[4 * t4 + 3] + ds[4 * t4 + 3] * qv.w;
+            for (int q2 = 0; q2 < 16; ++q2) acc[q2] = 0.f;
+            const float* wr = L.w + (ct * 32 + rl) * LP + hf;
+            const float* qr = L.q + (ct * 32 + rl) * LP + hf;
+            float a1[LP / 2], b1[LP / 2], b2[LP / 2];
+#pragma unroll
+            for (int kk = 0; kk < LP / 2; ++kk) {
+                const int t = 2 * kk + hf;
+                const bool ok = rv && t < T;
+                b1[kk] = ok ? attn[(pair * Lw + t) * R + r] : 0.f;
+                b2[kk] = ok ? L.z[t * R + r] : 0.f;
+                a1[kk] = wr[2 * kk];
             }
-            atomicAdd(&dfeat[((int64_t)j * nef + c) * R + tid], acc);
+#pragma unroll
+            for (int kk = 0; kk < LP / 2; ++kk) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[kk], b1[kk], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qr[2 * kk], b2[kk], acc, 0, 0, 0);
+            }
+            if (rv) {
+#pragma unroll
+                for (int q2 = 0; q2 < 16; ++q2) {
+                    const int c = ct * 32 + (q2 & 3) + 8 * (q2 >> 2) + 4 * hf;
+                    atomicAdd(&dfeat[((int64_t)j * nef + c) * R + r], acc[q2]);
+                }
+            }
         }
     }
     if (dwords) {
@@ -384,7 +432,7 @@ extern "C" int sba_damsm_words_fwd(const float* feat, const float* words, const 
                                    float* attn, float* attn1, float* wctx, int B, int nef, int R, int L,
                                    float gamma1, float gamma2, void* stream) {
     if (!feat || !words || !cap_lens || !sim || !attn || !attn1 || !wctx) return SBA_E_ARG;
-    if (B <= 0 || B > 1024 || nef <= 0 || nef % CCH || R <= 0 || R > NT || L <= 0 || L > TMAX) return SBA_E_ARG;
+    if (B <= 0 || B > 1024 || nef <= 0 || nef % 32 || R <= 0 || R > NT || L <= 0 || L > TMAX) return SBA_E_ARG;
     const int LP = L <= 20 ? 20 : 32;
     const size_t sh = lds_bytes(nef, LP, L, R);
     if (sh > 160 * 1024) return SBA_E_ARG;
@@ -407,7 +455,7 @@ extern "C" int sba_damsm_words_bwd(const float* feat, const float* words, const 
                                    float* dfeat, float* dwords, int B, int nef, int R, int L, float gamma1,
                                    float gamma2, void* stream) {
     if (!feat || !words || !cap_lens || !sim || !attn || !attn1 || !wctx || !dsim || !dfeat) return SBA_E_ARG;
-    if (B <= 0 || B > 1024 || nef <= 0 || nef % CCH || R <= 0 || R > NT || L <= 0 || L > TMAX) return SBA_E_ARG;
+    if (B <= 0 || B > 1024 || nef <= 0 || nef % 32 || R <= 0 || R > NT || L <= 0 || L > TMAX) return SBA_E_ARG;
     const int LP = L <= 20 ? 20 : 32;
     const size_t sh = lds_bytes(nef, LP, L, R);
     if (sh > 160 * 1024) return SBA_E_ARG;
