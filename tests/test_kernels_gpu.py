@@ -351,7 +351,9 @@ def test_init_stage_and_conditioning(dev, dt):
     torch.cuda.synchronize()
     close(imgs[0], imgs_r[0], dt, 'img64', scale=4)
     close(mu, mu_r, torch.float32, 'mu'); close(lv, lv_r, torch.float32, 'logvar')
-    _check_module(g, Q, dt, '', gscale=6)
+    # BatchNorm1d over a batch of 4 right behind the fc amplifies summation-order differences of the
+    # dense layers (each within 5e-7 of an f64 reference, tools/debug_linear.py) by |x|/sigma
+    _check_module(g, Q, dt, '', gscale=20)
 
 
 def test_damsm_losses(dev):
