@@ -177,6 +177,81 @@ __global__ __launch_bounds__(64) void linear_bwd_w_mfma_kernel(const float* __re
     }
 }
 
+// attention key projection (conv_context, GlobalAttention.py:75,97) on the f32 matrix cores.
+// forward: src[b][i][l] = sum_c W[i][c] words[b][c][l]: rows = (b, l) pairs, 32 per wave; columns = i.
+__global__ __launch_bounds__(64) void ctx_proj_fwd_mfma_kernel(const float* __restrict__ words, const float* __restrict__ W,
+                                                               float* __restrict__ src, int B, int idf, int cdf, int L) {
+    const int lane = threadIdx.x, rl = lane & 31, hf = lane >> 5;
+    const int row = blockIdx.x * 32 + rl;                 // (b, l)
+    const bool rv = row < B * L;
+    const int b = rv ? row / L : 0, l = rv ? row - b * L : 0;
+    const int i = blockIdx.y * 32 + rl;
+    const bool iv = i < idf;
+    const float* wp = words + ((int64_t)b * cdf + hf) * L + l;      // + 2*kk*L per step
+    const float* Wr = W + (int64_t)(iv ? i : 0) * cdf;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int c0 = 0; c0 < cdf; c0 += 32) {                 // 16 steps of 2 channels
+        float av[16];
+        float4 wv[8];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) av[kk] = (rv && c0 + 2 * kk + hf < cdf) ? wp[(int64_t)(c0 + 2 * kk) * L] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            wv[u] = (iv && c0 + 4 * u < cdf) ? *reinterpret_cast<const float4*>(Wr + c0 + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float4 q = wv[kk >> 1];
+            const float bq = (kk & 1) ? (hf ? q.w : q.z) : (hf ? q.y : q.x);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bq, acc, 0, 0, 0);
+        }
+    }
+    if (iv) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = blockIdx.x * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            if (rr < B * L) {
+                const int bb = rr / L, ll = rr - bb * L;
+                src[((int64_t)bb * idf + i) * L + ll] = acc[r];
+            }
+        }
+    }
+}
+
+// dW[i][c] += sum_{b,l} dsrc[b][i][l] words[b][c][l]: tile = 32 i x 32 c, reduction over the B*L positions
+__global__ __launch_bounds__(64) void ctx_proj_bwd_w_mfma_kernel(const float* __restrict__ words,
+                                                                 const float* __restrict__ dsrc, float* __restrict__ dW,
+                                                                 int B, int idf, int cdf, int L) {
+    const int lane = threadIdx.x, rl = lane & 31, hf = lane >> 5;
+    const int c = blockIdx.x * 32 + rl, i = blockIdx.y * 32 + rl;
+    const bool cv = c < cdf, iv = i < idf;
+    const int P = B * L;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int p0 = 0; p0 < P; p0 += 16) {                   // 8 steps of 2 positions
+        float av[8], bv[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int p = p0 + 2 * kk + hf;
+            const bool ok = p < P;
+            const int b = ok ? p / L : 0, l = ok ? p - b * L : 0;
+            av[kk] = (ok && iv) ? dsrc[((int64_t)b * idf + i) * L + l] : 0.f;
+            bv[kk] = (ok && cv) ? words[((int64_t)b * cdf + c) * L + l] : 0.f;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
+    }
+    if (cv) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ii = blockIdx.y * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            if (ii < idf) dW[(int64_t)ii * cdf + c] += acc[r];
+        }
+    }
+}
+
 // CA_NET tail: h[B][4C]: GLU -> x[0..2C) = h[:, :2C] * sigmoid(h[:, 2C:]); mu = x[:C], logvar = x[C:]
 __global__ void ca_fwd_kernel(const float* __restrict__ h, const float* __restrict__ eps, float* __restrict__ c,
                               float* __restrict__ mu, float* __restrict__ logvar, int B, int C) {
@@ -305,6 +380,11 @@ extern "C" int sba_ca_bwd(const float* h, const float* eps, const float* dc, con
 extern "C" int sba_ctx_proj_fwd(const float* words, const float* W, float* src, int B, int idf, int cdf, int L,
                                 void* stream) {
     if (!words || !W || !src || B <= 0 || idf <= 0 || cdf <= 0 || L <= 0) return SBA_E_ARG;
+    if (cdf % 4 == 0) {
+        SBA_LAUNCH(ctx_proj_fwd_mfma_kernel, dim3(cdiv((int64_t)B * L, 32), cdiv(idf, 32)), dim3(64), 0,
+                   (hipStream_t)stream, words, W, src, B, idf, cdf, L);
+        return SBA_CHECK_LAUNCH();
+    }
     SBA_LAUNCH(ctx_proj_fwd_kernel, dim3(cdiv((int64_t)B * idf * L, 256)), dim3(256), 0,
                        (hipStream_t)stream, words, W, src, B, idf, cdf, L);
     return SBA_CHECK_LAUNCH();
@@ -313,6 +393,11 @@ extern "C" int sba_ctx_proj_fwd(const float* words, const float* W, float* src, 
 extern "C" int sba_ctx_proj_bwd(const float* words, const float* W, const float* dsrc, float* dW, float* dwords,
                                 int B, int idf, int cdf, int L, void* stream) {
     if (!words || !W || !dsrc || !dW || B <= 0 || idf <= 0 || cdf <= 0 || L <= 0) return SBA_E_ARG;
+    if (!dwords) {      // GAN training: the word embeddings carry no gradient -- only dW, on the matrix cores
+        SBA_LAUNCH(ctx_proj_bwd_w_mfma_kernel, dim3(cdiv(cdf, 32), cdiv(idf, 32)), dim3(64), 0, (hipStream_t)stream,
+                   words, dsrc, dW, B, idf, cdf, L);
+        return SBA_CHECK_LAUNCH();
+    }
     const int total = idf * cdf + (dwords ? B * cdf * L : 0);
     SBA_LAUNCH(ctx_proj_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, words, W,
                        dsrc, dW, dwords, B, idf, cdf, L);
