@@ -104,8 +104,9 @@ __global__ __launch_bounds__(64) void linear_fwd_mfma_kernel(const float* __rest
 }
 
 // dx[b][k] = sum_n dy[b][n] w[n][k]: tile = 32 input features, reduction over N
+// blockIdx.y = slice of `nper` output features of the reduction (atomic accumulation when sliced)
 __global__ __launch_bounds__(64) void linear_bwd_x_mfma_kernel(const float* __restrict__ w, const float* __restrict__ dy,
-                                                               float* __restrict__ dx, int B, int K, int N) {
+                                                               float* __restrict__ dx, int B, int K, int N, int nper) {
     const int lane = threadIdx.x, rl = lane & 31, hf = lane >> 5;
     const int k = blockIdx.x * 32 + rl;
     const bool kv = k < K, bv = rl < B;
@@ -114,17 +115,18 @@ __global__ __launch_bounds__(64) void linear_bwd_x_mfma_kernel(const float* __re
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int n0 = 0; n0 < N; n0 += 32) {
+    const int n_lo = blockIdx.y * nper, n_hi = min(n_lo + nper, N);
+    for (int n0 = n_lo; n0 < n_hi; n0 += 32) {
         float4 dv[8];
         float wv[16];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            dv[u] = (bv && n0 + 4 * u < N) ? *reinterpret_cast<const float4*>(dr + n0 + 4 * u)
+            dv[u] = (bv && n0 + 4 * u < n_hi) ? *reinterpret_cast<const float4*>(dr + n0 + 4 * u)
                                            : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const int n = n0 + 2 * kk + hf;
-            wv[kk] = (kv && n < N) ? wc[(int64_t)n * K] : 0.f;
+            wv[kk] = (kv && n < n_hi) ? wc[(int64_t)n * K] : 0.f;
         }
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
@@ -137,7 +139,10 @@ __global__ __launch_bounds__(64) void linear_bwd_x_mfma_kernel(const float* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int b = (r & 3) + 8 * (r >> 2) + 4 * hf;
-            if (b < B) dx[(int64_t)b * K + k] = acc[r];
+            if (b < B) {
+                if (gridDim.y > 1) atomicAdd(&dx[(int64_t)b * K + k], acc[r]);
+                else dx[(int64_t)b * K + k] = acc[r];
+            }
         }
     }
 }
@@ -343,7 +348,7 @@ extern "C" int sba_linear_bwd(const float* x, const float* w, const float* dy, f
     hipStream_t st = (hipStream_t)stream;
     if (B <= 32 && N % 4 == 0 && N <= 2048) {
         if (dw) SBA_LAUNCH(linear_bwd_w_mfma_kernel, dim3(cdiv(K, 32), cdiv(N, 32)), dim3(64), 0, st, x, dy, dw, dbias, B, K, N);
-        if (dx) SBA_LAUNCH(linear_bwd_x_mfma_kernel, dim3(cdiv(K, 32)), dim3(64), 0, st, w, dy, dx, B, K, N);
+        if (dx) SBA_LAUNCH(linear_bwd_x_mfma_kernel, dim3(cdiv(K, 32)), dim3(64), 0, st, w, dy, dx, B, K, N, N);
         return SBA_CHECK_LAUNCH();
     }
     const size_t sh = sizeof(float) * B * K;
@@ -353,7 +358,11 @@ extern "C" int sba_linear_bwd(const float* x, const float* w, const float* dy, f
         if (blocks > 2048) blocks = 2048;
         SBA_LAUNCH(linear_bwd_w_kernel, dim3(blocks), dim3(256), sh, st, x, dy, dw, dbias, B, K, N);
     }
-    if (dx) {
+    if (dx && B <= 32 && N % 32 == 0) {    // wide layer (INIT_STAGE_G.fc): the reduction sliced over workgroups
+        if (hipMemsetAsync(dx, 0, sizeof(float) * B * K, st) != hipSuccess) return SBA_E_LAUNCH;
+        const int nper = 512;
+        SBA_LAUNCH(linear_bwd_x_mfma_kernel, dim3(cdiv(K, 32), cdiv(N, nper)), dim3(64), 0, st, w, dy, dx, B, K, N, nper);
+    } else if (dx) {
         if (hipMemsetAsync(dx, 0, sizeof(float) * B * K, st) != hipSuccess) return SBA_E_LAUNCH;
         const int nper = N >= 4096 ? 64 : (N >= 512 ? 16 : 4);
         SBA_LAUNCH(linear_bwd_x_kernel, dim3(cdiv(N, nper)), dim3(256), 0, st, w, dy, dx, B, K, N, nper);

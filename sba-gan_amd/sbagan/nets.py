@@ -145,6 +145,8 @@ def pack_group(net):
         elif isinstance(m, ResBlock):
             l1, l2 = m._layers()
             layers += [(l1.pw, '3x3'), (l2.pw, '3x3')]
+        elif isinstance(m, _EncodeBy16):
+            layers += [(l.pw, '4x4s2') for l in m._layers()]
     return ops.PackGroup(layers) if layers else None
 
 
@@ -409,7 +411,8 @@ class _EncodeBy16(nn.Sequential):
 
     def _layers(self):
         if '_ls' not in self.__dict__:
-            self.__dict__['_ls'] = [_Layer(self[2], self[3]), _Layer(self[5], self[6]), _Layer(self[8], self[9])]
+            self.__dict__['_ls'] = [_Layer(self[2], self[3], '4x4s2'), _Layer(self[5], self[6], '4x4s2'),
+                                    _Layer(self[8], self[9], '4x4s2')]
         return self.__dict__['_ls']
 
     def forward(self, x, groups=1):
