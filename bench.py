@@ -310,6 +310,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     finite = all(bool(torch.isfinite(v).all()) for v in out.values() if torch.is_tensor(v))
+    if not finite and rank == 0:
+        sys.stderr.write('WARNING: non-finite losses after the timed steps -- the measurement is not a valid '
+                         'training step (config.losses_finite = false)\n')
     ips = world * args.batch * args.steps / dt
     res = {
         'metric': 'images/sec (G+D step) at %dpx' % (64 * 2 ** (args.branch - 1)),

@@ -96,3 +96,18 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
     } while (0)
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Accumulators are cleared by a KERNEL, never by hipMemsetAsync: a memset node captured into a hipGraph is not
+// reliably ordered before the kernel node that follows it on ROCm 7.2 (the accumulation can run first and the
+// memset then wipes it; seen as instance-norm statistics of 0 / eps on replays, tools/debug_gA.py).
+static __global__ void sba_zero_f32_kernel(float* __restrict__ a, float* __restrict__ b, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        a[i] = 0.f;
+        if (b) b[i] = 0.f;
+    }
+}
+static inline void sba_zero_f32(float* a, float* b, int64_t n, hipStream_t st) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(sba_zero_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, n);
+}

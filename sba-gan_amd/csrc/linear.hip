@@ -359,11 +359,11 @@ extern "C" int sba_linear_bwd(const float* x, const float* w, const float* dy, f
         SBA_LAUNCH(linear_bwd_w_kernel, dim3(blocks), dim3(256), sh, st, x, dy, dw, dbias, B, K, N);
     }
     if (dx && B <= 32 && N % 32 == 0) {    // wide layer (INIT_STAGE_G.fc): the reduction sliced over workgroups
-        if (hipMemsetAsync(dx, 0, sizeof(float) * B * K, st) != hipSuccess) return SBA_E_LAUNCH;
+        sba_zero_f32(dx, nullptr, (int64_t)B * K, st);
         const int nper = 512;
         SBA_LAUNCH(linear_bwd_x_mfma_kernel, dim3(cdiv(K, 32), cdiv(N, nper)), dim3(64), 0, st, w, dy, dx, B, K, N, nper);
     } else if (dx) {
-        if (hipMemsetAsync(dx, 0, sizeof(float) * B * K, st) != hipSuccess) return SBA_E_LAUNCH;
+        sba_zero_f32(dx, nullptr, (int64_t)B * K, st);
         const int nper = N >= 4096 ? 64 : (N >= 512 ? 16 : 4);
         SBA_LAUNCH(linear_bwd_x_kernel, dim3(cdiv(N, nper)), dim3(256), 0, st, w, dy, dx, B, K, N, nper);
     }

@@ -864,8 +864,7 @@ extern "C" int sba_instnorm_stats(int dtype, const void* h, float* mean, float* 
                                   float eps, void* stream) {
     if (!h || !mean || !rstd || !in_shape_ok(dtype, N, HW, C)) return SBA_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(mean, 0, sizeof(float) * N * C, st) != hipSuccess) return SBA_E_LAUNCH;
-    if (hipMemsetAsync(rstd, 0, sizeof(float) * N * C, st) != hipSuccess) return SBA_E_LAUNCH;
+    sba_zero_f32(mean, rstd, (int64_t)N * C, st);
     const int V = dtype == SBA_BF16 ? 8 : 4;
     const int rpi = 256 / (C / V);
     int splits = cdiv(HW, rpi * 16);

@@ -247,6 +247,76 @@ def test_full_size_step_properties(dev):
     assert int(st.netG.h_net1.upsample1[2].num_batches_tracked) == 1
 
 
+def test_graph_replay_matches_eager_generator(dev):
+    """hipGraph replay of the generator forward (phase A of GraphedStep) reproduces the eager forward on the
+    same noise / eps on EVERY replay.  Regression test: a hipMemsetAsync captured as a graph memset node is not
+    reliably ordered before the next kernel node on ROCm 7.2 -- the instance-norm accumulators of the AdaIN
+    stages were wiped after the accumulation on replays >= 1 (images of stages 2/3 collapsed), so the library
+    now clears accumulators with a kernel (csrc/common.h sba_zero_f32)."""
+    from sbagan import ops
+    from sbagan.synth import synthetic_batch
+    ops.set_compute_dtype(torch.bfloat16)
+    B = 20
+    st = _build_step(dev, B)
+    b = synthetic_batch(B, device=dev, seed=100)
+    noise = torch.randn((B, 100), device=dev)
+    netG = st.netG
+    netG.ca_net.eps = torch.randn((B, 100), device=dev)
+
+    def fwd():
+        ops.ARENA.begin(dev)
+        with torch.no_grad():
+            r = netG(noise, b['sent_emb'], b['words_embs'], b['mask'])[0]
+        ops.ARENA.end()
+        return r
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        fwd()                                        # warm the capture stream (workspaces, packed weights)
+        ref = [x.float().clone() for x in fwd()]
+    torch.cuda.current_stream().wait_stream(cap)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=cap, capture_error_mode='thread_local'):
+        imgs = fwd()
+    for r in range(4):
+        g.replay()
+        torch.cuda.synchronize()
+        for i, (a, c) in enumerate(zip(imgs, ref)):
+            assert rel_l2(a.float(), c) <= 3e-2, 'replay %d stage %d' % (r, i)     # bf16 + atomic-order noise
+    netG.ca_net.eps = None
+
+
+def test_graphed_step_tracks_eager_step(dev):
+    """GraphedStep (one graph per phase, discriminator updates on their own streams) after a few eager steps:
+    every replay keeps all losses finite and close to the eager trajectory's level (no collapse of a stage)."""
+    from sbagan import ops
+    from sbagan.synth import synthetic_batch
+    from sbagan.trainer import GraphedStep
+    ops.set_compute_dtype(torch.bfloat16)
+    B = 20
+    st = _build_step(dev, B)
+    b = synthetic_batch(B, device=dev, seed=100)
+    noise = torch.empty((B, 100), device=dev)
+    args = (b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'], b['class_ids'], noise)
+    for _ in range(3):
+        noise.normal_(0, 1)
+        out = st.step(*args)
+    torch.cuda.synchronize()
+    last = {k: float(v) for k, v in out.items()}
+    graph = GraphedStep(st, *args, prologue=lambda: noise.normal_(0, 1))
+    for r in range(6):
+        graph.replay()
+        torch.cuda.synchronize()
+        cur = {k: float(v) for k, v in graph.out.items()}
+        for k, v in cur.items():
+            assert np.isfinite(v), (r, k)
+        # a collapsed stage shows as g_loss jumping to the BCE clamp (>= 30) within one step
+        for k in ('g_loss0', 'g_loss1', 'g_loss2'):
+            assert cur[k] <= last[k] + 8.0, (r, k, cur[k], last[k])
+        last = cur
+
+
 @pytest.mark.parametrize('dt', DTYPES)
 def test_image_encoder_hip_vs_torch(dev, dt):
     """CNN_ENCODER on the HIP kernels (sbagan.inception_hip) against the same module evaluated by
