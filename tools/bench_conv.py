@@ -45,7 +45,10 @@ def main():
     print('%-12s %-7s %5s %5s %4s %8s | %8s %7s | %8s %7s | %8s %7s' % (
         'layer', 'kind', 'Cin', 'Cout', 'H', 'M', 'fwd_us', 'TF/s', 'dgrad_us', 'TF/s', 'wgrad_us', 'TF/s'))
     tot = [0.0, 0.0, 0.0]
+    only = os.environ.get('ONLY')
     for kind, cin, cout, h, tag in SHAPES:
+        if only and not any(o in tag for o in only.split(',')):
+            continue
         k = 4 if kind == '4x4s2' else 3
         x = torch.randn((B, cin, h, h), device=dev).to(dt).contiguous(memory_format=torch.channels_last)
         w = torch.nn.Parameter((torch.randn((cout, cin, k, k), device=dev) / (cin * k * k) ** 0.5)
