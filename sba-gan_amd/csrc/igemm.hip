@@ -225,7 +225,7 @@ __device__ __forceinline__ void tile_epilogue(f32x16_t (&acc)[TM][TN], const boo
 // pad makes the 16-lane ds_read_b128 groups hit 16 distinct 4-bank slots).
 // ---------------------------------------------------------------------------
 template <typename T, int BM, int BN, int WM, int WN, int KS, int KG, int PF>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KG) void igemm_kernel(const T* __restrict__ x, const T* __restrict__ w,
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KG, (sizeof(T) == 2 && BM * BN == 128 * 128 && KS == 1) ? 3 : 1) void igemm_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                     T* __restrict__ y, const T* __restrict__ addend,
                                                     float* __restrict__ stats, const sba_conv_geom g,
                                                     const int M, float* __restrict__ ws,
@@ -809,10 +809,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
 // weight gradient, small-pixel-count regime (GEMM-like layers at 4x4 / 8x8 maps with
 // thousands of channels): every wave owns its own 64(co) x 64(ci) tile of one tap and walks
 // ALL pixels of the block's range, so there is no cross-wave reduction; the four waves of a
-// workgroup share the dy slice (same co tile) and differ in (tap, ci tile).
+// workgroup share the dy slice (same co tile) and differ in (tap, ci tile).  CT = 2: every wave owns
+// TWO co tiles (128 x 64 outputs) against the same x slice -- these launches are bound by the L2 traffic
+// of the operand slices (each wave streams its own), 0.375 instead of 0.625 KB per MFMA.
 // ---------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+template <typename T, int CT>
+__global__ __launch_bounds__(256, 2) void wgrad_small_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           float* __restrict__ dw, const sba_conv_geom g,
                                                           const int M, const int chunks_per_split,
                                                           const int use_atomic, const FastDiv dsub,
@@ -821,12 +823,12 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ 
     constexpr int CH = 16 / (int)sizeof(T);
     constexpr int CPR = 64 / CH;
     constexpr int LPT = 16 * CPR / 64;               // 16-byte loads per lane for a wave-private slice
-    constexpr int APT = (16 * CPR + 255) / 256;      // 16-byte loads per thread for the shared dy slice
+    constexpr int APT = (16 * CPR * CT + 255) / 256; // 16-byte loads per thread for the shared dy slice(s)
     constexpr int SLICE = 16 * ROWS;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[5 * SLICE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(CT + 4) * SLICE];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int co0 = blockIdx.x * 64;
+    const int co0 = blockIdx.x * (64 * CT);
     const int ci_tiles = (g.Cin + 63) / 64;
     const int item = blockIdx.y * 4 + wid;
     const bool active = item < g.ntaps * ci_tiles;
@@ -840,15 +842,17 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ 
     const int sub = g.OHs * g.OWs;
 
     unsigned char* sa = lds;
-    unsigned char* sb = lds + (1 + wid) * SLICE;
+    unsigned char* sb = lds + (CT + wid) * SLICE;
 
-    f32x16_t acc[2][2];
+    f32x16_t acc[CT][2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int s = 0; s < CT; ++s)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[s][i][j][r] = 0.f;
 
     const int total_chunks = (M + 15) / 16;
     const int chunk_lo = blockIdx.z * chunks_per_split;
@@ -861,8 +865,8 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ 
         for (int u = 0; u < APT; ++u) {
             const int idx = tid + 256 * u;
             va[u] = make_uint4(0, 0, 0, 0);
-            if (idx < 16 * CPR) {
-                const int pix = idx / CPR, cc = idx - pix * CPR;
+            if (idx < 16 * CPR * CT) {
+                const int pix = idx / (CPR * CT), cc = idx - pix * (CPR * CT);
                 const int m = m0 + pix, co = co0 + cc * CH;
                 if (m < M && co < g.Cout) {
                     const int n = (int)fdiv(m, dsub), rem = m - n * sub;
@@ -898,9 +902,9 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ 
 #pragma unroll
         for (int u = 0; u < APT; ++u) {
             const int idx = tid + 256 * u;
-            if (idx < 16 * CPR) {
-                const int pix = idx / CPR, cc = idx - pix * CPR;
-                *reinterpret_cast<uint4*>(sa + pix * ROWS + cc * 16) = va[u];
+            if (idx < 16 * CPR * CT) {
+                const int pix = idx / (CPR * CT), cc = idx - pix * (CPR * CT);
+                *reinterpret_cast<uint4*>(sa + (cc / CPR) * SLICE + pix * ROWS + (cc % CPR) * 16) = va[u];
             }
         }
 #pragma unroll
@@ -911,25 +915,28 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(const T* __restrict__ 
         }
         __syncthreads();
         if (ck + 1 < chunk_hi) gload(ck + 1);
-        WgFrag<T>::mma(sa, sb, lane, acc);
+#pragma unroll
+        for (int s = 0; s < CT; ++s) WgFrag<T>::mma(sa + s * SLICE, sb, lane, acc[s]);
     }
 
     if (!active) return;
     const int col_l = lane & 31, rsel = 4 * (lane >> 5);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int s = 0; s < CT; ++s)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
-                const int ci = ci0 + j * 32 + col_l;
-                if (co < g.Cout && ci < g.Cin) {
-                    float* p = dw + ((int64_t)co * g.ntaps + tap) * g.Cin + ci;
-                    if (use_atomic) atomicAdd(p, acc[i][j][r]);
-                    else *p += acc[i][j][r];
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + s * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
+                    const int ci = ci0 + j * 32 + col_l;
+                    if (co < g.Cout && ci < g.Cin) {
+                        float* p = dw + ((int64_t)co * g.ntaps + tap) * g.Cin + ci;
+                        if (use_atomic) atomicAdd(p, acc[s][i][j][r]);
+                        else *p += acc[s][i][j][r];
+                    }
                 }
-            }
 }
 
 // ---------------------------------------------------------------------------
@@ -1532,7 +1539,16 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
         split = cdiv(total_chunks, cps);
         dim3 grid(co_tiles, cdiv(items, 4), split);
         if (grid.y > 65535 || grid.z > 65535) return SBA_E_ARG;
-        SBA_DISPATCH(dtype, SBA_LAUNCH((wgrad_small_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
+        static int ct2 = -1;        // SBA_WGRAD_SMALL_CT2: minimum workgroups for the 128-wide variant (0 = never,
+                                    // the default: measured 20-35 % SLOWER than CT = 1 at 4 waves per SIMD)
+        if (ct2 < 0) { const char* e = getenv("SBA_WGRAD_SMALL_CT2"); ct2 = e ? atoi(e) : 0; }
+        if (ct2 > 0 && split == 1 && g->Cout % 128 == 0 && (co_tiles / 2) * (int)grid.y >= ct2) {
+            grid.x = co_tiles / 2;
+            SBA_DISPATCH(dtype, SBA_LAUNCH((wgrad_small_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)x, (const T*)dy, dw, *g, M, cps, 0, dsub, dow));
+            return SBA_CHECK_LAUNCH();
+        }
+        SBA_DISPATCH(dtype, SBA_LAUNCH((wgrad_small_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream,
                                                (const T*)x, (const T*)dy, dw, *g, M, cps, split > 1 ? 1 : 0, dsub,
                                                dow));
         return SBA_CHECK_LAUNCH();
