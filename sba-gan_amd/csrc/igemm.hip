@@ -250,9 +250,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KG, (sizeof(T) == 2 &&
 
     // KS slabs are staged per barrier (KS > 1 for the small tiles, whose MFMA work per slab is short);
     // each K-group has its own double buffer
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[KG * GROUP_BYTES + BM * 4 + BN * 8];
-    int* rowoff = reinterpret_cast<int*>(lds_all + KG * GROUP_BYTES);
-    float* s_stat = reinterpret_cast<float*>(lds_all + KG * GROUP_BYTES + BM * 4);
+    // The epilogue's row table and statistics accumulators live INSIDE the (by then free) staging buffers,
+    // behind the staged bf16 output tile: the 64x64 tile then needs 36 KB instead of 40.75 KB of LDS and a CU
+    // holds four workgroups instead of three.
+    constexpr int EPI_OFF = sizeof(T) == 2 ? BM * (BN * 2 + 16) : 0;
+    constexpr int EPI_END = EPI_OFF + BM * 4 + BN * 8;
+    constexpr int LDS_BYTES = KG * GROUP_BYTES > EPI_END ? KG * GROUP_BYTES : EPI_END;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[LDS_BYTES];
+    int* rowoff = reinterpret_cast<int*>(lds_all + EPI_OFF);
+    float* s_stat = reinterpret_cast<float*>(lds_all + EPI_OFF + BM * 4);
 
     const int kg = KG > 1 ? (int)threadIdx.x / NT : 0;
     const int tid = KG > 1 ? (int)threadIdx.x - kg * NT : (int)threadIdx.x;
@@ -281,18 +287,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KG, (sizeof(T) == 2 &&
             a_nb[i] = 0;
         }
     }
-    for (int r = threadIdx.x; r < BM; r += NTT) {
-        const int m = m_base + r;
-        int off = -1;
-        if (m < M) {
-            const int n = m / sub, rem = m - n * sub;
-            const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
-            off = (n * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox;
-        }
-        rowoff[r] = off;
-    }
-    for (int c = threadIdx.x; c < 2 * BN; c += NTT) s_stat[c] = 0.f;
-
     const int cpt = g.Cin / KS_CH;            // slabs per tap
     const int nsteps = g.ntaps * cpt;
     // tap offsets packed 4 bits each (offset + 8) so that the per-step lookup is
@@ -492,8 +486,21 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KG, (sizeof(T) == 2 &&
         return;
     }
 
-    tile_epilogue<T, BM, BN, TM, TN, NTT, KG * GROUP_BYTES>(acc, lead, lds_all, rowoff, s_stat, wm0, wn0, lane, n_base,
-                                                            ycs, g, y, addend, stats, ex);
+    // (the main loop / K-group reduction ended with a barrier: the staging buffers are free)
+    for (int r = threadIdx.x; r < BM; r += NTT) {
+        const int m = m_base + r;
+        int off = -1;
+        if (m < M) {
+            const int n = m / sub, rem = m - n * sub;
+            const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
+            off = (n * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox;
+        }
+        rowoff[r] = off;
+    }
+    for (int c = threadIdx.x; c < 2 * BN; c += NTT) s_stat[c] = 0.f;
+    __syncthreads();
+    tile_epilogue<T, BM, BN, TM, TN, NTT, LDS_BYTES>(acc, lead, lds_all, rowoff, s_stat, wm0, wn0, lane, n_base, ycs, g,
+                                                     y, addend, stats, ex);
 }
 
 // ---------------------------------------------------------------------------
@@ -1353,7 +1360,7 @@ struct IgemmCfg { int bm, bn, ks, occ; float eff; bool split; };
 // per-wave tiles (less LDS traffic per MFMA, but 4 waves and one workgroup per CU) lost to E everywhere.)
 static const IgemmCfg kCfg[5] = {
     {128, 128, 1, 3, 1.00f, false}, {256, 64, 1, 3, 1.00f, false}, {128, 64, 2, 2, 0.80f, false},
-    {64, 64, 2, 3, 0.50f, true},    {320, 128, 2, 1, 0.90f, true}};
+    {64, 64, 2, 4, 0.50f, true},    {320, 128, 2, 1, 0.90f, true}};
 
 template <typename T, int BM, int BN, int WM, int WN, int KS, int KG = 1, int PF = 1>
 static void launch_cfg(const T* xp, const T* wp, T* yp, const T* ap, float* stats, const sba_conv_geom& g, int M,
@@ -1447,7 +1454,7 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
         static int split_m = -1;
         if (split_m < 0) { const char* e = getenv("SBA_IGEMM_SPLIT_M"); split_m = e ? atoi(e) : 2048; }
         if (k.split && can_split && tiles < slots && M <= split_m) {     // split-K only pays on the GEMM-like maps
-            int split = cdiv(slots, tiles);
+            int split = slots / tiles;          // floor: one more split than fits leaves a nearly empty second round
             if (split > nslabs / 8) split = nslabs / 8;
             if (split > 32) split = 32;
             if (split > 1) best_split = split;
