@@ -32,7 +32,7 @@ __device__ __forceinline__ BnCoef bn_coef(const float* __restrict__ stats, const
 // ---- batch statistics of an NHWC tensor (used when the conv epilogue cannot provide them:
 //      grouped passes, where one conv launch covers several BatchNorm batches); blockIdx.y = group ----
 template <typename T>
-__global__ void bn_stats_kernel(const T* __restrict__ y_all, float* __restrict__ stats_all, int64_t rows, int C) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y_all, float* __restrict__ stats_all, int64_t rows, int C) {
     constexpr int V = Vec16<T>::N;
     const T* y = y_all + (int64_t)blockIdx.y * rows * C;
     float* stats = stats_all + ((int64_t)blockIdx.y * SBA_BN_STAT_SLOTS + (blockIdx.x & (SBA_BN_STAT_SLOTS - 1))) * 2 * C;
@@ -69,7 +69,7 @@ __global__ void bn_stats_kernel(const T* __restrict__ y_all, float* __restrict__
 // shift, mean, rstd for the backward, and workgroup (0, 0) applies the running-statistics updates
 // of all groups in order (momentum, unbiased variance), as consecutive module calls would.
 template <typename T, int ACT>
-__global__ void bn_act_fwd_kernel(const T* __restrict__ y_all, const float* __restrict__ stats_all,
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y_all, const float* __restrict__ stats_all,
                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                   float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ nbt,
                                   float* __restrict__ aux_all, const T* __restrict__ residual_all,
@@ -148,7 +148,7 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y_all, const float* __re
 // ---- backward pass 1: per-channel sum(dz), sum(dz*xhat); blockIdx.y = group ----
 // thread mapping: each thread keeps a fixed set of channel vectors and strides over rows
 template <typename T, int ACT>
-__global__ void bn_bwd_reduce_kernel(const T* __restrict__ y_all, const T* __restrict__ dout_all,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ y_all, const T* __restrict__ dout_all,
                                      const float* __restrict__ aux_all, float* __restrict__ red_all,
                                      int64_t rows, int C, int dcs, int dco) {
     constexpr int V = Vec16<T>::N;
@@ -181,6 +181,7 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y_all, const T* __res
                 mng[k] = mean[Co + c + k]; rsg[k] = rstd[Co + c + k];
             }
         }
+#pragma unroll 2
         for (int64_t row = (int64_t)blockIdx.x * rpi + tr; row < rows; row += (int64_t)gridDim.x * rpi) {
             Vec16<T> a = ld16(y + row * C + c);
             Vec16<T> d = ld16(dout + row * dcs + dco + c);
@@ -227,7 +228,7 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ y_all, const T* __res
 // ---- backward pass 2: dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); blockIdx.y = group ----
 // per-channel coefficients live in LDS: A = scale, B = shift, M = mean, R = rstd, P = red0/rows, Q = red1/rows
 template <typename T, int ACT>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ y_all, const T* __restrict__ dout_all,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ y_all, const T* __restrict__ dout_all,
                                     const float* __restrict__ aux_all, const float* __restrict__ red_all,
                                     T* __restrict__ dy_all, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                     int64_t rows, int C, int dcs, int dco) {
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const T* __restrict__
 // ---- BatchNorm1d + GLU on [B][F] f32 with the NCHW->NHWC view permutation ----
 // feature f' in [0,F/2) pairs with gate f'+F/2; view(B, F/2/16, 4, 4): f' = c*16 + s
 template <typename T>
-__global__ void bn1d_glu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void bn1d_glu_fwd_kernel(const float* __restrict__ y, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, float* __restrict__ rmean,
                                     float* __restrict__ rvar, int64_t* __restrict__ nbt,
                                     float* __restrict__ mean_o, float* __restrict__ rstd_o,
@@ -524,7 +525,7 @@ __global__ void bn1d_glu_fwd_kernel(const float* __restrict__ y, const float* __
 }
 
 template <typename T>
-__global__ void bn1d_glu_bwd_kernel(const float* __restrict__ y, const T* __restrict__ dout,
+__global__ __launch_bounds__(256) void bn1d_glu_bwd_kernel(const float* __restrict__ y, const T* __restrict__ dout,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     float* __restrict__ dy, float* __restrict__ dgamma,
@@ -561,7 +562,7 @@ __global__ void bn1d_glu_bwd_kernel(const float* __restrict__ y, const T* __rest
 // ---- InstanceNorm statistics / AdaIN ----
 // grid (N, splits); threads [rows][C/V]; accumulates (sum, sumsq) into mean/rstd buffers
 template <typename T>
-__global__ void instnorm_accum_kernel(const T* __restrict__ h, float* __restrict__ sum,
+__global__ __launch_bounds__(256) void instnorm_accum_kernel(const T* __restrict__ h, float* __restrict__ sum,
                                       float* __restrict__ sumsq, int HW, int C) {
     constexpr int V = Vec16<T>::N;
     const int cv = C / V, n = blockIdx.x;
@@ -592,7 +593,7 @@ __global__ void instnorm_accum_kernel(const T* __restrict__ h, float* __restrict
     }
 }
 
-__global__ void instnorm_finalize_kernel(float* __restrict__ mean, float* __restrict__ rstd, int NC,
+__global__ __launch_bounds__(256) void instnorm_finalize_kernel(float* __restrict__ mean, float* __restrict__ rstd, int NC,
                                          float HW, float eps) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= NC) return;
@@ -603,7 +604,7 @@ __global__ void instnorm_finalize_kernel(float* __restrict__ mean, float* __rest
 }
 
 template <typename T>
-__global__ void adain_fwd_kernel(const T* __restrict__ h, const float* __restrict__ mean,
+__global__ __launch_bounds__(256) void adain_fwd_kernel(const T* __restrict__ h, const float* __restrict__ mean,
                                  const float* __restrict__ rstd, const float* __restrict__ style,
                                  T* __restrict__ out, int N, int HW, int C, int ocs, int oco) {
     constexpr int V = Vec16<T>::N;
@@ -626,7 +627,7 @@ __global__ void adain_fwd_kernel(const T* __restrict__ h, const float* __restric
 
 // red[n][c][0] += sum dout*xhat, red[n][c][1] += sum dout
 template <typename T>
-__global__ void adain_bwd_reduce_kernel(const T* __restrict__ h, const T* __restrict__ dout,
+__global__ __launch_bounds__(256) void adain_bwd_reduce_kernel(const T* __restrict__ h, const T* __restrict__ dout,
                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                         float* __restrict__ red, int HW, int C, int dcs, int dco) {
     constexpr int V = Vec16<T>::N;
@@ -666,7 +667,7 @@ __global__ void adain_bwd_reduce_kernel(const T* __restrict__ h, const T* __rest
 }
 
 template <typename T>
-__global__ void adain_bwd_apply_kernel(const T* __restrict__ h, const T* __restrict__ dout,
+__global__ __launch_bounds__(256) void adain_bwd_apply_kernel(const T* __restrict__ h, const T* __restrict__ dout,
                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                        const float* __restrict__ style, const float* __restrict__ red,
                                        T* __restrict__ dh, float* __restrict__ dstyle, int N, int HW,
