@@ -93,7 +93,8 @@ def build(args, dev):
             return f.float(), c.float()
     else:       # diagnostic only: the step without the Inception trunk (a 1x1 conv on a 17x17 average pool)
         enc = _LightEncoder(cfg.TEXT.EMBEDDING_DIM, dev)
-    step = GANStep(netG, netsD, enc, args.batch, distributed=(args.gpus > 1))
+    step = GANStep(netG, netsD, enc, args.batch,
+                   distributed=(args.gpus > 1 or os.environ.get('SBA_BENCH_FORCE_DIST', '0') == '1'))
     step.overlap_wgrad_d = os.environ.get('SBA_OVERLAP_WGRAD_D', '0') == '1'
     step.overlap_wgrad = os.environ.get('SBA_OVERLAP_WGRAD', '1') == '1'
     step.concurrent_d = os.environ.get('SBA_CONCURRENT_D', '1') == '1'
@@ -216,7 +217,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world == 1 and args.gpus <= 1 and args.graph and not args.child:
         sys.exit(supervise(args))
-    if args.gpus > 1 or world > 1:
+    # SBA_BENCH_FORCE_DIST=1: run the multi-rank code path (RCCL communicator, eager all-reduce between the
+    # per-network graphs) with ONE rank -- the only way to exercise RCCL on a 1-GPU development box
+    force_dist = os.environ.get('SBA_BENCH_FORCE_DIST', '0') == '1'
+    if args.gpus > 1 or world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         # SBA_BENCH_BACKEND=gloo rehearses the multi-rank control flow with several ranks on ONE card
@@ -228,6 +232,7 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local)
+    multi = dist.is_initialized()
     from sbagan.synth import synthetic_batch
     step = build(args, dev)
     b = synthetic_batch(args.batch, branch_num=args.branch, device=dev, seed=100 + rank)
@@ -284,7 +289,7 @@ def main():
             sys.stderr.write('graph capture failed (%s: %s); timing eager launches\n' % (type(e).__name__, e))
             graph = None
             torch.cuda.synchronize()
-        if world > 1:       # every rank must issue the same sequence of collectives: graphs only if ALL captured
+        if multi:           # every rank must issue the same sequence of collectives: graphs only if ALL captured
             ok = torch.tensor([1 if graph is not None else 0], device=dev, dtype=torch.int32)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok) == 0:
@@ -292,7 +297,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -305,7 +310,7 @@ def main():
             out = one_step()
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -333,7 +338,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
