@@ -43,6 +43,9 @@ def parse():
                     help='CNN_ENCODER inside the G step: the Inception-v3 trunk on the HIP kernels '
                          '(sbagan.inception_hip), the same module through PyTorch-ROCm/MIOpen, or the light '
                          'stand-in used by the parity fixtures')
+    ap.add_argument('--text-encoder', default='rnn', choices=['rnn', 'none'],
+                    help="rnn: the frozen RNN_ENCODER forward (trainer.py:248-252) runs inside every timed step "
+                         "(hand-written bi-LSTM, caption lengths read on the device); none: embeddings are inputs")
     ap.add_argument('--graph', type=int, default=2,
                     help='0: eager launches; 1: replay the step from a captured hipGraph; 2: capture, time a few '
                          'untimed probe steps in both modes during warmup and keep the faster one')
@@ -240,8 +243,23 @@ def main():
     noise = torch.empty(noise_shape, device=dev)
     torch.manual_seed(100 + rank)
 
+    txt = None
+    if args.text_encoder == 'rnn':
+        import model
+        txt = model.RNN_ENCODER(5450, nhidden=b['sent_emb'].size(1)).to(dev).eval()   # CUB vocabulary size
+        hid = txt.init_hidden(args.batch)
+
+    def encode():
+        # words_embs, sent_emb = text_encoder(captions, cap_lens, hidden) of trainer.py:248-252 (no_grad, eval)
+        if txt is not None:
+            with torch.no_grad():
+                w, s = txt(b['captions'], b['cap_lens'], hid, max_len=b['words_embs'].size(2))
+            b['words_embs'].copy_(w)
+            b['sent_emb'].copy_(s)
+
     def one_step():
         noise.normal_(0, 1)
+        encode()
         return step.step(b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'], b['class_ids'],
                          noise)
 
@@ -265,7 +283,7 @@ def main():
         try:
             from sbagan.trainer import GraphedStep
             graph = GraphedStep(step, b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'],
-                                b['class_ids'], noise, prologue=lambda: noise.normal_(0, 1),
+                                b['class_ids'], noise, prologue=lambda: (noise.normal_(0, 1), encode()),
                                 single=os.environ.get('SBA_GRAPH_SINGLE', '0') == '1')
             out = graph.out
             for _ in range(2):
@@ -326,7 +344,8 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': 'bird_style.yml %d-stage G+D step (64..%dpx), B=%d per GPU, G_NET variant=%s, '
                                'image_encoder=%s' % (args.branch, 64 * 2 ** (args.branch - 1), args.batch,
-                                                     args.variant, args.image_encoder),
+                                                     args.variant, args.image_encoder)
+                               + (', text_encoder=RNN_ENCODER in the step' if args.text_encoder == 'rnn' else ''),
                    'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'launch': mode,
                    'losses_finite': finite},
         'step_tflops': round(GFLOP_PER_IMG[args.branch] * ips / 1e3, 2),

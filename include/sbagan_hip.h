@@ -315,6 +315,20 @@ int sba_adam_prepare(void* state, float lr, float beta1, float beta2, void* stre
 int sba_adam_step(float* p, const float* g, float* m, float* v, float* avg, void* shadow,
                   const void* state, int64_t n, float beta1, float beta2, float eps, float grad_scale,
                   void* stream);
+/* RNN_ENCODER.forward of the frozen text encoder (model.py:127-159; trainer.py:248-252 calls it under
+ * eval/no_grad every step): Embedding -> one-layer bidirectional LSTM over packed sequences.
+ *   captions [B][T] int64 token ids, cap_lens [B] int64 (device memory: replaces the reference's
+ *   cap_lens.tolist() host sync, model.py:139), emb_weight [ntoken][ninput],
+ *   w_ih [2][4H][ninput], w_hh [2][4H][H], b_ih / b_hh [2][4H]  (= weight_ih_l0 | weight_ih_l0_reverse ...,
+ *   PyTorch gate order i|f|g|o), h0 / c0 [2][B][H] or both NULL (= init_hidden zeros),
+ *   gx_scratch [2][B*T][4H] f32 workspace.
+ * Outputs: words [B][2H][Lout] (zeros past each caption's length, like pad_packed_sequence; Lout <= T is
+ * the reference's max(cap_lens) when the host knows it, else T), sent [B][2H] (last valid hidden state,
+ * forward | backward).  H in {64, 128}, ninput % 4 == 0. */
+int sba_lstm_bidir_fwd(const int64_t* captions, const int64_t* cap_lens, const float* emb_weight,
+                       const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                       const float* h0, const float* c0, float* gx_scratch, float* words, float* sent,
+                       int B, int T, int Lout, int ntoken, int ninput, int H, void* stream);
 /* y = cast(x) between f32 and dtype, n elements. */
 int sba_cast(int dtype_dst, void* dst, int dtype_src, const void* src, int64_t n, void* stream);
 

@@ -97,6 +97,7 @@ SIGNATURES = {
     'sba_adam_prepare': [P, F, F, F, P],
     'sba_adam_step': [P, P, P, P, P, P, P, L, F, F, F, F, P],
     'sba_cast': [I, P, I, P, L, P],
+    'sba_lstm_bidir_fwd': [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
 }
 
 for _name, _args in SIGNATURES.items():

@@ -540,7 +540,33 @@ class RNN_ENCODER(nn.Module):
         z = lambda: w.new_zeros(self.nlayers * self.num_directions, bsz, self.nhidden)
         return (z(), z()) if self.rnn_type == 'LSTM' else z()
 
-    def forward(self, captions, cap_lens, hidden, mask=None):
+    use_hip = True      # frozen-encoder forward (eval / no_grad, one-layer bi-LSTM, CUDA) through sba_lstm_bidir_fwd
+
+    def _hip_ok(self, captions):
+        return (self.use_hip and captions.is_cuda and not torch.is_grad_enabled()
+                and (not self.training or self.drop_prob == 0) and self.rnn_type == 'LSTM' and self.nlayers == 1
+                and self.bidirectional and self.nhidden in (64, 128) and self.ninput % 4 == 0)
+
+    def _packed_lstm_weights(self):
+        """[2][4H][*] stacks of the forward / reverse direction parameters, rebuilt when they change."""
+        r = self.rnn
+        ps = (r.weight_ih_l0, r.weight_ih_l0_reverse, r.weight_hh_l0, r.weight_hh_l0_reverse,
+              r.bias_ih_l0, r.bias_ih_l0_reverse, r.bias_hh_l0, r.bias_hh_l0_reverse)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, '_lstm_key', None) != key:
+            self._lstm_pack = tuple(torch.stack((ps[i].detach().float(), ps[i + 1].detach().float())).contiguous()
+                                    for i in (0, 2, 4, 6))
+            self._lstm_key = key
+        return self._lstm_pack
+
+    def forward(self, captions, cap_lens, hidden, mask=None, max_len=None):
+        """`max_len` (optional, host int = the reference's max(cap_lens)): without it the sync-free path returns
+        words_emb over the full padded width T; the extra columns are zeros and are masked / sliced away by
+        every consumer (GlobalAttention mask, words_loss cap_lens), so results are unchanged."""
+        if self._hip_ok(captions):
+            w_ih, w_hh, b_ih, b_hh = self._packed_lstm_weights()
+            return ops.lstm_bidir_forward(captions, cap_lens, self.encoder.weight.detach().float(), w_ih, w_hh, b_ih,
+                                          b_hh, hidden, max_len)
         from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
         emb = self.drop(self.encoder(captions))
         lens = cap_lens.data.tolist()

@@ -1090,3 +1090,27 @@ class SentLossFn(torch.autograd.Function):
         call('sba_damsm_sent_bwd', _p(cnn), _p(rnn), _p(ds), _p(dcnn), _p(drnn), B, nef, ctx.k[0], ctx.k[1],
              _stream())
         return dcnn, drnn, None, None, None
+
+
+# ----------------------------------------------------------------------------
+# text encoder
+def lstm_bidir_forward(captions, cap_lens, emb_weight, w_ih, w_hh, b_ih, b_hh, hidden=None, max_len=None):
+    """RNN_ENCODER.forward (model.py:127-159) of the frozen text encoder, sync-free: cap_lens stays on the
+    device.  w_ih [2][4H][ninput], w_hh [2][4H][H], b_* [2][4H]; returns (words_emb B x 2H x L,
+    sent_emb B x 2H) with L = max_len (the reference's max(cap_lens), if the host knows it) or T."""
+    _need_gpu(captions)
+    B, T = captions.shape
+    H = w_hh.shape[2]
+    L = T if max_len is None else int(max_len)
+    dev = captions.device
+    captions = captions.to(torch.int64).contiguous()
+    cap_lens = cap_lens.to(device=dev, dtype=torch.int64).contiguous()
+    gx = torch.empty((2, B * T, 4 * H), dtype=torch.float32, device=dev)
+    words = torch.empty((B, 2 * H, L), dtype=torch.float32, device=dev)
+    sent = torch.empty((B, 2 * H), dtype=torch.float32, device=dev)
+    h0 = c0 = None
+    if hidden is not None:
+        h0, c0 = hidden[0].float().contiguous(), hidden[1].float().contiguous()
+    call('sba_lstm_bidir_fwd', _p(captions), _p(cap_lens), _p(emb_weight), _p(w_ih), _p(w_hh), _p(b_ih), _p(b_hh),
+         _p(h0), _p(c0), _p(gx), _p(words), _p(sent), B, T, L, emb_weight.shape[0], emb_weight.shape[1], H, _stream())
+    return words, sent

@@ -486,3 +486,45 @@ def test_grouped_real_fake_pass_equals_two_calls(dev, dt):
         # statistics pass); a rounding-level change can flip a LeakyReLU mask bit of a near-zero
         # activation, which moves a gradient by ~1e-3 relative -- hence not 1e-6
         assert r < (1e-2 if dt == torch.float32 else 0.12), (n, r)
+
+
+@pytest.mark.parametrize('name', ['small', 'bird'])
+def test_text_encoder_lstm(dev, name, golden_dir):
+    """sba_lstm_bidir_fwd (frozen RNN_ENCODER forward, cap_lens read on the device) against the reference's
+    golden outputs and the numpy oracle: f32, 1e-5.  Also the sync-free shape contract (max_len=None -> full
+    padded width, extra columns zero) and a non-zero initial state against the module's torch path."""
+    import model
+    from helpers import load_golden
+    from oracle import text_encoder as TE
+    T = load_golden(golden_dir, 'text_encoder.npz')
+    ntoken, ninput, nhidden = (int(v) for v in T['%s/dims' % name])
+    net = model.RNN_ENCODER(ntoken, ninput=ninput, nhidden=nhidden)
+    P = fill.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, salt=7)
+    net.load_state_dict(P)
+    net.to(dev).eval()
+    cap = torch.from_numpy(T['%s/captions' % name]).to(dev)
+    lens = torch.from_numpy(T['%s/cap_lens' % name]).to(dev)
+    B, Tw = cap.shape
+    lmax = int(T['%s/cap_lens' % name].max())
+    with torch.no_grad():
+        assert net._hip_ok(cap)
+        words, sent = net(cap, lens, net.init_hidden(B), max_len=lmax)
+        wfull, sfull = net(cap, lens, net.init_hidden(B))
+    assert words.shape == T['%s/words_emb' % name].shape and wfull.shape == (B, nhidden, Tw)
+    np.testing.assert_allclose(words.cpu().numpy(), T['%s/words_emb' % name], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(sent.cpu().numpy(), T['%s/sent_emb' % name], rtol=0, atol=1e-5)
+    ow, osent = TE.rnn_encoder_forward({k: v.numpy() for k, v in P.items()}, T['%s/captions' % name],
+                                       T['%s/cap_lens' % name])
+    np.testing.assert_allclose(words.cpu().numpy(), ow, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(sent.cpu().numpy(), osent, rtol=0, atol=1e-5)
+    assert torch.equal(wfull[:, :, :lmax], words) and float(wfull[:, :, lmax:].abs().max() if lmax < Tw else 0) == 0
+    assert torch.equal(sfull, sent)
+    # non-zero initial state: HIP path vs the torch (MIOpen) path of the same module
+    h0 = (0.3 * torch.randn(2, B, nhidden // 2, device=dev), 0.3 * torch.randn(2, B, nhidden // 2, device=dev))
+    with torch.no_grad():
+        w1, s1 = net(cap, lens, h0, max_len=lmax)
+        net.use_hip = False
+        w2, s2 = net(cap, lens, h0)
+        net.use_hip = True
+    np.testing.assert_allclose(w1.cpu().numpy(), w2.cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(s1.cpu().numpy(), s2.cpu().numpy(), rtol=0, atol=2e-5)

@@ -210,3 +210,31 @@ def test_two_training_steps_full_dims(golden_dir):
     Gs = load_golden(golden_dir, 'step_full_model_b4.npz')
     st, outs = _run_oracle_steps(Gs, FULL, 4, 'model')
     _check_steps(Gs, st, outs, rtol=5e-4)
+
+
+def _text_case(golden_dir, name):
+    import model
+    T = load_golden(golden_dir, 'text_encoder.npz')
+    ntoken, ninput, nhidden = (int(v) for v in T['%s/dims' % name])
+    net = model.RNN_ENCODER(ntoken, ninput=ninput, nhidden=nhidden)
+    P = fill.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, salt=7)
+    net.load_state_dict(P)
+    net.eval()
+    return T, net, P
+
+
+@pytest.mark.parametrize('name', ['small', 'bird'])
+def test_text_encoder_oracle_vs_reference_golden(golden_dir, name):
+    """oracle/text_encoder.py (numpy packed bi-LSTM) and the module's torch path against the outputs of the
+    reference's RNN_ENCODER (model.py:127-159) on the same closed-form parameters."""
+    from oracle import text_encoder as TE
+    T, net, P = _text_case(golden_dir, name)
+    cap, lens = T['%s/captions' % name], T['%s/cap_lens' % name]
+    words, sent = TE.rnn_encoder_forward({k: v.numpy() for k, v in P.items()}, cap, lens)
+    assert words.shape == T['%s/words_emb' % name].shape
+    np.testing.assert_allclose(words, T['%s/words_emb' % name], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(sent, T['%s/sent_emb' % name], rtol=0, atol=2e-6)
+    with torch.no_grad():
+        w2, s2 = net(torch.from_numpy(cap), torch.from_numpy(lens), net.init_hidden(cap.shape[0]))
+    np.testing.assert_allclose(w2.numpy(), T['%s/words_emb' % name], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(s2.numpy(), T['%s/sent_emb' % name], rtol=0, atol=2e-6)

@@ -308,11 +308,40 @@ def gen_step(ref, name, d, B, nsteps, variant):
     print('%s: %d arrays' % (name, len(S)))
 
 
+def gen_text(ref):
+    """RNN_ENCODER.forward (model.py:127-159) in eval mode on closed-form parameters: two sizes
+    (nhidden 128 / ninput 12 and the bird_style.yml size nhidden 256 / ninput 300)."""
+    cfg, _, model, _, _ = ref
+    S = {}
+    for name, ntoken, ninput, nhidden, B, T, lens in (
+            ('small', 40, 12, 128, 4, 6, [6, 4, 3, 1]),
+            ('bird', 60, 300, 256, 5, 18, [18, 11, 11, 7, 2])):
+        cfg.TEXT.WORDS_NUM = T
+        net = model.RNN_ENCODER(ntoken, ninput=ninput, nhidden=nhidden)
+        P = load_filled(net, salt=7)
+        net.eval()
+        cap = np.zeros((B, T), dtype=np.int64)
+        for b in range(B):
+            for t in range(lens[b]):
+                cap[b, t] = 1 + (7 * b + 3 * t + b * t) % (ntoken - 1)
+        with torch.no_grad():
+            words, sent = net(torch.from_numpy(cap), torch.tensor(lens), net.init_hidden(B))
+        S['%s/captions' % name] = cap
+        S['%s/cap_lens' % name] = np.asarray(lens, dtype=np.int64)
+        S['%s/dims' % name] = np.asarray([ntoken, ninput, nhidden], dtype=np.int64)
+        S['%s/words_emb' % name] = words.contiguous().numpy()
+        S['%s/sent_emb' % name] = sent.numpy()
+    np.savez_compressed(os.path.join(OUT, 'text_encoder.npz'), **S)
+    print('text_encoder.npz: %d arrays' % len(S))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     what = sys.argv[1:] or ['units', 'step_tiny', 'step_full']
     torch.set_num_threads(8)
     ref = load_reference()
+    if 'text' in what:
+        gen_text(ref)
     if 'units' in what:
         gen_units(ref)
     if 'step_tiny' in what:
