@@ -540,7 +540,8 @@ extern "C" int sba_d_stem_bwd(int dtype, const float* img, const float* w, const
     if (dw) {
         const int64_t pix = (int64_t)N * (S / 2) * (S / 2);
         const int64_t tiles = (pix + 63) / 64;
-        int tpb = (int)((tiles + 511) / 512);
+        int tpb = (int)((tiles + 767) / 768);      // three workgroups per CU (LDS 49 KB, 138 registers): staging is not
+                                                   // software-pipelined, the co-resident workgroups hide it
         if (tpb < 1) tpb = 1;
         const int blocks = (int)((tiles + tpb - 1) / tpb);
         const size_t sh = sizeof(float) * (64 * (C + (C % 64 == 0 ? 32 : 0)) + 64 * 96);

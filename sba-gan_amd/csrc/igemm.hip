@@ -556,16 +556,31 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const bf16_t* __restr
 
     // ---- halo tile: source rows sy0 .. sy0+HR-1, columns sx0 .. sx0+HC-1 (zeros outside the image)
     const int sy0 = UPS ? (oy0 >> 1) - 1 : oy0 - 1, sx0 = UPS ? (ox0 >> 1) - 1 : ox0 - 1;
-    for (int idx = tid; idx < HR * HC * CPP; idx += 256) {
-        const int p = idx / CPP, ch = idx - p * CPP;
-        const int hr = p / HC, hc = p - hr * HC;
-        const int iy = sy0 + hr, ix = sx0 + hc;
-        const bool ok = iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
-        const uint32_t o = ok ? (uint32_t)((n * g.IH + iy) * g.IW + ix) * (uint32_t)(xcs * 2) +
-                                    (uint32_t)(g.x_coff * 2) + (uint32_t)ch * 16u
-                              : OOB;
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(xr, o, 0, 0);
-        *reinterpret_cast<uint4*>(lA + p * PIXB + ch * 16) = make_uint4(v[0], v[1], v[2], v[3]);
+    // (loads are issued in batches of HB before the first LDS write: a load -> wait -> ds_write loop pays the
+    // global latency once per iteration, 4 (upsampling) to 11 times per workgroup)
+    constexpr int NCH = HR * HC * CPP, NI = (NCH + 255) / 256, HB = 6;
+#pragma unroll
+    for (int i0 = 0; i0 < NI; i0 += HB) {
+        u32x4_t hv[HB];
+#pragma unroll
+        for (int u = 0; u < HB; ++u) {
+            const int idx = tid + 256 * (i0 + u);
+            const int p = idx / CPP, ch = idx - p * CPP;
+            const int hr = p / HC, hc = p - hr * HC;
+            const int iy = sy0 + hr, ix = sx0 + hc;
+            const bool ok = i0 + u < NI && idx < NCH && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+            const uint32_t o = ok ? (uint32_t)((n * g.IH + iy) * g.IW + ix) * (uint32_t)(xcs * 2) +
+                                        (uint32_t)(g.x_coff * 2) + (uint32_t)ch * 16u
+                                  : OOB;
+            hv[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, o, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < HB; ++u) {
+            const int idx = tid + 256 * (i0 + u);
+            const int p = idx / CPP, ch = idx - p * CPP;
+            if (i0 + u < NI && idx < NCH)
+                *reinterpret_cast<uint4*>(lA + p * PIXB + ch * 16) = make_uint4(hv[u][0], hv[u][1], hv[u][2], hv[u][3]);
+        }
     }
     // ---- weights of one tap: BN rows of CIN channels
     uint4 rb[BI];
