@@ -120,7 +120,9 @@ int sba_pool2x2_sum(int dtype, const void* dup, void* dx, int N, int H, int W, i
  * (sum[C], sumsq[C]) pair: a conv epilogue adds into slot (workgroup index mod SLOTS), which divides the
  * same-address atomic contention of thousands of workgroups by SLOTS; readers add the slots up.  A
  * statistics buffer is therefore stats[groups][SBA_BN_STAT_SLOTS][2C] floats, zeroed by the caller. */
+#ifndef SBA_BN_STAT_SLOTS
 #define SBA_BN_STAT_SLOTS 8
+#endif
 /* All BatchNorm entry points take `groups` >= 1 independent BatchNorm batches laid back to back
  * (`rows` NHWC rows each; the discriminator's real | fake passes of losses.py:139-140 share one conv
  * launch); per-group arrays are stats[groups][SLOTS][2C], aux[groups][4C] (= scale, shift, mean, rstd),

@@ -466,7 +466,8 @@ def wgrad_tail_stream():
     return comp
 
 
-BN_STAT_SLOTS = 8          # = SBA_BN_STAT_SLOTS (include/sbagan_hip.h)
+BN_STAT_SLOTS = int(os.environ.get('SBA_BN_STAT_SLOTS', '8'))   # = SBA_BN_STAT_SLOTS the library was built with
+#                                                                  (include/sbagan_hip.h; the env var is for A/B builds)
 
 
 class BNState(object):
