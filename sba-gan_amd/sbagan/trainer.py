@@ -293,10 +293,19 @@ class GraphedStep(object):
     loss / backward / Adam.  (A single captured graph of the whole step runs its discriminator branches
     almost back to back on ROCm 7.2: measured 8.5 ms for the three updates against ~4.5 ms here.)
     Inputs are static tensors; `prologue` (e.g. drawing the noise in place) is captured with phase A.
-    Call after a few eager steps on the same GANStep (per-stream workspaces and packed buffers exist)."""
+    Call after a few eager steps on the same GANStep (per-stream workspaces and packed buffers exist).
+    The graphs repack the bf16 weight copies exactly where the capture did (after each network's Adam step), so
+    between replays parameters must only change through the replayed optimizer steps; after loading a checkpoint
+    or editing parameters run one eager `gan.step` (or rebuild the GraphedStep) before replaying again."""
 
     def __init__(self, gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, prologue=None,
                  single=False):
+        self._capture(gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, prologue, single)
+        # the weight repacks issued during capture were recorded, not executed, yet the host-side change counters
+        # now call the packed copies fresh: invalidate them so that an eager step after the capture repacks
+        ops.weights_changed()
+
+    def _capture(self, gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, prologue, single):
         self.gan = gan
         self.single = single and not gan.distributed
         dev = gan.device
@@ -351,6 +360,9 @@ class GraphedStep(object):
 
     def replay(self):
         main = torch.cuda.current_stream()
+        # the graphs repack the bf16 weight copies at the points where the capture did, without consulting the
+        # host-side change counters; invalidate those so that an EAGER call after a replay repacks as well
+        ops.weights_changed()
         self.gA.replay()
         if self.single:
             return self.out

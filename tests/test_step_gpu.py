@@ -317,6 +317,43 @@ def test_graphed_step_tracks_eager_step(dev):
         last = cur
 
 
+def test_graphed_step_equals_eager_step(dev):
+    """Two identical trainers (same closed-form parameters, inputs, noise, eps) run in lockstep: one steps
+    eagerly, the other is replayed from the per-phase hipGraphs after the same warm-up.  Every loss of every
+    replayed step matches the eager trainer's step (bf16 path; tolerance = atomic-order noise carried over a
+    few updates).  (The graphs repack the bf16 weight copies where the capture did, so parameters must not be
+    modified behind their back between replays -- hence two trainers instead of snapshot / restore.)"""
+    from sbagan import ops
+    from sbagan.synth import synthetic_batch
+    from sbagan.trainer import GraphedStep
+    ops.set_compute_dtype(torch.bfloat16)
+    B = 20
+    b = synthetic_batch(B, device=dev, seed=100)
+    noise = torch.randn((B, 100), device=dev)
+    eps = torch.randn((B, 100), device=dev)
+    args = (b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'], b['class_ids'], noise)
+    trainers = []
+    for _ in range(2):
+        st = _build_step(dev, B)
+        orig = st.phase_a
+        st.phase_a = (lambda o: (lambda se, we, m, nz, e=None: o(se, we, m, nz, eps)))(orig)   # fixed eps everywhere
+        trainers.append(st)
+    eager, graphed = trainers
+    for _ in range(3):
+        eager.step(*args)
+        graphed.step(*args)
+    torch.cuda.synchronize()
+    graph = GraphedStep(graphed, *args)          # runs one more eager step on the capture stream, then captures
+    eager.step(*args)
+    for r in range(3):
+        out_e = {k: float(v) for k, v in eager.step(*args).items()}
+        graph.replay()
+        torch.cuda.synchronize()
+        out_g = {k: float(v) for k, v in graph.out.items()}
+        for k, v in out_e.items():
+            assert abs(out_g[k] - v) <= 5e-2 * abs(v) + 5e-3, (r, k, out_g[k], v)
+
+
 @pytest.mark.parametrize('dt', DTYPES)
 def test_image_encoder_hip_vs_torch(dev, dt):
     """CNN_ENCODER on the HIP kernels (sbagan.inception_hip) against the same module evaluated by
