@@ -246,7 +246,9 @@ def main():
     txt = None
     if args.text_encoder == 'rnn':
         import model
+        torch.manual_seed(102)                    # the frozen encoder is identical on every rank
         txt = model.RNN_ENCODER(5450, nhidden=b['sent_emb'].size(1)).to(dev).eval()   # CUB vocabulary size
+        torch.manual_seed(100 + rank)
         hid = txt.init_hidden(args.batch)
 
     def encode():
