@@ -94,6 +94,29 @@ def test_reference_yml_files_load_unchanged():
     reset_cfg()
 
 
+def test_shipped_cfg_equals_reference(golden_dir):
+    """Every shipped cfg/*.yml parses to exactly the values of the reference file of the same name
+    (tests/golden/cfg_values.json = yaml.safe_load of the reference's nine files, written by the same session
+    that ran tools/make_cfg.py; compared against /root/reference directly where it is mounted)."""
+    import json
+    import yaml
+    with open(os.path.join(golden_dir, 'cfg_values.json')) as f:
+        ref = json.load(f)
+    assert len(ref) == 9
+    base = os.path.join(ROOT, 'sba-gan_amd', 'cfg')
+    shipped = sorted(os.path.relpath(os.path.join(dp, f), base) for dp, _, fs in os.walk(base) for f in fs
+                     if f.endswith('.yml'))
+    assert shipped == sorted(ref)
+    for rel in shipped:
+        with open(os.path.join(base, rel)) as f:
+            mine = yaml.safe_load(f)
+        assert mine == ref[rel], rel
+        live = os.path.join('/root/reference/AttnGAN2/code/cfg', rel)
+        if os.path.exists(live):
+            with open(live) as f:
+                assert mine == yaml.safe_load(f), rel
+
+
 def test_state_dict_surface_matches_reference():
     from helpers import FULL, d_shapes, g_shapes
     from miscc.config import cfg, reset_cfg

@@ -147,11 +147,11 @@ def test_discriminators(G, x, which):
     check(G, 'd%d/gimg' % which, torch.autograd.grad(l, fk)[0], rtol=2e-3, atol=1e-7)
 
 
-def _run_oracle_steps(Gs, d, Bs, variant, nsteps=2, tag=500):
-    x = make_inputs(d, Bs, 18, lmax=18, tag=tag)
+def _run_oracle_steps(Gs, d, Bs, variant, nsteps=2, tag=500, branch=3):
+    x = make_inputs(d, Bs, 18, branch=branch, lmax=18, tag=tag)
     v = 'model' if variant == 'model' else 'bert'
-    PG = fill.fill_state_dict(g_shapes(d, 3, v))
-    PDs = [fill.fill_state_dict(d_shapes(d, i), salt=i) for i in range(3)]
+    PG = fill.fill_state_dict(g_shapes(d, branch, v))
+    PDs = [fill.fill_state_dict(d_shapes(d, i), salt=i) for i in range(branch)]
     st = O.OracleState(PG, PDs)
     enc = fill.StandInImageEncoder(d['nef'])
     outs = []
@@ -163,19 +163,27 @@ def _run_oracle_steps(Gs, d, Bs, variant, nsteps=2, tag=500):
     return st, outs
 
 
-def _check_steps(Gs, st, outs, rtol):
+def _check_steps(Gs, st, outs, rtol, slim=False):
+    nD = len(st.PDs)
     for step, o in enumerate(outs):
-        for k in ('errD0', 'errD1', 'errD2', 'errG_total', 'kl_loss',
-                  'gnormD0', 'gnormD1', 'gnormD2', 'gnormG'):
+        for k in ['errD%d' % i for i in range(nD)] + ['gnormD%d' % i for i in range(nD)] + \
+                ['errG_total', 'kl_loss', 'gnormG']:
             ref = float(Gs['step%d/%s' % (step, k)])
             # step >= 1 follows an Adam update, whose first step is sign-like
             # (p -= lr * g / (|g| + eps)): rounding-level differences in tiny
             # gradients move parameters by O(lr), so later steps get 10x slack.
-            tol = rtol * (10 if step else 1)
+            # (gradient norms after an update: 3x more, as in tests/test_step_gpu.py)
+            tol = rtol * (10 if step else 1) * (3 if (step and k.startswith('gnorm')) else 1)
+            if k == 'gnormG' and not step:
+                # already downstream of the discriminators' (sign-like) Adam updates of this step: measured
+                # 1.5e-4 at B=4 and 1.2e-3 at B=20 between two fp32 CPU evaluations, losses at 1e-7
+                tol = max(tol, 3e-3)
             assert abs(o[k] - ref) <= tol * abs(ref) + 1e-6, (step, k, o[k], ref)
         for i, f in enumerate(o['fake']):
-            check(Gs, 'step%d/fake%d' % (step, i), f, rtol=10 * rtol, atol=1e-4, l2tol=(5e-3 if step else None))
+            check(Gs, 'step%d/fake%d' % (step, i), f, rtol=10 * rtol, atol=1e-4, l2tol=(1e-2 if step else None))
     nsteps = len(outs)
+    if slim:            # the B=20 fixture holds losses, gradient norms and image slices only
+        return
     for n, p in st.PG.items():
         if n.endswith('num_batches_tracked'):
             assert int(p) == int(Gs['final/G/%s/sum' % n]), n
@@ -210,6 +218,32 @@ def test_two_training_steps_full_dims(golden_dir):
     Gs = load_golden(golden_dir, 'step_full_model_b4.npz')
     st, outs = _run_oracle_steps(Gs, FULL, 4, 'model')
     _check_steps(Gs, st, outs, rtol=5e-4)
+
+
+@pytest.mark.parametrize('variant', ['bert', 'mix'])
+def test_two_training_steps_full_dims_bert_variants(golden_dir, variant):
+    """BASELINE config 3 / 5 generators (model_bert.py G_NET, G_NET_MIX) at bird_style dims, B=4, 2 steps."""
+    torch.set_num_threads(8)
+    Gs = load_golden(golden_dir, 'step_full_%s_b4.npz' % variant)
+    st, outs = _run_oracle_steps(Gs, FULL, 4, variant)
+    _check_steps(Gs, st, outs, rtol=5e-4)
+
+
+def test_two_training_steps_stage1_only(golden_dir):
+    """BASELINE config 1: bird_style.yml dims with TREE.BRANCH_NUM = 1 (64 px, D_NET64 only), B=4."""
+    torch.set_num_threads(8)
+    Gs = load_golden(golden_dir, 'step_full_model_b4_branch1.npz')
+    st, outs = _run_oracle_steps(Gs, FULL, 4, 'model', branch=1)
+    _check_steps(Gs, st, outs, rtol=5e-4)
+
+
+def test_one_training_step_full_dims_b20(golden_dir):
+    """BASELINE config 2 at its own batch size (B=20): first step vs the reference (the second costs another
+    ~20 s of CPU and is covered by the GPU test)."""
+    torch.set_num_threads(8)
+    Gs = load_golden(golden_dir, 'step_full_model_b20.npz')
+    st, outs = _run_oracle_steps(Gs, FULL, 20, 'model', nsteps=1)
+    _check_steps(Gs, st, outs, rtol=5e-4, slim=True)
 
 
 def _text_case(golden_dir, name):

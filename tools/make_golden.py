@@ -232,20 +232,22 @@ def gen_units(ref):
 
 
 # ---------------------------------------------------------------- full step
-def run_reference_steps(ref, d, B, nsteps, variant='model', tag=500):
-    """Drive the reference modules in the order of trainer.py:261-299."""
+def run_reference_steps(ref, d, B, nsteps, variant='model', tag=500, branch=3, slim=False):
+    """Drive the reference modules in the order of trainer.py:261-299.  `branch` = TREE.BRANCH_NUM
+    (1: the 64 px stage with D_NET64 only, BASELINE config 1); `slim`: losses, gradient norms and
+    1024-element slices of the fake images only (the B=20 fixture)."""
     import torch.optim as optim
     cfg, GA, model, model_bert, losses = ref
-    set_dims(cfg, d)
+    set_dims(cfg, dict(d, branch=branch))
     L = 20
-    x = make_inputs(d, B, L - 2, lmax=18, tag=tag)
+    x = make_inputs(d, B, L - 2, branch=branch, lmax=18, tag=tag)
     if variant == 'model':
         netG = model.G_NET()
     elif variant == 'bert':
         netG = model_bert.G_NET()
     else:
         netG = model_bert.G_NET_MIX()
-    netsD = [model.D_NET64(), model.D_NET128(), model.D_NET256()]
+    netsD = [model.D_NET64(), model.D_NET128(), model.D_NET256()][:branch]
     load_filled(netG)
     for i, n in enumerate(netsD):
         load_filled(n, salt=i)
@@ -262,7 +264,7 @@ def run_reference_steps(ref, d, B, nsteps, variant='model', tag=500):
         S['step%d/eps' % step] = eps.numpy()
         torch.manual_seed(777 + step)
         fake, _, mu, logvar = netG(noise, x['sent'], x['words'], x['mask'])
-        for i in range(3):
+        for i in range(branch):
             netsD[i].zero_grad()
             errD = losses.discriminator_loss(netsD[i], x['imgs'][i], fake[i], x['sent'],
                                              real_labels, fake_labels)
@@ -286,9 +288,15 @@ def run_reference_steps(ref, d, B, nsteps, variant='model', tag=500):
         for p, a in zip(netG.parameters(), avg):
             a.mul_(0.999).add_(p.data, alpha=0.001)
         for i, f in enumerate(fake):
-            put(S, 'step%d/fake%d' % (step, i), f)
+            if slim:
+                for k, a in summarize(f, full_limit=0, nsample=1024).items():
+                    S['step%d/fake%d/%s' % (step, i, k)] = a
+            else:
+                put(S, 'step%d/fake%d' % (step, i), f)
         print('  step', step, {k: float(v) for k, v in S.items()
                                if k.startswith('step%d/err' % step)}, flush=True)
+    if slim:
+        return S
     # post-run state of every parameter and buffer (sum, sumsq, strided sample)
     for n, v in netG.state_dict().items():
         for k, a in summarize(v.float(), full_limit=600, nsample=512).items():
@@ -302,8 +310,8 @@ def run_reference_steps(ref, d, B, nsteps, variant='model', tag=500):
     return S
 
 
-def gen_step(ref, name, d, B, nsteps, variant):
-    S = run_reference_steps(ref, d, B, nsteps, variant)
+def gen_step(ref, name, d, B, nsteps, variant, **kw):
+    S = run_reference_steps(ref, d, B, nsteps, variant, **kw)
     np.savez_compressed(os.path.join(OUT, name), **S)
     print('%s: %d arrays' % (name, len(S)))
 
@@ -351,6 +359,12 @@ def main():
         gen_step(ref, 'step_full_model_b4.npz', FULL, 4, 2, 'model')
     if 'step_full_bert' in what:
         gen_step(ref, 'step_full_bert_b4.npz', FULL, 4, 2, 'bert')
+    if 'step_full_mix' in what:
+        gen_step(ref, 'step_full_mix_b4.npz', FULL, 4, 2, 'mix')
+    if 'step_full_branch1' in what:     # BASELINE config 1: bird_style.yml, stage 1 only (64 px), B=4
+        gen_step(ref, 'step_full_model_b4_branch1.npz', FULL, 4, 2, 'model', branch=1)
+    if 'step_full_b20' in what:         # BASELINE config 2 at its own batch size (losses, grad norms, slices)
+        gen_step(ref, 'step_full_model_b20.npz', FULL, 20, 2, 'model', slim=True)
 
 
 if __name__ == '__main__':
