@@ -47,8 +47,9 @@ def parse():
                     help="rnn: the frozen RNN_ENCODER forward (trainer.py:248-252) runs inside every timed step "
                          "(hand-written bi-LSTM, caption lengths read on the device); none: embeddings are inputs")
     ap.add_argument('--graph', type=int, default=2,
-                    help='0: eager launches; 1: replay the step from a captured hipGraph; 2: capture, time a few '
-                         'untimed probe steps in both modes during warmup and keep the faster one')
+                    help='0: eager launches; 1: replay the step from captured hipGraphs (hipGraphLaunch); 3: the '
+                         'native multi-stream launch replayer (csrc/replay.hip) over the captured step; 2: build '
+                         'all of them, time a few untimed probe steps of each during warmup and keep the fastest')
     ap.add_argument('--phases', action='store_true', help='also print per-phase times of an eager step (stderr)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -254,10 +255,9 @@ def main():
     def encode():
         # words_embs, sent_emb = text_encoder(captions, cap_lens, hidden) of trainer.py:248-252 (no_grad, eval)
         if txt is not None:
-            with torch.no_grad():
-                w, s = txt(b['captions'], b['cap_lens'], hid, max_len=b['words_embs'].size(2))
-            b['words_embs'].copy_(w)
-            b['sent_emb'].copy_(s)
+            with torch.no_grad():       # written straight into the step's static input tensors
+                txt(b['captions'], b['cap_lens'], hid, max_len=b['words_embs'].size(2),
+                    out=(b['words_embs'], b['sent_emb']))
 
     def one_step():
         noise.normal_(0, 1)
@@ -281,34 +281,52 @@ def main():
     for _ in range(n_eager):
         out = one_step()
     torch.cuda.synchronize()
+
+    def probe(fn, n=4):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n
+
     if args.graph:
-        try:
-            from sbagan.trainer import GraphedStep
-            graph = GraphedStep(step, b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'],
-                                b['class_ids'], noise, prologue=lambda: (noise.normal_(0, 1), encode()),
-                                single=os.environ.get('SBA_GRAPH_SINGLE', '0') == '1')
-            out = graph.out
-            for _ in range(2):
-                graph.replay()
-            torch.cuda.synchronize()
-            mode = 'hipgraph'
-            if args.graph == 2 and world == 1:
-                def probe(fn, n=4):
-                    torch.cuda.synchronize()
-                    t = time.perf_counter()
-                    for _ in range(n):
-                        fn()
-                    torch.cuda.synchronize()
-                    return (time.perf_counter() - t) / n
-                t_graph, t_eager = probe(graph.replay), probe(one_step)
-                sys.stderr.write('launch probe: hipgraph %.2f ms, eager %.2f ms per step\n'
-                                 % (t_graph * 1e3, t_eager * 1e3))
-                if t_eager < t_graph:
-                    graph, mode = None, 'eager'
-        except Exception as e:      # capture is an optimisation, never a requirement
-            sys.stderr.write('graph capture failed (%s: %s); timing eager launches\n' % (type(e).__name__, e))
-            graph = None
-            torch.cuda.synchronize()
+        cands = {}
+        a = (b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'], b['class_ids'], noise)
+        if args.graph in (1, 2):
+            try:
+                from sbagan.trainer import GraphedStep
+                g1 = GraphedStep(step, *a, prologue=lambda: (noise.normal_(0, 1), encode()),
+                                 single=os.environ.get('SBA_GRAPH_SINGLE', '0') == '1')
+                for _ in range(2):
+                    g1.replay()
+                torch.cuda.synchronize()
+                cands['hipgraph'] = g1
+            except Exception as e:      # capture is an optimisation, never a requirement
+                sys.stderr.write('graph capture failed (%s: %s)\n' % (type(e).__name__, e))
+                torch.cuda.synchronize()
+        if args.graph in (2, 3) and not multi:
+            try:
+                from sbagan.trainer import ReplayedStep
+                g3 = ReplayedStep(step, *a, recorded_prologue=encode,
+                                  max_streams=int(os.environ.get('SBA_REPLAY_STREAMS', '8')), verbose=True)
+                for _ in range(2):
+                    g3.replay()
+                torch.cuda.synchronize()
+                cands['replayer'] = g3
+            except Exception as e:
+                sys.stderr.write('launch replayer unavailable (%s: %s)\n' % (type(e).__name__, e))
+                torch.cuda.synchronize()
+        if cands:
+            times = {k: probe(v.replay) for k, v in cands.items()}
+            if world == 1 and args.graph == 2:
+                times['eager'] = probe(one_step)
+            sys.stderr.write('launch probe (ms per step): ' + ', '.join('%s %.2f' % (k, v * 1e3)
+                                                                       for k, v in times.items()) + '\n')
+            mode = min(times, key=times.get)
+            graph = cands.get(mode)
+            if graph is not None:
+                out = graph.out
         if multi:           # every rank must issue the same sequence of collectives: graphs only if ALL captured
             ok = torch.tensor([1 if graph is not None else 0], device=dev, dtype=torch.int32)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)

@@ -31,6 +31,7 @@ extern "C" {
 #define SBA_OK 0
 #define SBA_E_ARG (-1)      /* shape / alignment / enum argument the kernels do not support */
 #define SBA_E_LAUNCH (-2)   /* hipGetLastError() != hipSuccess after the launch */
+#define SBA_E_UNSUPPORTED (-3)   /* sba_replay_create: the captured graph holds a node kind that cannot be re-issued */
 
 #define SBA_ACT_NONE 0
 #define SBA_ACT_GLU 1       /* model.py:15-23 */
@@ -331,6 +332,22 @@ int sba_lstm_bidir_fwd(const int64_t* captions, const int64_t* cap_lens, const f
                        const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                        const float* h0, const float* c0, float* gx_scratch, float* words, float* sent,
                        int B, int T, int Lout, int ntoken, int ninput, int H, void* stream);
+/* ---- multi-stream launch replayer (host side of the step loop; no counterpart in the reference, whose
+ * trainer.py:245-299 issues every launch from Python) ----
+ * sba_replay_create walks a CAPTURED hipGraph_t (stream capture of one training step, or of one phase of it:
+ * kernel / 1-D memcpy / memset / empty nodes and their edges), assigns every node a stream -- a chain keeps its
+ * stream, a fork takes the next of at most max_streams -- and stores the launch list; sba_replay_launch
+ * re-issues the nodes in topological order as plain asynchronous launches on those streams, with events only
+ * where a dependency crosses streams; it begins after everything already queued on `stream` and `stream` waits
+ * for its end.  Unlike hipGraphLaunch on ROCm 7.2, independent branches then really run concurrently, at ~3 us
+ * of host time per launch.  The graph must outlive the handle (kernel arguments live in its nodes); the handle
+ * owns its streams and events.  Returns SBA_E_UNSUPPORTED for node kinds it cannot re-issue (callers fall
+ * back to hipGraphLaunch).  info8 = {nodes, kernels, copies, memsets, streams, cross-stream waits, events, 0}.
+ * This is the one entry point family that creates HIP objects (streams / events), at create time only. */
+int sba_replay_create(void* hip_graph, int max_streams, int verbose, void** out_handle);
+int sba_replay_launch(void* handle, void* stream);
+int sba_replay_info(void* handle, int* info8);
+int sba_replay_destroy(void* handle);
 /* y = cast(x) between f32 and dtype, n elements. */
 int sba_cast(int dtype_dst, void* dst, int dtype_src, const void* src, int64_t n, void* stream);
 

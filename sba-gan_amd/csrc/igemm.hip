@@ -112,7 +112,7 @@ __device__ __forceinline__ void tile_epilogue(f32x16_t (&acc)[TM][TN], const boo
                                               const int lane, const int n_base, const int ycs,
                                               const sba_conv_geom& g, T* __restrict__ y,
                                               const T* __restrict__ addend, float* __restrict__ stats,
-                                              const EpiX ex) {
+                                              const EpiX ex, const int slot_id = -1) {
     const float* __restrict__ bias = ex.bias;
     const T* __restrict__ rmask = reinterpret_cast<const T*>(ex.mask);
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -204,7 +204,8 @@ __device__ __forceinline__ void tile_epilogue(f32x16_t (&acc)[TM][TN], const boo
     }
     if (stats) {
         // one of SBA_BN_STAT_SLOTS replicas per workgroup: 1/SLOTS of the same-address atomic traffic
-        float* slot = stats + (int64_t)((blockIdx.x + blockIdx.z) & (SBA_BN_STAT_SLOTS - 1)) * 2 * g.Cout;
+        const int sid = slot_id >= 0 ? slot_id : (int)(blockIdx.x + blockIdx.z);
+        float* slot = stats + (int64_t)(sid & (SBA_BN_STAT_SLOTS - 1)) * 2 * g.Cout;
         for (int c = threadIdx.x; c < BN; c += NTT) {
             const int co = n_base + c;
             if (co < g.Cout) {
@@ -501,6 +502,256 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64 * KG, (sizeof(T) == 2 &&
     __syncthreads();
     tile_epilogue<T, BM, BN, TM, TN, NTT, LDS_BYTES>(acc, lead, lds_all, rowoff, s_stat, wm0, wn0, lane, n_base, ycs, g,
                                                      y, addend, stats, ex);
+}
+
+// ---------------------------------------------------------------------------
+// The same implicit GEMM with the operands staged by LDS-DMA (bf16): `buffer_load_dwordx4 ... lds` moves
+// 16 bytes per lane from a per-lane global offset straight into LDS (wave-uniform base + lane * 16), so a
+// K stage costs no staging VGPRs and no ds_write pass, and a ring of D stages keeps D-1 of them in flight:
+// the generic kernel above exposes one full global-load latency per stage on the launch-latency-bound
+// layers (273-workgroup grids of the Inception trunk: ~1440 cycles per 64-deep stage for 128 cycles of MFMA).
+//   * LDS image of one 32-channel slab: rows of 64 B, unpadded (the DMA destination is lane-linear: 4 lanes
+//     per row, 16 rows per wave-instruction); the 16-byte chunk c of row r lives at chunk c ^ ((r >> 2) & 3),
+//     applied on the SOURCE side (each lane loads the chunk its slot holds) and on the fragment reads: every
+//     16-lane phase of a ds_read_b128 then covers all 64 banks.
+//   * out-of-image taps, rows beyond M and slabs beyond the split's range are out-of-range buffer offsets:
+//     the DMA writes zeros (tools/ldsdma_probe.hip).
+//   * the DMA is issued from inline asm (hipcc would otherwise drain ALL of it -- vmcnt(0) -- in front of
+//     every LDS read); completion is counted by hand: before stage s is read every wave waits until only the
+//     (D-2) younger stages it issued are outstanding, then the workgroup barrier makes all waves' parts visible
+//     and proves that nobody still reads the buffer the next issue overwrites.
+//   * workgroups are numbered so that the N tiles of one M tile run on one XCD, back to back (shared A rows
+//     are served by that XCD's L2).
+// ---------------------------------------------------------------------------
+// M0 = LDS destination of the DMA.  M0 is compiler-reserved; nothing else in these kernels uses it (LDS
+// instructions need no M0 on gfx9+, no dynamic register indexing, no LDS-DMA builtins), so it is simply
+// overwritten: saving and restoring it around every load cost two of the ~10 scalar instructions per load, and
+// with one wave per SIMD the main loop is instruction-ISSUE bound (rocprofv3: SQ_ACTIVE_INST_ANY 45 % of the wave
+// cycles against 10 % SQ_VALU_MFMA_BUSY_CYCLES on the 17x17 layers, profiles/r02_pmc_igemm_dma_v1.txt).
+// voff: per-lane byte offset (bounds-checked: 0xFFFFFFFF -> zeros); soff: wave-uniform byte offset added after
+// the bounds check -- the walk along K costs no per-lane arithmetic.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t rsrc, const uint32_t voff, const uint32_t soff,
+                                          const uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                 :: "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+template <int BM, int BN, int WM, int WN, int KS, int D>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+    const bf16_t* __restrict__ addend, float* __restrict__ stats, const sba_conv_geom g, const int M,
+    float* __restrict__ ws, const int slabs_per_split, const EpiX ex, const int gx, const int gy) {
+    typedef bf16_t T;
+    constexpr int TM = WM / 32, TN = WN / 32, WAVES_N = BN / WN;
+    constexpr int NW = (BM / WM) * (BN / WN), NT = NW * 64;
+    static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "every wave issues the same number of DMA loads");
+    constexpr int AI = BM / (16 * NW), BI = BN / (16 * NW);
+    constexpr int SLAB_BYTES = (BM + BN) * 64, STAGE_BYTES = KS * SLAB_BYTES, RING_BYTES = D * STAGE_BYTES;
+    constexpr int LPS = KS * (AI + BI);                       // DMA loads per thread per stage
+    static_assert(D >= 3 && (D - 2) * LPS <= 63, "vmcnt field");
+    static_assert(RING_BYTES <= 65536, "DMA destinations stay within the first 64 KiB of LDS (M0 offset field)");
+    constexpr int EPI_OFF = BM * (BN * 2 + 16);
+    constexpr int EPI_END = EPI_OFF + BM * 4 + BN * 8;
+    constexpr int LDS_BYTES = RING_BYTES > EPI_END ? RING_BYTES : EPI_END;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds_all[LDS_BYTES];
+    int* rowoff = reinterpret_cast<int*>(lds_all + EPI_OFF);
+    float* s_stat = reinterpret_cast<float*>(lds_all + EPI_OFF + BM * 4);
+
+    // workgroup -> tile: ids L and L + 8 share an XCD; the N tiles of an M tile take consecutive slots of one XCD
+    const int L = blockIdx.x, xcd = L & 7, q = L >> 3;
+    const int mt = xcd + 8 * (q / gy), nt = q - (q / gy) * gy;
+    if (mt >= gx) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+    const int m_base = mt * BM, n_base = nt * BN;
+    const int IHL = g.ups ? 2 * g.IH : g.IH, IWL = g.ups ? 2 * g.IW : g.IW;
+    const int sub = g.OHs * g.OWs;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_all;
+
+    // rows this thread's lane slot belongs to: instruction i of wave `wid` covers tile rows 16 * (wid + NW * i) ..+16
+    const int rsub = lane >> 2;
+    const uint32_t chunk = (uint32_t)((lane & 3) ^ ((lane >> 4) & 3));       // logical 16-byte chunk of the slot
+    int a_iy0[AI], a_ix0[AI], a_nb[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m_base + 16 * (wid + NW * i) + rsub;
+        if (m < M) {
+            const int n = m / sub, rem = m - n * sub;
+            const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
+            a_iy0[i] = oy * g.sy;
+            a_ix0[i] = ox * g.sx;
+            a_nb[i] = n * g.IH * g.IW;
+        } else {
+            a_iy0[i] = -100000;
+            a_ix0[i] = 0;
+            a_nb[i] = 0;
+        }
+    }
+    const int cpt = g.Cin / 32;
+    const int nsteps = g.ntaps * cpt;
+    uint64_t tyb[2] = {0, 0}, txb[2] = {0, 0};
+#pragma unroll
+    for (int t = 0; t < SBA_MAX_TAPS; ++t) {
+        tyb[t >> 4] |= (uint64_t)((g.ty[t] + 8) & 15) << (4 * (t & 15));
+        txb[t >> 4] |= (uint64_t)((g.tx[t] + 8) & 15) << (4 * (t & 15));
+    }
+    const int xcs = g.x_cstride ? g.x_cstride : g.Cin;
+    const int ycs = g.y_cstride ? g.y_cstride : g.Cout;
+    const int s_begin = blockIdx.z * slabs_per_split;
+    const int s_end = min(s_begin + slabs_per_split, nsteps);
+
+    int g_tap = s_begin / cpt, g_c = s_begin - g_tap * cpt, g_step = s_begin;
+    int cur_tap = -1;
+    constexpr uint32_t OOB = 0xFFFFFFFFu;
+    uint32_t a_off[AI];           // per-lane byte offset of (pixel of the current tap, channel 0, this lane's chunk)
+#pragma unroll
+    for (int i = 0; i < AI; ++i) a_off[i] = OOB;
+    uint32_t w_off[BI];           // per-lane byte offset of (co, K = 0, this lane's chunk): constant over the K loop
+    const uint32_t krow_bytes = (uint32_t)g.ntaps * (uint32_t)g.Cin * 2u;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int co = n_base + 16 * (wid + NW * i) + rsub;
+        w_off[i] = co < g.Cout ? (uint32_t)co * krow_bytes + chunk * 16u : OOB;
+    }
+    const uint32_t x_bytes = (uint32_t)((int64_t)g.N * g.IH * g.IW * xcs * 2);
+    const uint32_t w_bytes = (uint32_t)g.Cout * krow_bytes;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, w_bytes, 0x00020000);
+    const uint32_t lds_wave = lds_base + (uint32_t)(wid * 1024);
+    uint32_t v_oob = OOB;
+    asm volatile("" : "+v"(v_oob));         // a VGPR that holds the out-of-range offset (dead stages)
+
+    // issue the DMA of one stage (KS consecutive slabs) into the ring buffer at LDS offset `dst`
+    auto issue = [&](const uint32_t dst0) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const uint32_t dst = dst0 + (uint32_t)(k * SLAB_BYTES);
+            if (g_step < s_end) {
+                if (g_tap != cur_tap) {             // (uniform) new tap: per-lane pixel offsets
+                    cur_tap = g_tap;
+                    const int tsel = g_tap < SBA_MAX_TAPS ? g_tap : 0;
+                    const uint64_t tyw = tsel < 16 ? tyb[0] : tyb[1], txw = tsel < 16 ? txb[0] : txb[1];
+                    const int ty = (int)((tyw >> (4 * (tsel & 15))) & 15) - 8;
+                    const int tx = (int)((txw >> (4 * (tsel & 15))) & 15) - 8;
+#pragma unroll
+                    for (int i = 0; i < AI; ++i) {
+                        int iy = a_iy0[i] + ty, ix = a_ix0[i] + tx;
+                        const bool ok = (iy >= 0) & (iy < IHL) & (ix >= 0) & (ix < IWL);
+                        if (g.ups) { iy >>= 1; ix >>= 1; }
+                        const uint32_t o = (uint32_t)(a_nb[i] + iy * g.IW + ix) * (uint32_t)(xcs * 2) +
+                                           (uint32_t)(g.x_coff * 2) + chunk * 16u;
+                        a_off[i] = ok ? o : OOB;
+                    }
+                }
+                const uint32_t sa = (uint32_t)g_c * 64u, sw = (uint32_t)g_step * 64u;
+#pragma unroll
+                for (int i = 0; i < AI; ++i) lds_dma16(xr, a_off[i], sa, dst + (uint32_t)(NW * i * 1024));
+#pragma unroll
+                for (int i = 0; i < BI; ++i) lds_dma16(wr, w_off[i], sw, dst + (uint32_t)(BM * 64 + NW * i * 1024));
+                ++g_step;
+                if (++g_c == cpt) { g_c = 0; ++g_tap; }
+            } else {                                 // past this split's K range: zeros (keeps the vmcnt count uniform)
+#pragma unroll
+                for (int i = 0; i < AI; ++i) lds_dma16(xr, v_oob, 0u, dst + (uint32_t)(NW * i * 1024));
+#pragma unroll
+                for (int i = 0; i < BI; ++i) lds_dma16(wr, v_oob, 0u, dst + (uint32_t)(BM * 64 + NW * i * 1024));
+            }
+        }
+    };
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addressing: lane l reads row (l & 31), logical chunk 2 * kk + (l >> 5), swizzled by its row
+    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 2) & 3;
+    const int foff0 = fr * 64 + ((fh ^ fsw) << 4), foff1 = fr * 64 + (((2 + fh) ^ fsw) << 4);
+
+    const int nstages = (s_end - s_begin + KS - 1) / KS;
+    uint32_t idst = lds_wave;               // LDS destination (this wave's 1 KB slot) of the next stage to issue
+    const uint32_t idst_end = lds_wave + (uint32_t)RING_BYTES;
+#pragma unroll
+    for (int p = 0; p < D - 1; ++p) { issue(idst); idst += STAGE_BYTES; }
+    if (idst == idst_end) idst = lds_wave;
+    const unsigned char* cptr = lds_all;
+    for (int s = 0; s < nstages; ++s) {
+        wait_vmcnt<(D - 2) * LPS>();        // this wave's part of stage s has landed ...
+        wg_barrier();                       // ... and everybody else's; nobody reads buffer (s - 1) % D any more
+        issue(idst);                        // stage s + D - 1 (zeros past the end) into that buffer
+        idst += STAGE_BYTES;
+        if (idst == idst_end) idst = lds_wave;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const unsigned char* base = cptr + k * SLAB_BYTES;
+            const unsigned char* ar = base + wm0 * 64;
+            const unsigned char* br = base + (BM + wn0) * 64;
+            bf16x8_t a0[TM], a1[TM], b0[TN], b1[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                a0[i] = *reinterpret_cast<const bf16x8_t*>(ar + i * 2048 + foff0);
+                a1[i] = *reinterpret_cast<const bf16x8_t*>(ar + i * 2048 + foff1);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                b0[j] = *reinterpret_cast<const bf16x8_t*>(br + j * 2048 + foff0);
+                b1[j] = *reinterpret_cast<const bf16x8_t*>(br + j * 2048 + foff1);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+        }
+        cptr += STAGE_BYTES;
+        if (cptr == lds_all + RING_BYTES) cptr = lds_all;
+    }
+    wait_vmcnt<0>();        // the dead stages issued past the end still write (zeros) into the ring
+    wg_barrier();
+
+    if (ws) {
+        const int col_s = lane & 31, rsel_s = 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int co = n_base + wn0 + j * 32 + col_s;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m_base + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel_s;
+                    if (m < M && co < g.Cout) atomicAdd(&ws[(int64_t)m * g.Cout + co], acc[i][j][r]);
+                }
+        }
+        return;
+    }
+    for (int r = threadIdx.x; r < BM; r += NT) {
+        const int m = m_base + r;
+        int off = -1;
+        if (m < M) {
+            const int n = m / sub, rem = m - n * sub;
+            const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
+            off = (n * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox;
+        }
+        rowoff[r] = off;
+    }
+    for (int c = threadIdx.x; c < 2 * BN; c += NT) s_stat[c] = 0.f;
+    __syncthreads();
+    tile_epilogue<T, BM, BN, TM, TN, NT, LDS_BYTES>(acc, true, lds_all, rowoff, s_stat, wm0, wn0, lane, n_base, ycs, g, y,
+                                                    addend, stats, ex, mt + (int)blockIdx.z);
 }
 
 // ---------------------------------------------------------------------------
@@ -1395,6 +1646,32 @@ static void launch_cfg(const T* xp, const T* wp, T* yp, const T* ap, float* stat
     }
 }
 
+template <int BM, int BN, int WM, int WN, int KS, int D>
+static void launch_dma(const bf16_t* xp, const bf16_t* wp, bf16_t* yp, const bf16_t* ap, float* stats,
+                       const sba_conv_geom& g, int M, int nslabs, int split, float* ws, hipStream_t st, const EpiX ex) {
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    int sps = nslabs;
+    if (split > 1) {
+        sps = cdiv(cdiv(nslabs, split), KS) * KS;
+        split = cdiv(nslabs, sps);
+    }
+    const int gx = cdiv(M, BM), gy = cdiv(g.Cout, BN);
+    dim3 grid(8 * cdiv(gx, 8) * gy, 1, split);
+    SBA_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, KS, D>), grid, dim3(NT), 0, st, xp, wp, yp, ap, stats, g, M,
+               split > 1 ? ws : (float*)nullptr, sps, ex, gx, gy);
+    if (split > 1) {
+        dim3 fgrid(cdiv(g.Cout / 4, 256), cdiv(M, 8));
+        SBA_LAUNCH((splitk_finish_kernel<bf16_t>), fgrid, dim3(256), 0, st, ws, yp, ap, stats, g, M, ex);
+    }
+}
+
+// SBA_IGEMM_DMA: 1 (default) = LDS-DMA staged kernels for the bf16 tiles A-D, 0 = register-staged kernels
+static int dma_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SBA_IGEMM_DMA"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
+
 static int forced_cfg() {
     static int v = -2;
     if (v == -2) {
@@ -1476,6 +1753,17 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
         }
     }
     float* ws = (float*)workspace;
+    if (sizeof(T) == 2 && best <= 3 && dma_enabled()) {
+        const bf16_t* xb = (const bf16_t*)x; const bf16_t* wb = (const bf16_t*)w; bf16_t* yb = (bf16_t*)y;
+        const bf16_t* ab = (const bf16_t*)addend;
+        switch (best) {
+            case 0: launch_dma<128, 128, 64, 64, 1, 4>(xb, wb, yb, ab, stats, g, M, nslabs, best_split, ws, st, ex); break;
+            case 1: launch_dma<256, 64, 64, 64, 1, 3>(xb, wb, yb, ab, stats, g, M, nslabs, best_split, ws, st, ex); break;
+            case 2: launch_dma<128, 64, 32, 64, 1, 4>(xb, wb, yb, ab, stats, g, M, nslabs, best_split, ws, st, ex); break;
+            default: launch_dma<64, 64, 32, 32, 2, 4>(xb, wb, yb, ab, stats, g, M, nslabs, best_split, ws, st, ex); break;
+        }
+        return SBA_CHECK_LAUNCH();
+    }
     switch (best) {
         case 0: launch_cfg<T, 128, 128, 64, 64, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
         case 1: launch_cfg<T, 256, 64, 64, 64, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;

@@ -96,14 +96,38 @@ def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake
     return ops.BCEMultiFn.apply((1., 0., 0.), (1., .5, .5), cond_real, cond_fake, cond_wrong)
 
 
+def damsm_image_terms(image_encoder, fake_img, words_embs, sent_emb, match_labels, cap_lens, class_ids):
+    """The DAMSM ranking terms of generator_loss (losses.py:187-204) for one batch of fake images, together with
+    their gradient with respect to the images: returns (w_loss, s_loss, d(w_loss + s_loss)/d fake_img).
+
+    These terms depend on the generator's output only -- not on the discriminators -- so a trainer can evaluate
+    them (image encoder forward, words / sentence loss, backward through the frozen encoder) beside the
+    discriminator updates and hand the image gradient to the generator's backward pass later
+    (generator_loss(..., damsm=...)); by linearity the parameter gradients are those of the reference's single
+    backward pass of errG_total."""
+    batch_size = fake_img.size(0)
+    leaf = fake_img.detach().requires_grad_(True)
+    region_features, cnn_code = image_encoder(leaf)
+    w_loss0, w_loss1, _ = words_loss(region_features, words_embs, match_labels, cap_lens, class_ids, batch_size)
+    w_loss = (w_loss0 + w_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+    s_loss0, s_loss1 = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size)
+    s_loss = (s_loss0 + s_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+    (grad,) = torch.autograd.grad(w_loss + s_loss, leaf)
+    return w_loss.detach(), s_loss.detach(), grad
+
+
 def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sent_emb, match_labels,
-                   cap_lens, class_ids, streams=None):
+                   cap_lens, class_ids, streams=None, damsm=None):
     """losses.py:164-206.  Returns (errG_total, logs) where logs is a dict of device scalars
     {'g_loss0', ..., 'w_loss', 's_loss'} (format with .item() outside the step).
 
     streams (optional, len(netsD) + 1 HIP streams): the per-discriminator terms and the
     encoder + DAMSM term are independent branches (forward and backward), so each may run on its
-    own stream; autograd replays every branch's backward on the stream of its forward."""
+    own stream; autograd replays every branch's backward on the stream of its forward.
+
+    damsm (optional, the (w_loss, s_loss, image gradient) of damsm_image_terms): the ranking terms were
+    evaluated ahead of time; errG_total then carries their VALUES (same summation order as the reference) and the
+    caller back-propagates with `backward_with_image_grad`."""
     import contextlib
     numDs = len(netsD)
     batch_size = real_labels.size(0)
@@ -128,17 +152,20 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
                 g_loss = ops.BCEMultiFn.apply((1.,), (1.,), cond_logits)
         terms.append(g_loss)
         logs['g_loss%d' % i] = g_loss.detach()
-    # ranking loss on the last scale (losses.py:187-204).  An encoder that forks its own streams
-    # (sbagan.inception_hip) stays on the calling stream: it already overlaps the D branches, and
-    # nested forks inside a captured branch crash hipStreamEndCapture on ROCm 7.2.
-    own = streams and not getattr(image_encoder, 'parallel', False)
-    with (branch(numDs) if own else contextlib.nullcontext()):
-        region_features, cnn_code = image_encoder(fake_imgs[numDs - 1])
-        w_loss0, w_loss1, _ = words_loss(region_features, words_embs, match_labels, cap_lens, class_ids,
-                                         batch_size)
-        w_loss = (w_loss0 + w_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
-        s_loss0, s_loss1 = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size)
-        s_loss = (s_loss0 + s_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+    if damsm is not None:
+        w_loss, s_loss = damsm[0], damsm[1]
+    else:
+        # ranking loss on the last scale (losses.py:187-204).  An encoder that forks its own streams
+        # (sbagan.inception_hip) stays on the calling stream: it already overlaps the D branches, and
+        # nested forks inside a captured branch crash hipStreamEndCapture on ROCm 7.2.
+        own = streams and not getattr(image_encoder, 'parallel', False)
+        with (branch(numDs) if own else contextlib.nullcontext()):
+            region_features, cnn_code = image_encoder(fake_imgs[numDs - 1])
+            w_loss0, w_loss1, _ = words_loss(region_features, words_embs, match_labels, cap_lens, class_ids,
+                                             batch_size)
+            w_loss = (w_loss0 + w_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+            s_loss0, s_loss1 = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size)
+            s_loss = (s_loss0 + s_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
     if streams:
         for st in streams[:numDs + 1]:
             main.wait_stream(st)
@@ -149,6 +176,12 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
     logs['w_loss'] = w_loss.detach()
     logs['s_loss'] = s_loss.detach()
     return errG_total, logs
+
+
+def backward_with_image_grad(errG_total, fake_img, image_grad):
+    """One backward pass for errG_total whose DAMSM terms were evaluated ahead of time: their gradient enters at
+    the generator's last image (generator_loss(..., damsm=...))."""
+    torch.autograd.backward([errG_total, fake_img], [None, image_grad])
 
 
 def KL_loss(mu, logvar):

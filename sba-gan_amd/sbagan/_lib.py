@@ -98,6 +98,10 @@ SIGNATURES = {
     'sba_adam_step': [P, P, P, P, P, P, P, L, F, F, F, F, P],
     'sba_cast': [I, P, I, P, L, P],
     'sba_lstm_bidir_fwd': [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    'sba_replay_create': [P, I, I, POINTER(c_void_p)],
+    'sba_replay_launch': [P, P],
+    'sba_replay_info': [P, POINTER(c_int)],
+    'sba_replay_destroy': [P],
 }
 
 for _name, _args in SIGNATURES.items():
@@ -107,7 +111,8 @@ for _name, _args in SIGNATURES.items():
 lib.sba_version.restype = c_char_p
 lib.sba_version.argtypes = []
 
-_ERR = {-1: 'SBA_E_ARG (unsupported shape/alignment/enum)', -2: 'SBA_E_LAUNCH (HIP launch failed)'}
+_ERR = {-1: 'SBA_E_ARG (unsupported shape/alignment/enum)', -2: 'SBA_E_LAUNCH (HIP launch failed)',
+        -3: 'SBA_E_UNSUPPORTED (graph node kind the replayer cannot re-issue)'}
 
 
 def call(name, *args):

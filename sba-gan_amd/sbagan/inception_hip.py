@@ -513,16 +513,23 @@ class InceptionHIP(object):
         # seed the two head gradients
         gf = self._grad_of(f)
         if dfeat is not None:
-            df = torch.zeros((N, f.C, 17, 17), dtype=torch.float32, device=self.device)
-            df[:, :self.nef] = dfeat
+            if dfeat.shape[1] == f.C and dfeat.dtype == torch.float32 and dfeat.is_contiguous():
+                df = dfeat                  # nef is a multiple of 32: no padded staging copy
+            else:
+                df = torch.zeros((N, f.C, 17, 17), dtype=torch.float32, device=self.device)
+                df[:, :self.nef] = dfeat
             call('sba_layout_nhwc_nchw', dt, gf[0].data_ptr(), df.data_ptr(), N, 289, f.C, 1, st)
         else:
             gf[0].zero_()
         self._filled.add(self._key(f))
         gc = self._grad_of(code)
-        gc[0].zero_()
-        if dcode is not None:
-            gc[0].view(N, -1)[:, :self.nef] = dcode.to(self.dtype)
+        if dcode is not None and gc[0].numel() == dcode.numel() and dcode.dtype == torch.float32 and \
+                dcode.is_contiguous():
+            call('sba_cast', dt, gc[0].data_ptr(), _lib.SBA_F32, dcode.data_ptr(), dcode.numel(), st)
+        else:
+            gc[0].zero_()
+            if dcode is not None:
+                gc[0].view(N, -1)[:, :self.nef] = dcode.to(self.dtype)
         self._filled.add(self._key(code))
         def run(op):
             kind, L, x, out = op

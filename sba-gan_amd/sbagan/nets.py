@@ -559,14 +559,15 @@ class RNN_ENCODER(nn.Module):
             self._lstm_key = key
         return self._lstm_pack
 
-    def forward(self, captions, cap_lens, hidden, mask=None, max_len=None):
+    def forward(self, captions, cap_lens, hidden, mask=None, max_len=None, out=None):
         """`max_len` (optional, host int = the reference's max(cap_lens)): without it the sync-free path returns
         words_emb over the full padded width T; the extra columns are zeros and are masked / sliced away by
-        every consumer (GlobalAttention mask, words_loss cap_lens), so results are unchanged."""
+        every consumer (GlobalAttention mask, words_loss cap_lens), so results are unchanged.  `out` (optional,
+        HIP path only): (words_emb, sent_emb) tensors to write into."""
         if self._hip_ok(captions):
             w_ih, w_hh, b_ih, b_hh = self._packed_lstm_weights()
             return ops.lstm_bidir_forward(captions, cap_lens, self.encoder.weight.detach().float(), w_ih, w_hh, b_ih,
-                                          b_hh, hidden, max_len)
+                                          b_hh, hidden, max_len, out)
         from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
         emb = self.drop(self.encoder(captions))
         lens = cap_lens.data.tolist()

@@ -1095,7 +1095,7 @@ class SentLossFn(torch.autograd.Function):
 
 # ----------------------------------------------------------------------------
 # text encoder
-def lstm_bidir_forward(captions, cap_lens, emb_weight, w_ih, w_hh, b_ih, b_hh, hidden=None, max_len=None):
+def lstm_bidir_forward(captions, cap_lens, emb_weight, w_ih, w_hh, b_ih, b_hh, hidden=None, max_len=None, out=None):
     """RNN_ENCODER.forward (model.py:127-159) of the frozen text encoder, sync-free: cap_lens stays on the
     device.  w_ih [2][4H][ninput], w_hh [2][4H][H], b_* [2][4H]; returns (words_emb B x 2H x L,
     sent_emb B x 2H) with L = max_len (the reference's max(cap_lens), if the host knows it) or T."""
@@ -1107,8 +1107,13 @@ def lstm_bidir_forward(captions, cap_lens, emb_weight, w_ih, w_hh, b_ih, b_hh, h
     captions = captions.to(torch.int64).contiguous()
     cap_lens = cap_lens.to(device=dev, dtype=torch.int64).contiguous()
     gx = torch.empty((2, B * T, 4 * H), dtype=torch.float32, device=dev)
-    words = torch.empty((B, 2 * H, L), dtype=torch.float32, device=dev)
-    sent = torch.empty((B, 2 * H), dtype=torch.float32, device=dev)
+    if out is not None:         # caller-owned (static) output tensors: no copy in a recorded / captured step
+        words, sent = out
+        assert words.shape == (B, 2 * H, L) and sent.shape == (B, 2 * H) and words.is_contiguous() and \
+            sent.is_contiguous() and words.dtype == torch.float32 and sent.dtype == torch.float32
+    else:
+        words = torch.empty((B, 2 * H, L), dtype=torch.float32, device=dev)
+        sent = torch.empty((B, 2 * H), dtype=torch.float32, device=dev)
     h0 = c0 = None
     if hidden is not None:
         h0, c0 = hidden[0].float().contiguous(), hidden[1].float().contiguous()

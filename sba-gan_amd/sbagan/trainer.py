@@ -11,11 +11,14 @@ CA_NET eps.  The discriminator weight-gradients the reference computes in the G 
 then discards (trainer.py:270,287) are not computed: D parameters are frozen for that
 backward, which changes no result.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 
 from miscc.config import cfg
-from miscc.losses import KL_loss, discriminator_loss, generator_loss
+from miscc.losses import (KL_loss, backward_with_image_grad, damsm_image_terms, discriminator_loss,
+                          generator_loss)
 
 from . import ops
 from ._lib import call
@@ -121,6 +124,12 @@ class GradExchange(object):
             return None
         if self.stream is None:
             return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=True)
+        if dist.get_backend() == 'gloo':
+            # development / test path (several ranks on one card): gloo reduces host memory
+            host = flat_grad.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat_grad.copy_(host)
+            return None
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
@@ -170,6 +179,17 @@ class GANStep(object):
         self._ctx = (fake_imgs, mu, logvar)
         self._out = {}
 
+    def phase_e(self, sent_emb, words_embs, cap_lens, class_ids):
+        """The DAMSM ranking terms of the generator loss and their gradient w.r.t. the last fake image (image
+        encoder forward, words / sentence loss, backward through the frozen encoder: losses.py:187-204).  They
+        depend on the generator's output only, so this phase runs BESIDE the discriminator updates instead of
+        behind them (the reference evaluates them inside generator_loss, after the updates: ~4.5 ms of the
+        critical path at B=20)."""
+        fake_imgs = self._ctx[0]
+        ops.SIDE_WGRAD = False
+        self._damsm = damsm_image_terms(self.image_encoder, fake_imgs[-1], words_embs, sent_emb, self.match_labels,
+                                        cap_lens, class_ids)
+
     def phase_d_bwd(self, i, imgs, sent_emb, forked):
         """loss + backward of discriminator i on the CURRENT stream; returns the stream on which the update
         must continue (the weight-gradient companion when `forked`, see ops.wgrad_tail_stream)."""
@@ -205,13 +225,18 @@ class GANStep(object):
         for p in self._d_params:
             p.requires_grad_(False)
         self.flatG.zero_grad()
+        damsm = getattr(self, '_damsm', None) if self.early_damsm else None
         errG_total, logs = generator_loss(self.netsD, self.image_encoder, fake_imgs, self.real_labels, words_embs,
                                           sent_emb, self.match_labels, cap_lens, class_ids,
-                                          streams=self._d_streams() if self.concurrent_d else None)
+                                          streams=self._d_streams() if self.concurrent_d else None, damsm=damsm)
         kl = KL_loss(mu, logvar)
         errG_total = errG_total + kl
         mark('g_loss_forward')
-        errG_total.backward()
+        if damsm is not None:
+            backward_with_image_grad(errG_total, fake_imgs[-1], damsm[2])
+            self._damsm = None
+        else:
+            errG_total.backward()
         ops.join_wgrads()
         mark('g_backward')
         for p in self._d_params:
@@ -246,6 +271,13 @@ class GANStep(object):
         # 4x4 / 8x8 layers of one network fill CUs the others leave idle.
         main = torch.cuda.current_stream()
         nD = len(self.netsD)
+        es = None
+        if self.early_damsm:
+            es = self._e_stream() if self.concurrent_d else main
+            if es is not main:
+                es.wait_stream(main)
+            with torch.cuda.stream(es):
+                self.phase_e(sent_emb, words_embs, cap_lens, class_ids)
         streams = self._d_streams()[:nD] if self.concurrent_d else [main] * nD
         tails = []
         for i in range(nD):
@@ -254,7 +286,7 @@ class GANStep(object):
                 st.wait_stream(main)
             with torch.cuda.stream(st):
                 tails.append(self.phase_d(i, imgs, sent_emb, forked=st is not main))
-        for st in streams + tails:
+        for st in streams + tails + ([es] if es is not None else []):
             if st is not main:
                 main.wait_stream(st)
         mark('d_steps')
@@ -269,9 +301,15 @@ class GANStep(object):
             self.phase_events.append((name, e))
 
     concurrent_d = True
+    early_damsm = True           # DAMSM terms + their image gradient beside the discriminator updates (phase_e)
     overlap_wgrad = True
     overlap_wgrad_d = False      # companion streams inside the (already concurrent) discriminator updates cost
                                  # 1.5 ms under hipGraph replay: ROCm 7.2 runs graph branches nearly serially
+
+    def _e_stream(self):
+        if getattr(self, '_estream', None) is None:
+            self._estream = torch.cuda.Stream(device=self.device)
+        return self._estream
 
     def _d_streams(self):
         if getattr(self, '_streams', None) is None:
@@ -280,6 +318,37 @@ class GANStep(object):
 
     def grad_norm(self, flat):
         return flat.grad.double().norm()
+
+    # ---- training state as a whole (checkpoint / resume, trainer.py:159-170 saves netG, the EMA copy and netsD;
+    # the reference restarts Adam from zero moments on resume, this keeps them as well)
+    def _trained(self):
+        return [(self.netG, self.flatG, self.optG)] + list(zip(self.netsD, self.flatD, self.optD))
+
+    def snapshot(self):
+        """Device copies of everything a step mutates: parameters, Adam moments and step counters, the EMA
+        shadow, BatchNorm running statistics / batch counters."""
+        snap = []
+        for net, flat, opt in self._trained():
+            snap.append({'data': flat.data.clone(), 'm': flat.m.clone(), 'v': flat.v.clone(),
+                         'avg': None if flat.avg is None else flat.avg.clone(), 'state': opt.state.clone(),
+                         'buffers': {n: b.detach().clone() for n, b in net.named_buffers()}})
+        return snap
+
+    def restore(self, snap):
+        """Write a snapshot() back in place (pointers are unchanged, so captured graphs stay valid; call
+        GraphedStep.resync() before the next replay: the graphs read packed bf16 copies of the weights)."""
+        for (net, flat, opt), s in zip(self._trained(), snap):
+            flat.data.copy_(s['data'])
+            flat.m.copy_(s['m'])
+            flat.v.copy_(s['v'])
+            if flat.avg is not None:
+                flat.avg.copy_(s['avg'])
+            opt.state.copy_(s['state'])
+            bufs = dict(net.named_buffers())
+            for n, b in s['buffers'].items():
+                bufs[n].copy_(b)
+            flat.epoch[0] += 1
+        ops.weights_changed()
 
 
 # "thread_local": only the capturing thread is policed -- the process group's watchdog thread polls events
@@ -335,6 +404,12 @@ class GraphedStep(object):
             if prologue is not None:
                 prologue()
             gan.phase_a(sent_emb, words_embs, mask, noise)
+        self.gE = None
+        if gan.early_damsm:         # DAMSM terms + image gradient: replayed beside the discriminator updates
+            self.gE = torch.cuda.CUDAGraph()
+            self.estream = gan._e_stream()
+            with torch.cuda.graph(self.gE, stream=self.estream, capture_error_mode=_CAPTURE_MODE):
+                gan.phase_e(sent_emb, words_embs, cap_lens, class_ids)
         if gan.distributed:
             # the gradient exchange (RCCL) stays OUTSIDE the graphs: per network one graph for loss +
             # backward and one for the Adam step, the all-reduce issued eagerly between them
@@ -358,6 +433,16 @@ class GraphedStep(object):
             self.out = gan.phase_b(sent_emb, words_embs, cap_lens, class_ids)
         torch.cuda.synchronize()
 
+    def resync(self):
+        """Bring the packed weight copies the graphs read in line with the f32 masters, eagerly.  Needed after
+        parameters changed behind the graphs' back (GANStep.restore, load_state_dict, a checkpoint): the graphs
+        repack a network only where the capture did, right after its own Adam step."""
+        dt = ops.compute_dtype()
+        for flat in [self.gan.flatG] + list(self.gan.flatD):
+            if flat.packs is not None:
+                flat.packs.refresh(dt)
+        ops.weights_changed()
+
     def replay(self):
         main = torch.cuda.current_stream()
         # the graphs repack the bf16 weight copies at the points where the capture did, without consulting the
@@ -367,6 +452,10 @@ class GraphedStep(object):
         if self.single:
             return self.out
         gan = self.gan
+        if self.gE is not None:
+            self.estream.wait_stream(main)
+            with torch.cuda.stream(self.estream):
+                self.gE.replay()
         if gan.distributed:
             # largest network first: its all-reduce (D256: 287 MB) then runs under the other updates
             order = sorted(range(len(self.gD)), key=lambda i: -gan.flatD[i].n)
@@ -377,6 +466,8 @@ class GraphedStep(object):
             for i in order:
                 gan._allreduce_wait(handles[i])
                 self.gDo[i].replay()
+            if self.gE is not None:
+                main.wait_stream(self.estream)
             self.gB.replay()
             gan._allreduce_wait(gan._allreduce_start(gan.flatG))
             self.gBo.replay()
@@ -387,6 +478,86 @@ class GraphedStep(object):
                 self.gD[i].replay()
         for st in self.dstreams:
             main.wait_stream(st)
+        if self.gE is not None:
+            main.wait_stream(self.estream)
         self.gB.replay()
         return self.out
 
+
+
+class ReplayedStep(object):
+    """GANStep re-issued by the native multi-stream launch replayer (csrc/replay.hip): the whole step is stream-
+    captured ONCE into a hipGraph -- with every fork GANStep.step makes (the three discriminator updates, the
+    branches of the generator loss and of the Inception blocks, weight gradients beside data gradients) -- and the
+    graph is never launched: libsbagan_hip.so walks its nodes and edges and re-issues them as ordinary launches
+    over up to `max_streams` HIP streams.  hipGraphLaunch (GraphedStep) runs those branches nearly back to back
+    on ROCm 7.2; launched this way they overlap, at ~3 us of host time per launch instead of ~20 us from Python.
+
+    Inputs are static tensors.  Random draws stay OUTSIDE the recorded launches (a captured Philox kernel reads an
+    offset that only torch's own graph replay advances): `noise` and `eps` are drawn eagerly by replay().
+    Same contract as GraphedStep for parameters changed behind its back (resync())."""
+
+    def __init__(self, gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, prologue=None,
+                 recorded_prologue=None, max_streams=8, verbose=False):
+        """prologue: called eagerly before every replay (after the random draws); recorded_prologue: deterministic
+        launches recorded in front of the step (e.g. the frozen text encoder's forward, trainer.py:248-252)."""
+        if gan.distributed:
+            raise RuntimeError('ReplayedStep records the whole step; the data-parallel path replays per phase '
+                               '(GraphedStep)')
+        self.gan, self.noise, self.prologue = gan, noise, prologue
+        dev = gan.device
+        self.eps = torch.empty((noise.shape[-2], cfg.GAN.CONDITION_DIM), dtype=torch.float32, device=dev)
+        self.cap = torch.cuda.Stream(device=dev)
+        self.draw = True
+        args = (imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise)
+        self.cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.cap):                   # warm the capture stream (workspaces, packed weights)
+            self._draw()
+            if recorded_prologue is not None:
+                recorded_prologue()
+            gan.step(*args, eps=self.eps)
+        torch.cuda.current_stream().wait_stream(self.cap)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True)
+        with torch.cuda.graph(self.graph, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
+            if recorded_prologue is not None:
+                recorded_prologue()
+            self.out = gan.step(*args, eps=self.eps)
+        torch.cuda.synchronize()
+        raw = self.graph.raw_cuda_graph()
+        self.handle = ctypes.c_void_p()
+        from ._lib import lib
+        rc = lib.sba_replay_create(ctypes.c_void_p(int(raw)), int(max_streams), 1 if verbose else 0,
+                                   ctypes.byref(self.handle))
+        if rc != 0:
+            raise RuntimeError('sba_replay_create failed (%d): the captured step holds a node the replayer '
+                               'cannot re-issue' % rc)
+        info = (ctypes.c_int * 8)()
+        call('sba_replay_info', self.handle, info)
+        self.info = dict(zip(('nodes', 'kernels', 'copies', 'memsets', 'streams', 'waits', 'events'), list(info)))
+        ops.weights_changed()
+
+    def _draw(self):
+        if self.draw:
+            self.noise.normal_(0, 1)
+            self.eps.normal_(0, 1)
+        if self.prologue is not None:
+            self.prologue()
+
+    def resync(self):
+        GraphedStep.resync(self)
+
+    def replay(self):
+        ops.weights_changed()
+        self._draw()
+        call('sba_replay_launch', self.handle, torch.cuda.current_stream().cuda_stream)
+        return self.out
+
+    def __del__(self):
+        h = getattr(self, 'handle', None)
+        if h:
+            try:
+                call('sba_replay_destroy', h)
+            except Exception:
+                pass
+            self.handle = None

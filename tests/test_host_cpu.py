@@ -53,6 +53,8 @@ def test_no_memset_nodes_in_the_library():
     before the following kernel node on ROCm 7.2 (tests/test_step_gpu.py::test_graph_replay_matches_eager_generator)"""
     csrc = os.path.join(ROOT, 'sba-gan_amd', 'csrc')
     for f in os.listdir(csrc):
+        if f == 'replay.hip':       # re-issues a captured graph's memset nodes as EAGER (stream-ordered) memsets
+            continue
         if f.endswith(('.hip', '.h')):
             code = '\n'.join(l.split('//')[0] for l in open(os.path.join(csrc, f)).read().splitlines())
             assert 'hipMemsetAsync' not in code and 'hipMemset(' not in code, f

@@ -139,54 +139,116 @@ def test_discriminator_loss(dev, dt, which):
     assert allr <= (1e-3 if dt == torch.float32 else 5e-2), allr
 
 
-def _build_step(dev, B, variant='model'):
+def _build_step(dev, B, variant='model', branch=3, encoder='standin'):
     import model
     import model_bert
+    from miscc.config import cfg
     from sbagan.trainer import GANStep
+    cfg.TREE.BRANCH_NUM = branch
     v = 'model' if variant == 'model' else 'bert'
     netG = {'model': model.G_NET, 'bert': model_bert.G_NET, 'mix': model_bert.G_NET_MIX}[variant]()
-    netG.load_state_dict(fill.fill_state_dict(g_shapes(FULL, 3, v)))
-    netsD = [model.D_NET64(), model.D_NET128(), model.D_NET256()]
+    netG.load_state_dict(fill.fill_state_dict(g_shapes(FULL, branch, v)))
+    netsD = [model.D_NET64(), model.D_NET128(), model.D_NET256()][:branch]
     for i, d in enumerate(netsD):
         d.load_state_dict(fill.fill_state_dict(d_shapes(FULL, i), salt=i))
     netG.to(dev).train()
     for d in netsD:
         d.to(dev).train()
     netG.set_return_attention(False)
-    enc = fill.StandInImageEncoder(256, device=dev)
+    if encoder == 'inception':      # the benched combination: hand-written Inception-v3 trunk inside the step
+        from sbagan.inception_hip import InceptionHIP
+        torch.manual_seed(101)
+        enc = InceptionHIP(model.CNN_ENCODER(256).to(dev).eval())
+    else:
+        enc = fill.StandInImageEncoder(256, device=dev)
     return GANStep(netG, netsD, enc, B, lr_g=2e-4, lr_d=2e-4)
 
 
-@pytest.mark.parametrize('dt', DTYPES)
-def test_two_training_steps_vs_reference_golden(dev, dt, golden_dir):
-    """The reference's own modules driven in trainer.py order produced these numbers."""
+# (fixture, variant, B, BRANCH_NUM, slim): the reference's own modules driven in trainer.py order produced these
+GOLDEN_STEPS = {
+    'model_b4': ('step_full_model_b4.npz', 'model', 4, 3, False),        # BASELINE config 2 at B=4
+    'bert_b4': ('step_full_bert_b4.npz', 'bert', 4, 3, False),           # config 3 generator (model_bert.py G_NET)
+    'mix_b4': ('step_full_mix_b4.npz', 'mix', 4, 3, False),              # config 5 generator (G_NET_MIX)
+    'stage1_b4': ('step_full_model_b4_branch1.npz', 'model', 4, 1, False),   # config 1 (64 px only)
+    'model_b20': ('step_full_model_b20.npz', 'model', 20, 3, True),      # config 2 at its own batch size
+}
+# stated tolerances on the losses / gradient norms of step 0 (x10 after an Adam update, x3 for discriminator
+# gradient norms): f32 1e-3 = the north star's bar.  bf16 (bf16 storage of activations and packed weights, f32
+# accumulate) is noisy run to run (see test_graph_replay_equals_eager_step_from_same_state): measured against the
+# reference at B=4 up to 4.9e-3 on a discriminator loss and 2.3e-2 on the generator gradient norm; at the
+# benched batch size B=20 (4.5x more logits averaged) losses are within 1.1e-3 and the generator gradient norm
+# within 1.7e-3 (profiles/r02_parity_vs_reference.json).
+LOSS_TOL = {torch.float32: 1e-3, torch.bfloat16: 8e-3}
+LOSS_TOL_B20 = {torch.bfloat16: 3e-3}
+GNORM_G_TOL = {torch.float32: 3e-3, torch.bfloat16: 4e-2}
+
+
+def _golden_case(dev, dt, case, launch, golden_dir):
     from sbagan import ops
+    from sbagan.trainer import GraphedStep
     ops.set_compute_dtype(dt)
-    Gs = load_golden(golden_dir, 'step_full_model_b4.npz')
-    B = 4
-    x = make_inputs(FULL, B, 18, lmax=18, tag=500)
-    st = _build_step(dev, B)
+    fname, variant, B, branch, slim = GOLDEN_STEPS[case]
+    Gs = load_golden(golden_dir, fname)
+    x = make_inputs(FULL, B, 18, branch=branch, lmax=18, tag=500)
+    st = _build_step(dev, B, variant, branch)
     imgs = [i.to(dev) for i in x['imgs']]
     sent, words, mask = x['sent'].to(dev), x['words'].to(dev), x['mask'].to(dev)
     lens = x['cap_lens'].to(dev)
+    nshape = (2, B, 100) if variant == 'mix' else (B, 100)
+    noise, eps = torch.zeros(nshape, device=dev), torch.zeros((B, 100), device=dev)
     f32 = dt == torch.float32
     report = {}
+    graph = None
+    if launch in ('graph', 'replayer'):
+        # capture needs warm buffers (a few eager steps move the parameters), so: snapshot the golden initial
+        # state, warm up, capture, restore the snapshot, resync the packed weights -- then every step below
+        # is a REPLAY (hipGraphLaunch, or the native multi-stream launch replayer) from exactly the reference's
+        # initial state
+        from sbagan.trainer import ReplayedStep
+        snap = st.snapshot()
+        noise.normal_(0, 1)
+        eps.normal_(0, 1)
+        if launch == 'graph':
+            orig = st.phase_a
+            st.phase_a = lambda se, we, m, nz, e=None: orig(se, we, m, nz, eps)
+        for _ in range(2):
+            st.step(imgs, sent, words, mask, lens, x['class_ids'], noise, eps)
+        if launch == 'graph':
+            graph = GraphedStep(st, imgs, sent, words, mask, lens, x['class_ids'], noise)
+        else:
+            graph = ReplayedStep(st, imgs, sent, words, mask, lens, x['class_ids'], noise)
+            graph.draw = False          # the test supplies noise and eps
+            eps = graph.eps
+        st.restore(snap)
+        graph.resync()
     for step in range(2):
-        noise = fill.unit((B, 100), 550 + step).to(dev)
-        eps = torch.from_numpy(Gs['step%d/eps' % step]).to(dev)
-        out = st.step(imgs, sent, words, mask, lens, x['class_ids'], noise, eps)
-        gn = {'gnormD%d' % i: float(st.grad_norm(st.flatD[i])) for i in range(3)}
+        noise.copy_(fill.unit(nshape, 550 + step))
+        eps.copy_(torch.from_numpy(Gs['step%d/eps' % step]))
+        if graph is not None:
+            graph.replay()
+            out = graph.out
+        else:
+            out = st.step(imgs, sent, words, mask, lens, x['class_ids'], noise, eps)
+        gn = {'gnormD%d' % i: float(st.grad_norm(st.flatD[i])) for i in range(branch)}
         gn['gnormG'] = float(st.grad_norm(st.flatG))
         torch.cuda.synchronize()
         vals = {k: float(v) for k, v in out.items() if torch.is_tensor(v)}
         vals.update(gn)
-        base = (1e-3 if f32 else 3e-2) * (10 if step else 1)
-        for k in ('errD0', 'errD1', 'errD2', 'errG_total', 'kl_loss', 'gnormD0', 'gnormD1', 'gnormD2', 'gnormG'):
+        base = (LOSS_TOL_B20 if B == 20 else LOSS_TOL)[dt] * (10 if step else 1)
+        keys = ['errD%d' % i for i in range(branch)] + ['errG_total', 'kl_loss'] + sorted(gn)
+        for k in keys:
             ref = float(Gs['step%d/%s' % (step, k)])
             rel = abs(vals[k] - ref) / max(abs(ref), 1e-12)
             report['s%d/%s' % (step, k)] = rel
             tolk = base * (3 if k.startswith('gnorm') else 1)
-            assert rel <= tolk, (step, k, vals[k], ref, rel)
+            if k == 'gnormG' and not step:
+                tolk = GNORM_G_TOL[dt] * (0.25 if B == 20 else 1)
+            if step and k == 'gnormG':
+                # ill-conditioned: the same step evaluated in float64 differs from the reference's float32 value
+                # by 2.2e-2 (bert; profiles/r02_conditioning.txt, tools/conditioning.py) -- rounding noise through
+                # the discriminators' sign-like first Adam update
+                tolk = max(tolk, 8e-2)
+            assert rel <= tolk, (case, launch, step, k, vals[k], ref, rel)
         for i, f in enumerate(st.fake_imgs):
             if f32 and step == 0:
                 check(Gs, 'step%d/fake%d' % (step, i), f, rtol=2e-3, atol=2e-4)
@@ -195,10 +257,11 @@ def test_two_training_steps_vs_reference_golden(dev, dt, golden_dir):
     import json
     import os
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
-    if os.path.isdir(out_dir):      # relative deviations from the reference's numbers, per dtype
-        with open(os.path.join(out_dir, 'parity_report_%s.json' % str(dt).split('.')[-1]), 'w') as f:
+    if os.path.isdir(out_dir):      # relative deviations from the reference's numbers
+        name = 'parity_report_%s_%s_%s.json' % (case, str(dt).split('.')[-1], launch)
+        with open(os.path.join(out_dir, name), 'w') as f:
             json.dump({k: float('%.3e' % v) for k, v in report.items()}, f, indent=1, sort_keys=True)
-    if f32:
+    if f32 and not slim:
         for n, p in st.netG.state_dict().items():
             if n.endswith('num_batches_tracked'):
                 assert int(p) == int(Gs['final/G/%s/sum' % n]), n
@@ -218,8 +281,31 @@ def test_two_training_steps_vs_reference_golden(dev, dt, golden_dir):
         assert abs(avg_sum - float(Gs['final/avgG_sum'])) <= 1e-3 * abs(float(Gs['final/avgG_sum'])) + 2e-2
 
 
-def test_full_size_step_properties(dev):
-    """BASELINE config 2 shape (B=20, bf16): size-independent properties -- losses finite, every
+@pytest.mark.parametrize('launch', ['eager', 'graph', 'replayer'])
+@pytest.mark.parametrize('dt', DTYPES)
+def test_two_training_steps_vs_reference_golden(dev, dt, launch, golden_dir):
+    """BASELINE config 2 (3-stage, model.py G_NET) at B=4: eager launches, hipGraph replay and the native
+    multi-stream launch replayer (the launch modes bench.py chooses from) are held to the same reference numbers."""
+    _golden_case(dev, dt, 'model_b4', launch, golden_dir)
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('case', ['bert_b4', 'mix_b4', 'stage1_b4'])
+def test_training_steps_other_configs_vs_reference_golden(dev, dt, case, golden_dir):
+    """BASELINE configs 1 (stage 1 only), 3 (model_bert.py G_NET) and 5 (G_NET_MIX), two steps each."""
+    _golden_case(dev, dt, case, 'eager', golden_dir)
+
+
+@pytest.mark.parametrize('launch', ['eager', 'graph', 'replayer'])
+def test_training_steps_b20_vs_reference_golden(dev, launch, golden_dir):
+    """BASELINE config 2 at its own batch size and dtype (B=20, bf16), eager and replayed."""
+    _golden_case(dev, torch.bfloat16, 'model_b20', launch, golden_dir)
+
+
+@pytest.mark.parametrize('encoder', ['standin', 'inception'])
+def test_full_size_step_properties(dev, encoder):
+    """BASELINE config 2 shape (B=20, bf16; `inception` = the benched combination with the hand-written
+    Inception-v3 trunk inside the step): size-independent properties -- losses finite, every
     parameter moved by at most lr per step (Adam bound), EMA = 0.999*old + 0.001*new, BN counters
     advanced exactly as the reference's call pattern implies (D trunk: 2 fwd in the D step + 1 in
     the G step = 3 per step)."""
@@ -227,7 +313,7 @@ def test_full_size_step_properties(dev):
     from sbagan.synth import synthetic_batch
     ops.set_compute_dtype(torch.bfloat16)
     B = 20
-    st = _build_step(dev, B)
+    st = _build_step(dev, B, encoder=encoder)
     b = synthetic_batch(B, device=dev, seed=100)
     p0 = st.flatG.data.clone()
     d0 = [f.data.clone() for f in st.flatD]
@@ -317,16 +403,24 @@ def test_graphed_step_tracks_eager_step(dev):
         last = cur
 
 
-def test_graphed_step_equals_eager_step(dev):
-    """Two identical trainers (same closed-form parameters, inputs, noise, eps) run in lockstep: one steps
-    eagerly, the other is replayed from the per-phase hipGraphs after the same warm-up.  Every loss of every
-    replayed step tracks the eager trainer's step (bf16 path; tolerance = atomic-order noise carried over a few
-    updates of a fast-moving GAN).  (The graphs repack the bf16 weight copies where the capture did, so parameters must not be
-    modified behind their back between replays -- hence two trainers instead of snapshot / restore.)"""
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('encoder', ['standin', 'inception'])
+def test_graph_replay_equals_eager_step_from_same_state(dev, encoder, dt):
+    """ONE step from IDENTICAL state, eager vs hipGraph replay (B=20; bf16 = the benched mode, f32 = the tight
+    yardstick): after warm-up and capture the whole training state is snapshotted; it is restored (and the packed
+    weights resynced) before each of two eager steps and two replays.
+
+    Two eager runs from the same state already differ -- f32 atomic order perturbs BatchNorm statistics and
+    split-K sums at 1e-7, and in bf16 every such perturbation has a ~2.5 % chance per element to flip a rounding,
+    which cascades through the layers (measured run to run, tools/debug_determinism.py: D_NET256 loss 1.5e-3,
+    gradients 2-9 %; f32: loss 1e-7, gradients 2e-4).  So the bound is the measured eager-vs-eager noise: a replay
+    may differ from an eager step by at most 4x the largest difference among four eager runs (+ a small floor), for every loss, every network's gradient,
+    the BatchNorm running statistics and the fake images.  A replay defect (stale packed weights, a mis-ordered
+    node, a missing accumulator clear) is O(1) against these bounds."""
     from sbagan import ops
     from sbagan.synth import synthetic_batch
     from sbagan.trainer import GraphedStep
-    ops.set_compute_dtype(torch.bfloat16)
+    ops.set_compute_dtype(dt)
     B = 20
     b = synthetic_batch(B, device=dev, seed=100)
     gen = torch.Generator(device='cpu')
@@ -334,30 +428,61 @@ def test_graphed_step_equals_eager_step(dev):
     noise = torch.randn((B, 100), generator=gen).to(dev)
     eps = torch.randn((B, 100), generator=gen).to(dev)
     args = (b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'], b['class_ids'], noise)
-    trainers = []
-    for _ in range(2):
-        st = _build_step(dev, B)
-        orig = st.phase_a
-        st.phase_a = (lambda o: (lambda se, we, m, nz, e=None: o(se, we, m, nz, eps)))(orig)   # fixed eps everywhere
-        trainers.append(st)
-    eager, graphed = trainers
+    st = _build_step(dev, B, encoder=encoder)
+    orig = st.phase_a
+    st.phase_a = lambda se, we, m, nz, e=None: orig(se, we, m, nz, eps)      # fixed eps, eager and captured
     for _ in range(3):
-        eager.step(*args)
-        graphed.step(*args)
+        st.step(*args)
+    graph = GraphedStep(st, *args)
+    from sbagan.trainer import ReplayedStep
+    rs = ReplayedStep(st, *args)
+    rs.draw = False
+    rs.eps.copy_(eps)
     torch.cuda.synchronize()
-    graph = GraphedStep(graphed, *args)          # runs one more eager step on the capture stream, then captures
-    eager.step(*args)
-    for r in range(3):
-        out_e = {k: float(v) for k, v in eager.step(*args).items()}
-        graph.replay()
+    snap = st.snapshot()
+
+    def run(fn):
+        st.restore(snap)
+        graph.resync()
+        out = fn()
         torch.cuda.synchronize()
-        out_g = {k: float(v) for k, v in graph.out.items()}
-        # the two trainers drift apart through atomic-order noise that these early, fast-moving GAN steps amplify
-        # (measured: up to 12 % on a discriminator loss after two more updates); a replay defect shows as a
-        # collapsed stage (losses at the BCE clamp), NaN, or factors
-        rel, ab = (0.2, 0.01) if r == 0 else (0.5, 0.03)
-        for k, v in out_e.items():
-            assert abs(out_g[k] - v) <= rel * abs(v) + ab, (r, k, out_g[k], v)
+        r = {'loss/%s' % k: v.detach().float().reshape(1).clone() for k, v in out.items() if torch.is_tensor(v)}
+        r['grad/G'] = st.flatG.grad.clone()
+        for i, f in enumerate(st.flatD):
+            r['grad/D%d' % i] = f.grad.clone()
+        for i, net in enumerate([st.netG] + st.netsD):
+            for n, t in net.named_buffers():
+                if n.endswith(('running_mean', 'running_var')):
+                    r['buf/%d/%s' % (i, n)] = t.detach().float().clone()
+        for i, f in enumerate(st.fake_imgs):
+            r['fake/%d' % i] = f.float().clone()
+        return r
+
+    def eager():
+        return st.step(*args)
+
+    def replay():
+        graph.replay()
+        return graph.out
+
+    def replay_native():
+        rs.replay()
+        return rs.out
+    es = [run(eager) for _ in range(4)]
+    e1 = es[0]
+    g1, g2 = run(replay), run(replay)
+    n1, n2 = run(replay_native), run(replay_native)
+    floor = {'loss': 1e-6, 'grad': 1e-5, 'buf': 1e-6, 'fake': 1e-6}
+    worst = {}
+    for k in e1:
+        noise_k = max(rel_l2(es[i][k], es[j][k]) for i in range(4) for j in range(i))
+        bound = 4 * noise_k + floor[k.split('/')[0]]
+        for name, g in (('replay 1', g1), ('replay 2', g2), ('native replay 1', n1), ('native replay 2', n2)):
+            d = rel_l2(g[k], e1[k])
+            worst[k.split('/')[0]] = max(worst.get(k.split('/')[0], 0.0), d)
+            assert d <= bound, (name, k, 'replay vs eager %.3e' % d, 'eager vs eager %.3e' % noise_k)
+    if dt == torch.float32:     # absolute statement where the arithmetic is quiet enough to make one
+        assert worst['loss'] <= 1e-4 and worst['fake'] <= 1e-4, worst
 
 
 @pytest.mark.parametrize('dt', DTYPES)
