@@ -203,14 +203,15 @@ def supervise(args):
     of losing the measurement.  The parent never touches the GPU."""
     import subprocess
     base = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]] + ['--child']
-    for extra in ([], ['--graph', '0']):
+    ladder = [[], ['--graph', '1'], ['--graph', '0']]     # all launch modes -> hipGraph only -> eager
+    for n, extra in enumerate(ladder):
         p = subprocess.run(base + extra, stdout=subprocess.PIPE, text=True)
         lines = [l for l in p.stdout.splitlines() if l.startswith('{') and '"metric"' in l]
         if p.returncode == 0 and lines:
             print(lines[-1], flush=True)
             return 0
-        sys.stderr.write('bench child failed (rc=%d)%s\n' % (p.returncode, '; retrying with eager launches'
-                                                               if not extra else ''))
+        sys.stderr.write('bench child failed (rc=%d)%s\n' % (p.returncode, '; retrying with %s'
+                                                               % ' '.join(ladder[n + 1]) if n + 1 < len(ladder) else ''))
     return 1
 
 

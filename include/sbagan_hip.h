@@ -61,7 +61,12 @@ typedef struct sba_conv_geom {
      * (x_cstride = Cin, y_cstride = Cout).  Honoured by sba_conv_igemm only. */
     int32_t x_cstride, x_coff, y_cstride, y_coff;
     int32_t relu;               /* epilogue: y = max(acc + bias, 0) when set (with `bias`) */
+    /* tile configuration of sba_conv_igemm: 0 = the library's rule table; 1..SBA_IGEMM_TILES = a specific one
+     * (measured per layer shape by tools/tune_igemm.py into sbagan/igemm_table.json; bf16 only, an id the
+     * geometry cannot use falls back to the rules).  ksplit: 0 = the library decides, n >= 1 = split K n ways. */
+    int32_t tile, ksplit;
 } sba_conv_geom;
+#define SBA_IGEMM_TILES 12
 
 const char* sba_version(void);
 

@@ -541,20 +541,36 @@ __device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t rsrc, con
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
+#ifdef SBA_DMA_TRACE     // tools/trace_dma.py: per-stage s_memtime stamps of wave 0 of the first workgroups
+static unsigned long long* g_dma_trace = nullptr;
+extern "C" void sba_set_dma_trace(unsigned long long* p) { g_dma_trace = p; }
+#define DMA_TRACE_PARAM , unsigned long long* __restrict__ trace
+#define DMA_TRACE_ARG , g_dma_trace
+#define DMA_STAMP(slot) do { if (trace && L < 32 && tid == 0 && s < 30) { asm volatile("" ::: "memory"); \
+    trace[(L * 32 + s) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } } while (0)
+#else
+#define DMA_TRACE_PARAM
+#define DMA_TRACE_ARG
+#define DMA_STAMP(slot) do { } while (0)
+#endif
+
 template <int BM, int BN, int WM, int WN, int KS, int D>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
     const bf16_t* __restrict__ addend, float* __restrict__ stats, const sba_conv_geom g, const int M,
-    float* __restrict__ ws, const int slabs_per_split, const EpiX ex, const int gx, const int gy) {
+    float* __restrict__ ws, const int slabs_per_split, const EpiX ex, const int gx, const int gy DMA_TRACE_PARAM) {
     typedef bf16_t T;
     constexpr int TM = WM / 32, TN = WN / 32, WAVES_N = BN / WN;
     constexpr int NW = (BM / WM) * (BN / WN), NT = NW * 64;
-    static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "every wave issues the same number of DMA loads");
-    constexpr int AI = BM / (16 * NW), BI = BN / (16 * NW);
-    constexpr int SLAB_BYTES = (BM + BN) * 64, STAGE_BYTES = KS * SLAB_BYTES, RING_BYTES = D * STAGE_BYTES;
+    // every wave issues the same number of DMA loads per slab (the vmcnt bookkeeping is per wave): the weight
+    // rows are padded to BNL, a multiple of 16 * NW; the padding rows load zeros (out of range) and are never read
+    static_assert(BM % (16 * NW) == 0, "A rows divide evenly over the waves");
+    constexpr int BNL = ((BN + 16 * NW - 1) / (16 * NW)) * (16 * NW);
+    constexpr int AI = BM / (16 * NW), BI = BNL / (16 * NW);
+    constexpr int SLAB_BYTES = (BM + BNL) * 64, STAGE_BYTES = KS * SLAB_BYTES, RING_BYTES = D * STAGE_BYTES;
     constexpr int LPS = KS * (AI + BI);                       // DMA loads per thread per stage
     static_assert(D >= 3 && (D - 2) * LPS <= 63, "vmcnt field");
-    static_assert(RING_BYTES <= 65536, "DMA destinations stay within the first 64 KiB of LDS (M0 offset field)");
+    static_assert(RING_BYTES <= 160 * 1024, "LDS");           // (DMA destinations beyond 64 KiB work: tools/ldsdma_probe.hip)
     constexpr int EPI_OFF = BM * (BN * 2 + 16);
     constexpr int EPI_END = EPI_OFF + BM * 4 + BN * 8;
     constexpr int LDS_BYTES = RING_BYTES > EPI_END ? RING_BYTES : EPI_END;
@@ -616,8 +632,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(
     const uint32_t krow_bytes = (uint32_t)g.ntaps * (uint32_t)g.Cin * 2u;
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-        const int co = n_base + 16 * (wid + NW * i) + rsub;
-        w_off[i] = co < g.Cout ? (uint32_t)co * krow_bytes + chunk * 16u : OOB;
+        const int r = 16 * (wid + NW * i) + rsub, co = n_base + r;
+        w_off[i] = (r < BN && co < g.Cout) ? (uint32_t)co * krow_bytes + chunk * 16u : OOB;
     }
     const uint32_t x_bytes = (uint32_t)((int64_t)g.N * g.IH * g.IW * xcs * 2);
     const uint32_t w_bytes = (uint32_t)g.Cout * krow_bytes;
@@ -685,11 +701,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(
     if (idst == idst_end) idst = lds_wave;
     const unsigned char* cptr = lds_all;
     for (int s = 0; s < nstages; ++s) {
+        DMA_STAMP(0);
         wait_vmcnt<(D - 2) * LPS>();        // this wave's part of stage s has landed ...
+        DMA_STAMP(1);
         wg_barrier();                       // ... and everybody else's; nobody reads buffer (s - 1) % D any more
+        DMA_STAMP(2);
         issue(idst);                        // stage s + D - 1 (zeros past the end) into that buffer
         idst += STAGE_BYTES;
         if (idst == idst_end) idst = lds_wave;
+        DMA_STAMP(3);
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const unsigned char* base = cptr + k * SLAB_BYTES;
@@ -719,8 +739,285 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(
         }
         cptr += STAGE_BYTES;
         if (cptr == lds_all + RING_BYTES) cptr = lds_all;
+#ifdef SBA_DMA_TRACE
+        { float keep = 0.f;             // make the stamp wait for the MFMA results of this stage
+#pragma unroll
+          for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) keep += acc[i][j][0];
+          asm volatile("" :: "v"(keep)); }
+        DMA_STAMP(4);
+#endif
     }
     wait_vmcnt<0>();        // the dead stages issued past the end still write (zeros) into the ring
+    wg_barrier();
+
+    if (ws) {
+        const int col_s = lane & 31, rsel_s = 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int co = n_base + wn0 + j * 32 + col_s;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m_base + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel_s;
+                    if (m < M && co < g.Cout) atomicAdd(&ws[(int64_t)m * g.Cout + co], acc[i][j][r]);
+                }
+        }
+        return;
+    }
+    for (int r = threadIdx.x; r < BM; r += NT) {
+        const int m = m_base + r;
+        int off = -1;
+        if (m < M) {
+            const int n = m / sub, rem = m - n * sub;
+            const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
+            off = (n * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox;
+        }
+        rowoff[r] = off;
+    }
+    for (int c = threadIdx.x; c < 2 * BN; c += NT) s_stat[c] = 0.f;
+    __syncthreads();
+    tile_epilogue<T, BM, BN, TM, TN, NT, LDS_BYTES>(acc, true, lds_all, rowoff, s_stat, wm0, wn0, lane, n_base, ycs, g, y,
+                                                    addend, stats, ex, mt + (int)blockIdx.z);
+}
+
+// ---------------------------------------------------------------------------
+// Second-generation LDS-DMA implicit GEMM (bf16, Cin % 64 == 0).  Per-stage s_memtime stamps of the kernel above
+// (tools/trace_dma.py, profiles/r02_dma_stage_trace.txt) showed where a 64-deep stage of a 64x64 tile spends its
+// ~1200 cycles: ~0 waiting for data, 80 in the barrier, ~430 ISSUING four DMA loads per wave (~100 cycles per
+// buffer_load ... lds: each instruction touches 16 half cache lines) and ~450 in ds_read -> MFMA with nothing
+// overlapping either.  Hence:
+//   * slabs of 64 channels: LDS rows of 128 B = whole cache lines, 8 rows per DMA instruction (half the lines
+//     per instruction); chunk c of row r lives at chunk c ^ ((r >> 1) & 7) -- every 16-lane phase of a
+//     ds_read_b128 covers all 64 banks;
+//   * the fragments of stage t+1 are read into a second register set right after the barrier, and the MFMAs of
+//     stage t run interleaved with the DMA issue of stage t+D: LDS latency, matrix pipe and the load-issue
+//     stall of one wave overlap each other;
+//   * the buffer of stage t is free as soon as its fragments sit in registers (all waves' reads are drained
+//     before the barrier), so the ring keeps D full stages in flight with D buffers.
+// Everything else (zero-filled out-of-range taps / rows / dead stages, XCD-aware tile numbering, split-K into
+// the f32 workspace, shared epilogue) is as in the kernel above.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int D>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma2_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+    const bf16_t* __restrict__ addend, float* __restrict__ stats, const sba_conv_geom g, const int M,
+    float* __restrict__ ws, const int slabs_per_split, const EpiX ex, const int gx, const int gy DMA_TRACE_PARAM) {
+    typedef bf16_t T;
+    constexpr int TM = WM / 32, TN = WN / 32, WAVES_N = BN / WN;
+    constexpr int NW = (BM / WM) * (BN / WN), NT = NW * 64;
+    static_assert(BM % (8 * NW) == 0, "A rows divide evenly over the waves");
+    constexpr int BNL = ((BN + 8 * NW - 1) / (8 * NW)) * (8 * NW);     // weight rows padded: same DMA count per wave
+    constexpr int AI = BM / (8 * NW), BI = BNL / (8 * NW);
+    constexpr int STAGE_BYTES = (BM + BNL) * 128, RING_BYTES = D * STAGE_BYTES;
+    constexpr int LPS = AI + BI;                               // DMA loads per thread per stage
+    constexpr int NM = 4 * TM * TN;                            // MFMAs per wave per stage
+    static_assert(D >= 2 && (D - 1) * LPS <= 63, "vmcnt field");
+    static_assert(RING_BYTES <= 160 * 1024, "LDS");
+    constexpr int EPI_OFF = BM * (BN * 2 + 16);
+    constexpr int EPI_END = EPI_OFF + BM * 4 + BN * 8;
+    constexpr int LDS_BYTES = RING_BYTES > EPI_END ? RING_BYTES : EPI_END;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds_all[LDS_BYTES];
+    int* rowoff = reinterpret_cast<int*>(lds_all + EPI_OFF);
+    float* s_stat = reinterpret_cast<float*>(lds_all + EPI_OFF + BM * 4);
+
+    const int L = blockIdx.x, xcd = L & 7, q = L >> 3;
+    const int mt = xcd + 8 * (q / gy), nt = q - (q / gy) * gy;
+    if (mt >= gx) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+    const int m_base = mt * BM, n_base = nt * BN;
+    const int IHL = g.ups ? 2 * g.IH : g.IH, IWL = g.ups ? 2 * g.IW : g.IW;
+    const int sub = g.OHs * g.OWs;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_all;
+
+    // DMA instruction i of wave `wid` covers tile rows 8 * (wid + NW * i) .. +8, 8 lanes (128 B) per row
+    const int rsub = lane >> 3;
+    int a_iy0[AI], a_ix0[AI], a_nb[AI];
+    uint32_t a_chunk[AI], w_off[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int r = 8 * (wid + NW * i) + rsub, m = m_base + r;
+        a_chunk[i] = (uint32_t)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
+        if (m < M) {
+            const int n = m / sub, rem = m - n * sub;
+            const int oy = rem / g.OWs, ox = rem - oy * g.OWs;
+            a_iy0[i] = oy * g.sy;
+            a_ix0[i] = ox * g.sx;
+            a_nb[i] = n * g.IH * g.IW;
+        } else {
+            a_iy0[i] = -100000;
+            a_ix0[i] = 0;
+            a_nb[i] = 0;
+        }
+    }
+    const int cpt = g.Cin / 64;               // slabs per tap
+    const int nsteps = g.ntaps * cpt;
+    uint64_t tyb[2] = {0, 0}, txb[2] = {0, 0};
+#pragma unroll
+    for (int t = 0; t < SBA_MAX_TAPS; ++t) {
+        tyb[t >> 4] |= (uint64_t)((g.ty[t] + 8) & 15) << (4 * (t & 15));
+        txb[t >> 4] |= (uint64_t)((g.tx[t] + 8) & 15) << (4 * (t & 15));
+    }
+    const int xcs = g.x_cstride ? g.x_cstride : g.Cin;
+    const int ycs = g.y_cstride ? g.y_cstride : g.Cout;
+    const int s_begin = blockIdx.z * slabs_per_split;
+    const int s_end = min(s_begin + slabs_per_split, nsteps);
+    int g_tap = s_begin / cpt, g_c = s_begin - g_tap * cpt, g_step = s_begin;
+    int cur_tap = -1;
+    constexpr uint32_t OOB = 0xFFFFFFFFu;
+    uint32_t a_off[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) a_off[i] = OOB;
+    const uint32_t krow_bytes = (uint32_t)g.ntaps * (uint32_t)g.Cin * 2u;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int r = 8 * (wid + NW * i) + rsub, co = n_base + r;
+        w_off[i] = (r < BN && co < g.Cout) ? (uint32_t)co * krow_bytes + (uint32_t)(((lane & 7) ^ ((r >> 1) & 7)) * 16)
+                                           : OOB;
+    }
+    const uint32_t x_bytes = (uint32_t)((int64_t)g.N * g.IH * g.IW * xcs * 2);
+    const uint32_t w_bytes = (uint32_t)g.Cout * krow_bytes;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, w_bytes, 0x00020000);
+    const uint32_t lds_wave = lds_base + (uint32_t)(wid * 1024);
+
+    // per-stage bookkeeping, split from the loads so that the loads can be spread between the MFMAs
+    bool st_live = false;
+    uint32_t st_sa = 0, st_sw = 0;
+    auto stage_begin = [&]() {
+        st_live = g_step < s_end;
+        if (st_live) {
+            if (g_tap != cur_tap) {             // (uniform) new tap: per-lane pixel offsets
+                cur_tap = g_tap;
+                const int tsel = g_tap < SBA_MAX_TAPS ? g_tap : 0;
+                const uint64_t tyw = tsel < 16 ? tyb[0] : tyb[1], txw = tsel < 16 ? txb[0] : txb[1];
+                const int ty = (int)((tyw >> (4 * (tsel & 15))) & 15) - 8;
+                const int tx = (int)((txw >> (4 * (tsel & 15))) & 15) - 8;
+#pragma unroll
+                for (int i = 0; i < AI; ++i) {
+                    int iy = a_iy0[i] + ty, ix = a_ix0[i] + tx;
+                    const bool ok = (iy >= 0) & (iy < IHL) & (ix >= 0) & (ix < IWL);
+                    if (g.ups) { iy >>= 1; ix >>= 1; }
+                    const uint32_t o = (uint32_t)(a_nb[i] + iy * g.IW + ix) * (uint32_t)(xcs * 2) +
+                                       (uint32_t)(g.x_coff * 2) + a_chunk[i];
+                    a_off[i] = ok ? o : OOB;
+                }
+            }
+            st_sa = (uint32_t)g_c * 128u;
+            st_sw = (uint32_t)g_step * 128u;
+            ++g_step;
+            if (++g_c == cpt) { g_c = 0; ++g_tap; }
+        } else {
+            st_sa = st_sw = 0u;
+        }
+    };
+    auto stage_load = [&](const int qd, const uint32_t dst0) {       // qd = 0 .. LPS-1 (compile-time after unrolling)
+        if (qd < AI) {
+            const uint32_t o = st_live ? a_off[qd < AI ? qd : 0] : OOB;
+            lds_dma16(xr, o, st_sa, dst0 + (uint32_t)(NW * qd * 1024));
+        } else {
+            const int i = qd - AI;
+            const uint32_t o = st_live ? w_off[(i >= 0 && i < BI) ? i : 0] : OOB;
+            lds_dma16(wr, o, st_sw, dst0 + (uint32_t)(BM * 128 + NW * i * 1024));
+        }
+    };
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addressing: lane l reads row (l & 31), logical chunk 2 * kk + (l >> 5), swizzled by its row
+    const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+    int foff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) foff[kk] = fr * 128 + (((2 * kk + fh) ^ fsw) << 4);
+
+    struct Frags { bf16x8_t a[4][TM], b[4][TN]; };
+    auto read_frags = [&](Frags& F, const unsigned char* base) {
+        const unsigned char* ar = base + wm0 * 128;
+        const unsigned char* br = base + (BM + wn0) * 128;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) F.a[kk][i] = *reinterpret_cast<const bf16x8_t*>(ar + i * 4096 + foff[kk]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) F.b[kk][j] = *reinterpret_cast<const bf16x8_t*>(br + j * 4096 + foff[kk]);
+        }
+    };
+
+    const int nstages = s_end - s_begin;
+    uint32_t idst = lds_wave;
+    const uint32_t idst_end = lds_wave + (uint32_t)RING_BYTES;
+#pragma unroll
+    for (int p = 0; p < D; ++p) {
+        stage_begin();
+#pragma unroll
+        for (int qd = 0; qd < LPS; ++qd) stage_load(qd, idst);
+        idst += STAGE_BYTES;
+    }
+    idst = lds_wave;
+    const unsigned char* rptr = lds_all;            // buffer of the stage whose fragments are read next
+    Frags F0, F1;
+    wait_vmcnt<(D - 1) * LPS>();
+    wg_barrier();
+    read_frags(F0, rptr);
+    rptr += STAGE_BYTES;
+    if (rptr == lds_all + RING_BYTES) rptr = lds_all;
+
+    // one stage: fragments of stage t in Fc (their reads are in flight), stage t+1 -> Fn, DMA of stage t+D
+    int s = 0;              // (stage counter of the trace build)
+    auto stage = [&](Frags& Fc, Frags& Fn) {
+        DMA_STAMP(0);
+        wait_vmcnt<(D - 2) * LPS>();                // this wave's part of stage t+1 has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // ... and its reads of stage t are in registers
+        DMA_STAMP(1);
+        wg_barrier();                               // everybody's: buffer t is free, buffer t+1 is complete
+        DMA_STAMP(2);
+        read_frags(Fn, rptr);
+        rptr += STAGE_BYTES;
+        if (rptr == lds_all + RING_BYTES) rptr = lds_all;
+        stage_begin();
+        DMA_STAMP(3);
+        int qd = 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Fc.a[kk][i], Fc.b[kk][j], acc[i][j], 0, 0, 0);
+                    const int m = (kk * TM + i) * TN + j;
+                    // spread the LPS loads evenly between the NM MFMAs
+                    if (((m + 1) * LPS) / NM > (m * LPS) / NM) {
+#pragma unroll
+                        for (int u = (m * LPS) / NM; u < ((m + 1) * LPS) / NM; ++u) stage_load(u, idst);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        (void)qd;
+        idst += STAGE_BYTES;
+        if (idst == idst_end) idst = lds_wave;
+#ifdef SBA_DMA_TRACE
+        { float keep = 0.f;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) keep += acc[i][j][0];
+          asm volatile("" :: "v"(keep)); }
+        DMA_STAMP(4);
+#endif
+        ++s;
+    };
+    for (int t = 0; t < nstages; t += 2) {
+        stage(F0, F1);
+        if (t + 1 < nstages) stage(F1, F0);
+    }
+    wait_vmcnt<0>();        // the dead stages issued past the end still write (zeros) into the ring
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wg_barrier();
 
     if (ws) {
@@ -1658,7 +1955,26 @@ static void launch_dma(const bf16_t* xp, const bf16_t* wp, bf16_t* yp, const bf1
     const int gx = cdiv(M, BM), gy = cdiv(g.Cout, BN);
     dim3 grid(8 * cdiv(gx, 8) * gy, 1, split);
     SBA_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, KS, D>), grid, dim3(NT), 0, st, xp, wp, yp, ap, stats, g, M,
-               split > 1 ? ws : (float*)nullptr, sps, ex, gx, gy);
+               split > 1 ? ws : (float*)nullptr, sps, ex, gx, gy DMA_TRACE_ARG);
+    if (split > 1) {
+        dim3 fgrid(cdiv(g.Cout / 4, 256), cdiv(M, 8));
+        SBA_LAUNCH((splitk_finish_kernel<bf16_t>), fgrid, dim3(256), 0, st, ws, yp, ap, stats, g, M, ex);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int D>
+static void launch_dma2(const bf16_t* xp, const bf16_t* wp, bf16_t* yp, const bf16_t* ap, float* stats,
+                        const sba_conv_geom& g, int M, int nslabs64, int split, float* ws, hipStream_t st, const EpiX ex) {
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    int sps = nslabs64;
+    if (split > 1) {
+        sps = cdiv(nslabs64, split);
+        split = cdiv(nslabs64, sps);
+    }
+    const int gx = cdiv(M, BM), gy = cdiv(g.Cout, BN);
+    dim3 grid(8 * cdiv(gx, 8) * gy, 1, split);
+    SBA_LAUNCH((igemm_dma2_kernel<BM, BN, WM, WN, D>), grid, dim3(NT), 0, st, xp, wp, yp, ap, stats, g, M,
+               split > 1 ? ws : (float*)nullptr, sps, ex, gx, gy DMA_TRACE_ARG);
     if (split > 1) {
         dim3 fgrid(cdiv(g.Cout / 4, 256), cdiv(M, 8));
         SBA_LAUNCH((splitk_finish_kernel<bf16_t>), fgrid, dim3(256), 0, st, ws, yp, ap, stats, g, M, ex);
@@ -1753,16 +2069,59 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
         }
     }
     float* ws = (float*)workspace;
-    if (sizeof(T) == 2 && best <= 3 && dma_enabled()) {
+    if (sizeof(T) == 2 && dma_enabled()) {
         const bf16_t* xb = (const bf16_t*)x; const bf16_t* wb = (const bf16_t*)w; bf16_t* yb = (bf16_t*)y;
         const bf16_t* ab = (const bf16_t*)addend;
-        switch (best) {
-            case 0: launch_dma<128, 128, 64, 64, 1, 4>(xb, wb, yb, ab, stats, g, M, nslabs, best_split, ws, st, ex); break;
-            case 1: launch_dma<256, 64, 64, 64, 1, 3>(xb, wb, yb, ab, stats, g, M, nslabs, best_split, ws, st, ex); break;
-            case 2: launch_dma<128, 64, 32, 64, 1, 4>(xb, wb, yb, ab, stats, g, M, nslabs, best_split, ws, st, ex); break;
-            default: launch_dma<64, 64, 32, 32, 2, 4>(xb, wb, yb, ab, stats, g, M, nslabs, best_split, ws, st, ex); break;
+        // tile ids (include/sbagan_hip.h: sba_conv_geom.tile): BM x BN, slabs per stage, ring depth
+        //   1/2: 64x64 (64 / 128 KB of LDS)   3/4: 96x64 (72 / 144 KB)   5/6: 128x64 (48 / 144 KB)
+        //   7/8: 128x128 (64 / 128 KB)        9/10: 256x64 (60 / 120 KB) 11: 320x128 register-staged   12: 96x128 (120 KB)
+        // the deep rings keep ~100 KB of loads in flight per CU: an L2-hit load takes ~1 us under load, so a
+        // workgroup alone on its CU moves bytes_in_flight / 1 us (measured 36-42 GB/s with 48 KB in flight)
+        int tile = g.tile;
+        int split = best_split;
+        if (tile <= 0 || tile > SBA_IGEMM_TILES) {
+            static const int rule_tile[4] = {7, 9, 5, 1};
+            tile = best <= 3 ? rule_tile[best] : 11;
+        } else if (g.ksplit >= 1) {
+            split = g.ksplit;
+            if (split > 1 && !(workspace && g.Cout % 4 == 0 && (int64_t)M * g.Cout * 4 <= ws_bytes)) split = 1;
+            if (split > nslabs / 2) split = nslabs / 2 > 0 ? nslabs / 2 : 1;
         }
-        return SBA_CHECK_LAUNCH();
+        static int gen2 = -1;       // SBA_IGEMM_DMA2=0: first-generation kernels only (A/B aid)
+        if (gen2 < 0) { const char* e = getenv("SBA_IGEMM_DMA2"); gen2 = (e && e[0] == '0') ? 0 : 1; }
+        if (gen2 && g.Cin % 64 == 0 && tile != 11) {
+            // 128-byte rows, fragment double buffering, DMA issue between the MFMAs (igemm_dma2_kernel)
+            const int ns64 = nslabs / 2;
+            int sp = split;
+            if (sp > ns64 / 2) sp = ns64 / 2 > 0 ? ns64 / 2 : 1;
+            switch (tile) {
+                case 1: launch_dma2<64, 64, 32, 32, 4>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
+                case 2: launch_dma2<64, 64, 32, 32, 8>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
+                case 3: launch_dma2<96, 64, 32, 64, 3>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
+                case 4: launch_dma2<96, 64, 32, 64, 6>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
+                case 5: launch_dma2<128, 64, 32, 64, 3>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
+                case 6: launch_dma2<128, 64, 32, 64, 6>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
+                case 7: launch_dma2<128, 128, 64, 64, 3>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
+                case 8: launch_dma2<128, 128, 64, 64, 4>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
+                case 9: launch_dma2<256, 64, 64, 64, 3>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
+                case 10: launch_dma2<256, 64, 64, 64, 4>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
+                default: launch_dma2<96, 128, 32, 128, 5>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
+            }
+        }
+        switch (tile) {
+            case 1: launch_dma<64, 64, 32, 32, 2, 4>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
+            case 2: launch_dma<64, 64, 32, 32, 2, 8>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
+            case 3: launch_dma<96, 64, 32, 64, 2, 3>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
+            case 4: launch_dma<96, 64, 32, 64, 2, 6>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
+            case 5: launch_dma<128, 64, 32, 64, 1, 4>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
+            case 6: launch_dma<128, 64, 32, 64, 2, 6>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
+            case 7: launch_dma<128, 128, 64, 64, 1, 4>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
+            case 8: launch_dma<128, 128, 64, 64, 1, 8>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
+            case 9: launch_dma<256, 64, 64, 64, 1, 3>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
+            case 10: launch_dma<256, 64, 64, 64, 1, 6>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
+            case 12: launch_dma<96, 128, 32, 128, 1, 8>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
+            default: best = 4; best_split = split; break;      // 11: the register-staged 320x128 tile below
+        }
     }
     switch (best) {
         case 0: launch_cfg<T, 128, 128, 64, 64, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;

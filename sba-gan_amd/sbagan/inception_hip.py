@@ -151,6 +151,7 @@ class InceptionHIP(object):
 
     def _igemm(self, x_ptr, w, y_ptr, addend_ptr, bias, g, mask_ptr=None):
         ws = ops.workspace(self.device)
+        ops.tune_geom(g, self._dt())
         call('sba_conv_igemm_bias', self._dt(), x_ptr, w.data_ptr(), y_ptr, addend_ptr,
              None, None if bias is None else bias.data_ptr(), mask_ptr, ctypes.byref(g), ws.data_ptr(),
              ops.WORKSPACE_BYTES, ops._stream())

@@ -341,8 +341,42 @@ def workspace(device):
     return ws
 
 
+# ---- measured tile table (tools/tune_igemm.py -> sbagan/igemm_table.json) --------------------------------
+# key -> [tile, ksplit]: the tile configuration / K split of sba_conv_igemm that was fastest for that layer shape
+# on an MI355X (bf16).  Shapes that are not in the table use the library's rule table (tile = 0).
+IGEMM_LOG = None            # set to a list to record the geometry of every implicit-GEMM launch (tuning aid)
+_IGEMM_TABLE = None
+
+
+def geom_key(g):
+    return '%d_%dx%d_%d_%dx%d_%d_t%d_s%d_u%d' % (g.N, g.IH, g.IW, g.Cin, g.OHs, g.OWs, g.Cout, g.ntaps, g.sy, g.ups)
+
+
+def _igemm_table():
+    global _IGEMM_TABLE
+    if _IGEMM_TABLE is None:
+        _IGEMM_TABLE = {}
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'igemm_table.json')
+        if os.environ.get('SBA_IGEMM_TABLE', '1') != '0' and os.path.exists(path):
+            import json
+            with open(path) as f:
+                _IGEMM_TABLE = json.load(f).get('bf16', {})
+    return _IGEMM_TABLE
+
+
+def tune_geom(g, dt):
+    """Fill g.tile / g.ksplit from the measured table, once per geometry object."""
+    if getattr(g, '_tuned', None) != dt:
+        g._tuned = dt
+        ent = _igemm_table().get(geom_key(g)) if dt == _lib.SBA_BF16 else None
+        g.tile, g.ksplit = (int(ent[0]), int(ent[1])) if ent else (0, 0)
+    if IGEMM_LOG is not None:
+        IGEMM_LOG.append(g)
+
+
 def _igemm(dt, x, w, y, addend, stats, g, device):
     ws = workspace(device)
+    tune_geom(g, dt)
     call('sba_conv_igemm', dt, x, w, y, addend, stats, ctypes.byref(g), ws.data_ptr(), WORKSPACE_BYTES, _stream())
 
 
