@@ -52,6 +52,7 @@ def parse():
                          'all of them, time a few untimed probe steps of each during warmup and keep the fastest')
     ap.add_argument('--phases', action='store_true', help='also print per-phase times of an eager step (stderr)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-also', action='store_true', help='skip the extra 64 px / 128 px / f32 lines')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--child', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -150,9 +151,63 @@ def measure_dominant_kernel(args, dev):
             'kernel_ms': round(ms, 4), 'algorithmic_gflop_per_launch': round(flops / 1e9, 2)}
 
 
+def measure_igemm_family(args, dev, step, one_step):
+    """The time-dominant kernel family: every implicit-GEMM launch of one step (forward / data-gradient convs of
+    G, the discriminators and the Inception trunk: sba_conv_igemm, all tile configurations).  The geometries of
+    one eager step are recorded, each distinct one is then timed alone with events on the launch stream (10
+    launches), and achieved = sum(2*M*Cout*K) / sum(duration) over the step's launches."""
+    import ctypes
+    from sbagan import ops
+    from sbagan._lib import ConvGeom, call
+    if args.dtype != 'bf16':
+        return None
+    ops.IGEMM_LOG = []
+    one_step()
+    torch.cuda.synchronize()
+    log, ops.IGEMM_LOG = ops.IGEMM_LOG, None
+    uniq = {}
+    for g in log:
+        k = (ops.geom_key(g), g.x_cstride, g.y_cstride)
+        if k not in uniq:
+            uniq[k] = [g, 0]
+        uniq[k][1] += 1
+    ws = ops.workspace(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    t_us = fl = 0.0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for g0, count in uniq.values():
+        g = ConvGeom()
+        ctypes.memmove(ctypes.byref(g), ctypes.byref(g0), ctypes.sizeof(ConvGeom))
+        xcs, ycs = g.x_cstride or g.Cin, g.y_cstride or g.Cout
+        x = torch.randn(g.N, g.IH, g.IW, xcs, device=dev).bfloat16()
+        w = (torch.randn(g.Cout, g.ntaps, g.Cin, device=dev) / (g.Cin * g.ntaps) ** 0.5).bfloat16()
+        y = torch.empty(g.N, g.OH, g.OW, ycs, device=dev, dtype=torch.bfloat16)
+
+        def run():
+            call('sba_conv_igemm', 1, x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, ctypes.byref(g),
+                 ws.data_ptr(), ops.WORKSPACE_BYTES, st)
+        run()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        t_us += e0.elapsed_time(e1) * 100.0 * count          # ms / 10 launches -> us per launch, x launches
+        fl += 2.0 * g.N * g.OHs * g.OWs * g.Cout * g.ntaps * g.Cin * count
+    achieved = fl / (t_us * 1e-6) / 1e12
+    return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS['bf16'], 'unit': 'TFLOP/s',
+            'frac': round(achieved / PEAK_TFLOPS['bf16'], 4), 'traffic': None,
+            'kernel': 'sba_conv_igemm family (igemm_dma2_kernel / igemm_dma_kernel / conv3x3_halo_kernel tiles): '
+                      '%d launches, %d distinct shapes per step' % (len(log), len(uniq)),
+            'kernel_ms_per_step': round(t_us / 1e3, 3), 'algorithmic_gflop_per_step': round(fl / 1e9, 1)}
+
+
 def cpu_baseline(args):
-    """The oracle (CPU restatement of the reference step, fp32) on the host cores: a bounded
-    sample of the same workload (3-stage, bird_style dims, B=4), 2 steps."""
+    """The oracle (CPU restatement of the reference step, fp32, `kind: port`) on the host cores: SURVEY.md 8d's
+    three configurations on a bounded sample (~30 s of CPU work) -- (1) stage 1 only, B=4: 3 warm-up + 10 timed
+    steps, median; 3-stage B=4: 1 warm-up + 5 timed, median (= `value`); 3-stage B=20: one step."""
+    import statistics
     from oracle import fill
     from oracle import sbagan_oracle as O
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -165,21 +220,28 @@ def cpu_baseline(args):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))
     torch.set_num_threads(cores)
-    B = 4
-    x = make_inputs(FULL, B, 18, branch=args.branch, lmax=18, tag=500)
-    PG = fill.fill_state_dict(g_shapes(FULL, args.branch, 'model'))
-    PDs = [fill.fill_state_dict(d_shapes(FULL, i), salt=i) for i in range(args.branch)]
-    st = O.OracleState(PG, PDs)
     enc = fill.StandInImageEncoder(256)
-    t0 = time.time()
-    nsteps = 6          # ~12 s of CPU work on 16 threads
-    for s in range(nsteps):
-        O.train_step(st, x['imgs'], x['sent'], x['words'], x['mask'], x['cap_lens'], x['class_ids'],
-                     fill.unit((B, 100), 550 + s), fill.unit((B, 100), 560 + s), enc, SMOOTH)
-    dt = time.time() - t0
-    return {'value': round(B * nsteps / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': '%d steps of the %d-stage step at B=%d (bird_style dims, fp32, stand-in image encoder), '
-                      'torch CPU threads=%d' % (nsteps, args.branch, B, cores)}
+
+    def run(branch, B, warm, timed):
+        x = make_inputs(FULL, B, 18, branch=branch, lmax=18, tag=500)
+        PG = fill.fill_state_dict(g_shapes(FULL, branch, 'model'))
+        PDs = [fill.fill_state_dict(d_shapes(FULL, i), salt=i) for i in range(branch)]
+        st = O.OracleState(PG, PDs)
+        ts = []
+        for s in range(warm + timed):
+            t0 = time.time()
+            O.train_step(st, x['imgs'], x['sent'], x['words'], x['mask'], x['cap_lens'], x['class_ids'],
+                         fill.unit((B, 100), 550 + s), fill.unit((B, 100), 560 + s), enc, SMOOTH)
+            if s >= warm:
+                ts.append(time.time() - t0)
+        return B / statistics.median(ts)
+    main = run(args.branch, 4, 1, 5)
+    also = [{'config': 'stage 1 only (64 px), B=4: 3 warm-up + 10 timed steps, median', 'value': round(run(1, 4, 3, 10), 3)}]
+    if args.branch == 3:
+        also.append({'config': '3-stage, B=20: one step', 'value': round(run(3, 20, 0, 1), 3)})
+    return {'value': round(main, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '%d-stage step at B=4 (bird_style dims, fp32, stand-in image encoder), 1 warm-up + 5 timed '
+                      'steps, median; torch CPU threads=%d' % (args.branch, cores), 'also': also}
 
 
 class _LightEncoder(object):
@@ -204,15 +266,34 @@ def supervise(args):
     import subprocess
     base = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]] + ['--child']
     ladder = [[], ['--graph', '1'], ['--graph', '0']]     # all launch modes -> hipGraph only -> eager
-    for n, extra in enumerate(ladder):
+
+    def child(extra):
         p = subprocess.run(base + extra, stdout=subprocess.PIPE, text=True)
         lines = [l for l in p.stdout.splitlines() if l.startswith('{') and '"metric"' in l]
-        if p.returncode == 0 and lines:
-            print(lines[-1], flush=True)
-            return 0
-        sys.stderr.write('bench child failed (rc=%d)%s\n' % (p.returncode, '; retrying with %s'
-                                                               % ' '.join(ladder[n + 1]) if n + 1 < len(ladder) else ''))
-    return 1
+        return (json.loads(lines[-1]) if p.returncode == 0 and lines else None), p.returncode
+    res = None
+    for n, extra in enumerate(ladder):
+        res, rc = child(extra)
+        if res is not None:
+            break
+        sys.stderr.write('bench child failed (rc=%d)%s\n' % (rc, '; retrying with %s' % ' '.join(ladder[n + 1])
+                                                               if n + 1 < len(ladder) else ''))
+    if res is None:
+        return 1
+    if not args.no_also and args.branch == 3 and args.dtype == 'bf16':
+        # the other points the metric names (64 / 128 px) and the fp32 step (the parity-compliant number: bf16
+        # storage costs ~2e-3 on a discriminator loss at B=4, tests/test_step_gpu.py), shorter runs
+        also = []
+        short = ['--steps', '10', '--warmup', '3', '--no-cpu-baseline', '--no-roofline', '--no-also']
+        for label, extra in (('256px f32', ['--dtype', 'f32']), ('128px bf16', ['--branch', '2']),
+                             ('64px bf16', ['--branch', '1'])):
+            r, _ = child(short + extra)
+            if r is not None:
+                also.append({'what': label, 'metric': r['metric'], 'value': r['value'], 'ms_per_step': r['ms_per_step'],
+                             'dtype': r['dtype'], 'launch': r['config']['launch']})
+        res['also'] = also
+    print(json.dumps(res), flush=True)
+    return 0
 
 
 def main():
@@ -375,6 +456,9 @@ def main():
     if rank == 0:
         if not args.no_roofline:
             res['roofline'] = measure_dominant_kernel(args, dev)
+            fam = measure_igemm_family(args, dev, step, one_step)
+            if fam is not None:
+                res['roofline_time_dominant'] = fam
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(res), flush=True)

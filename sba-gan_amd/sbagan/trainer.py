@@ -466,15 +466,19 @@ class GraphedStep(object):
             with torch.cuda.stream(self.estream):
                 self.gE.replay()
         if gan.distributed:
-            # largest network first: its all-reduce (D256: 287 MB) then runs under the other updates
+            # every discriminator update on its own stream (as in the single-GPU path): loss + backward graph, the
+            # gradient exchange (eager RCCL call; the exchange stream orders the collectives identically on every
+            # rank: largest network first, so D256's 287 MB all-reduce runs under the other updates), Adam graph
             order = sorted(range(len(self.gD)), key=lambda i: -gan.flatD[i].n)
-            handles = {}
             for i in order:
-                self.gD[i].replay()
-                handles[i] = gan._allreduce_start(gan.flatD[i])
-            for i in order:
-                gan._allreduce_wait(handles[i])
-                self.gDo[i].replay()
+                st = self.dstreams[i]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    self.gD[i].replay()
+                    gan._allreduce_wait(gan._allreduce_start(gan.flatD[i]))
+                    self.gDo[i].replay()
+            for st in self.dstreams:
+                main.wait_stream(st)
             if self.gE is not None:
                 main.wait_stream(self.estream)
             self.gB.replay()
