@@ -727,7 +727,13 @@ class FcBnGluFn(torch.autograd.Function):
         aux = torch.empty((2, F), dtype=torch.float32, device=x.device)
         out = torch.empty((B, F // 32, 4, 4), dtype=COMPUTE_DTYPE, device=x.device, memory_format=CL)
         if not bn.training:
-            raise RuntimeError('INIT_STAGE_G.fc BatchNorm1d eval mode: use sbagan.infer (not on the training path)')
+            # inference (netG.eval(): trainer.py:368 sampling / :437 gen_example): running statistics, plain
+            # tensor ops -- this layer runs once per generated batch and is off the training path
+            if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+                raise RuntimeError('INIT_STAGE_G.fc in eval mode is an inference path: call it under torch.no_grad()')
+            yn = (y - bn.running_mean) * torch.rsqrt(bn.running_var + BN_EPS) * bn.weight + bn.bias
+            glu = yn[:, :F // 2] * torch.sigmoid(yn[:, F // 2:])
+            return glu.view(B, F // 32, 4, 4).to(COMPUTE_DTYPE).contiguous(memory_format=CL)
         call('sba_bn1d_glu_fwd', _dt(out), _p(y), _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
              _p(bn.running_var), _p(bn.num_batches_tracked), _p(aux[0]), _p(aux[1]), _p(out), B, F, BN_EPS,
              BN_MOMENTUM, _stream())

@@ -211,3 +211,72 @@ def test_data_parallel_gradient_exchange_gloo_world2():
         p.join(60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _make_dataset(root, n_train=4, n_test=2, per_image=2):
+    """A CUB-shaped toy data_dir: images/<key>.jpg, text/<key>.txt, {train,test}/filenames.pickle, class_info."""
+    import pickle
+    from PIL import Image
+    rng = np.random.RandomState(0)
+    words = ['bird', 'red', 'small', 'wing', 'blue', 'beak', 'long', 'white', 'yellow', 'belly', 'tail', 'black']
+    os.makedirs(os.path.join(root, 'images', 'cls'), exist_ok=True)
+    os.makedirs(os.path.join(root, 'text', 'cls'), exist_ok=True)
+    names = {'train': ['cls/a%d' % i for i in range(n_train)], 'test': ['cls/t%d' % i for i in range(n_test)]}
+    for split, keys in names.items():
+        os.makedirs(os.path.join(root, split), exist_ok=True)
+        with open(os.path.join(root, split, 'filenames.pickle'), 'wb') as f:
+            pickle.dump(keys, f)
+        with open(os.path.join(root, split, 'class_info.pickle'), 'wb') as f:
+            pickle.dump(list(range(1, len(keys) + 1)), f)
+        for k in keys:
+            Image.fromarray(rng.randint(0, 255, (90, 110, 3)).astype(np.uint8)).save(os.path.join(root, 'images', k + '.jpg'))
+            with open(os.path.join(root, 'text', k + '.txt'), 'w') as f:
+                for c in range(per_image):
+                    n = 3 + rng.randint(0, 6)
+                    f.write('The ' + ' '.join(words[rng.randint(0, len(words))] for _ in range(n)) + ', it is!\n')
+    return names
+
+
+def test_data_path_matches_reference_contract(tmp_path):
+    """datasets.py:28-56,93-318: dictionary building, caption padding, per-scale images in [-1, 1], and
+    prepare_data's descending length sort (bit-exact integer work)."""
+    from miscc.config import cfg, reset_cfg
+    reset_cfg()
+    cfg.TREE.BRANCH_NUM, cfg.TEXT.CAPTIONS_PER_IMAGE, cfg.TEXT.WORDS_NUM, cfg.CUDA = 2, 2, 6, False
+    import datasets
+    from miscc import transforms
+    root = str(tmp_path / 'toy')
+    names = _make_dataset(root)
+    assert datasets.tokenize('The Bird, it is! café') == ['the', 'bird', 'it', 'is', 'caf']
+    tf = transforms.Compose([transforms.Resize(int(128 * 76 / 64)), transforms.RandomCrop(128),
+                             transforms.RandomHorizontalFlip()])
+    ds = datasets.TextDataset(root, 'train', base_size=64, transform=tf)
+    assert os.path.isfile(os.path.join(root, 'captions.pickle'))       # built on first use, like the reference
+    assert ds.filenames == names['train'] and len(ds) == 4 and ds.imsize == [64, 128]
+    assert ds.ixtoword[0] == '<end>' and ds.wordtoix['<end>'] == 0 and ds.n_words == len(ds.ixtoword)
+    assert len(ds.captions) == 4 * 2 and all(0 not in c for c in ds.captions)
+    imgs, caps, cap_len, cls_id, key = ds[1]
+    assert [tuple(i.shape) for i in imgs] == [(3, 64, 64), (3, 128, 128)]
+    assert float(imgs[1].min()) >= -1.0 and float(imgs[1].max()) <= 1.0
+    assert caps.shape == (6, 1) and caps.dtype == np.int64 and 1 <= cap_len <= 6
+    assert (caps[:cap_len, 0] > 0).all() and (caps[cap_len:, 0] == 0).all()
+    ds2 = datasets.TextDataset(root, 'test', base_size=64, transform=tf)      # second use loads the pickle
+    assert ds2.filenames == names['test'] and ds2.wordtoix == ds.wordtoix
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, drop_last=True, shuffle=False)
+    batch = next(iter(loader))
+    lens_in = batch[2].clone()
+    real, captions, lens, class_ids, keys = datasets.prepare_data(batch)
+    assert torch.equal(lens, torch.sort(lens_in, 0, True)[0]) and captions.shape == (4, 6)
+    assert len(keys) == 4 and real[1].shape == (4, 3, 128, 128) and class_ids.shape == (4,)
+    for b in range(4):      # the rows travelled together
+        assert int((captions[b] != 0).sum()) == int(lens[b])
+    # example sentences -> data_dic (main.py:34-83)
+    import main
+    with open(os.path.join(root, 'example_filenames.txt'), 'w') as f:
+        f.write('example_captions\n')
+    with open(os.path.join(root, 'example_captions.txt'), 'w') as f:
+        f.write('the small red bird\nblue wing\n\na long white yellow belly tail\n')
+    dic = main.build_example_dic(ds.wordtoix, root)
+    arr, cl, order = dic['example_captions']
+    assert list(cl) == sorted(cl, reverse=True) and arr.shape == (3, max(cl)) and list(order) == [2, 0, 1]
+    reset_cfg()
