@@ -51,6 +51,8 @@ def parse():
                          'native multi-stream launch replayer (csrc/replay.hip) over the captured step; 2: build '
                          'all of them, time a few untimed probe steps of each during warmup and keep the fastest')
     ap.add_argument('--phases', action='store_true', help='also print per-phase times of an eager step (stderr)')
+    ap.add_argument('--attn-fp8', action='store_true',
+                    help='BASELINE config 5: FP8 (e4m3) operands for the attention key projection GEMM')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-also', action='store_true', help='skip the extra 64 px / 128 px / f32 lines')
     ap.add_argument('--no-roofline', action='store_true')
@@ -70,6 +72,7 @@ def build(args, dev):
     from sbagan import ops
     from sbagan.trainer import GANStep
     ops.set_compute_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
+    ops.set_attention_fp8(args.attn_fp8)
     netG = {'model': model.G_NET, 'bert': model_bert.G_NET, 'mix': model_bert.G_NET_MIX}[args.variant]()
     netsD = [model.D_NET64(), model.D_NET128(), model.D_NET256()][:args.branch]
     torch.manual_seed(100)
@@ -447,7 +450,8 @@ def main():
         'config': {'workload': 'bird_style.yml %d-stage G+D step (64..%dpx), B=%d per GPU, G_NET variant=%s, '
                                'image_encoder=%s' % (args.branch, 64 * 2 ** (args.branch - 1), args.batch,
                                                      args.variant, args.image_encoder)
-                               + (', text_encoder=RNN_ENCODER in the step' if args.text_encoder == 'rnn' else ''),
+                               + (', text_encoder=RNN_ENCODER in the step' if args.text_encoder == 'rnn' else '')
+                               + (', attention key projection in fp8' if args.attn_fp8 else ''),
                    'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'launch': mode,
                    'losses_finite': finite},
         'step_tflops': round(GFLOP_PER_IMG[args.branch] * ips / 1e3, 2),

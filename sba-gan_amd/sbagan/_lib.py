@@ -63,6 +63,7 @@ SIGNATURES = {
     'sba_ca_bwd': [P, P, P, P, P, P, I, I, P],
     'sba_ctx_proj_fwd': [P, P, P, I, I, I, I, P],
     'sba_ctx_proj_bwd': [P, P, P, P, P, I, I, I, I, P],
+    'sba_ctx_proj_fwd_fp8': [P, P, P, I, I, I, I, P],
     'sba_instnorm_stats': [I, P, P, P, I, I, I, F, P],
     'sba_adain_fwd': [I, P, P, P, P, P, I, I, I, I, I, P],
     'sba_adain_bwd_reduce': [I, P, P, P, P, P, I, I, I, I, I, P],

@@ -756,6 +756,23 @@ class FcBnGluFn(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+# BASELINE config 5: the attention key projection (GlobalAttention.py:97 conv_context) with FP8 operands on
+# v_mfma_f32_32x32x16_fp8_fp8 (forward only; backward keeps f32 operands).  Off by default.
+ATTN_FP8 = os.environ.get('SBA_ATTN_FP8', '0') == '1'
+
+
+def set_attention_fp8(flag):
+    global ATTN_FP8
+    ATTN_FP8 = bool(flag)
+
+
+def _ctx_proj_fwd(words, wc, src, N, C, cdf, L):
+    if ATTN_FP8 and cdf % 16 == 0:
+        call('sba_ctx_proj_fwd_fp8', _p(words), _p(wc), _p(src), N, C, cdf, L, _stream())
+    else:
+        call('sba_ctx_proj_fwd', _p(words), _p(wc), _p(src), N, C, cdf, L, _stream())
+
+
 def _mask_u8(mask):
     if mask is None:
         return None
@@ -779,7 +796,7 @@ class AttnAdainCatFn(torch.autograd.Function):
         dev = h.device
         src = torch.empty((N, C, L), dtype=torch.float32, device=dev)
         wc = w_ctx.detach().reshape(C, cdf)
-        call('sba_ctx_proj_fwd', _p(words), _p(wc), _p(src), N, C, cdf, L, _stream())
+        _ctx_proj_fwd(words, wc, src, N, C, cdf, L)
         out = empty_act(N, 2 * C, H, W, h)
         att = torch.empty((N, L, H, W), dtype=torch.float32, device=dev) if want_att else None
         call('sba_word_attn_fwd', _dt(h), _p(h), _p(src), _p(m8), _p(out), _p(att), N, HW, C, L, mask_mode,
@@ -833,7 +850,7 @@ class WordAttnFn(torch.autograd.Function):
         m8 = _mask_u8(mask)
         src = torch.empty((N, C, L), dtype=torch.float32, device=h.device)
         wc = w_ctx.detach().reshape(C, cdf)
-        call('sba_ctx_proj_fwd', _p(words), _p(wc), _p(src), N, C, cdf, L, _stream())
+        _ctx_proj_fwd(words, wc, src, N, C, cdf, L)
         out = empty_act(N, C, H, W, h)
         att = torch.empty((N, L, H, W), dtype=torch.float32, device=h.device)
         call('sba_word_attn_fwd', _dt(h), _p(h), _p(src), _p(m8), _p(out), _p(att), N, H * W, C, L, mask_mode, C, 0,
