@@ -357,6 +357,20 @@ int sba_replay_create(void* hip_graph, int max_streams, int verbose, void** out_
 int sba_replay_launch(void* handle, void* stream);
 int sba_replay_info(void* handle, int* info8);
 int sba_replay_destroy(void* handle);
+/* Training path of the same encoder (DAMSM pre-training, pretrain_DAMSM.py:49-130).
+ *   sba_lstm_recur_train: the packed bidirectional recurrence on pre-computed input projections
+ *     gx [2][B*T][4H] (= x W_ih^T + b_ih + b_hh, a plain GEMM the caller runs), also storing what BPTT needs:
+ *     gates [2][B*T][4H] (i | f | g | o after their nonlinearities), cs / hs [2][B*T][H];
+ *   sba_lstm_recur_bwd: back-propagation through time given d words [B][2H][Lout] and d sent [B][2H]:
+ *     dG [2][B*T][4H] = gradient w.r.t. the gate pre-activations and hprev [2][B*T][H] = the hidden state every
+ *     step started from (both must be ZERO-FILLED by the caller: rows past a caption's length are not written).
+ *     The caller finishes with plain GEMMs: dW_ih = dG^T x, dW_hh = dG^T hprev, db = sum dG, dx = dG W_ih. */
+int sba_lstm_recur_train(const float* gx, const int64_t* cap_lens, const float* w_hh, const float* h0,
+                         const float* c0, float* words, float* sent, float* gates, float* cs, float* hs,
+                         int B, int T, int Lout, int H, void* stream);
+int sba_lstm_recur_bwd(const int64_t* cap_lens, const float* w_hh, const float* h0, const float* c0,
+                       const float* gates, const float* cs, const float* hs, const float* dwords,
+                       const float* dsent, float* dG, float* hprev, int B, int T, int Lout, int H, void* stream);
 /* y = cast(x) between f32 and dtype, n elements. */
 int sba_cast(int dtype_dst, void* dst, int dtype_src, const void* src, int64_t n, void* stream);
 

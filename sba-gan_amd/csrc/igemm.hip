@@ -1012,6 +1012,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma2_kernel(
 #endif
         ++s;
     };
+    (void)s;
     for (int t = 0; t < nstages; t += 2) {
         stage(F0, F1);
         if (t + 1 < nstages) stage(F1, F0);

@@ -99,6 +99,8 @@ SIGNATURES = {
     'sba_adam_step': [P, P, P, P, P, P, P, L, F, F, F, F, P],
     'sba_cast': [I, P, I, P, L, P],
     'sba_lstm_bidir_fwd': [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
+    'sba_lstm_recur_train': [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    'sba_lstm_recur_bwd': [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     'sba_replay_create': [P, I, I, POINTER(c_void_p)],
     'sba_replay_launch': [P, P],
     'sba_replay_info': [P, POINTER(c_int)],

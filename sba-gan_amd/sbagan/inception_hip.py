@@ -507,6 +507,19 @@ class InceptionHIP(object):
         self._saved = (img.shape, x299, a0, f, a, pooled_t, code)
         return features[:, :nef], code.t.view(N, -1)[:, :nef].float()
 
+    def trunk_features(self, img):
+        """The FROZEN part only, without a tape: (Mixed_6e output B x 768 x 17 x 17 as an NHWC f32 tensor
+        [B, 17, 17, 768], pooled Mixed_7c output [B, 2048] f32) -- the inputs of the two trainable embedding layers
+        (emb_features, emb_cnn_code) that the DAMSM pre-training loop updates (pretrain_DAMSM.py:62-75)."""
+        with torch.no_grad():
+            self.forward(img)
+            (_, _, _, _, last, pooled_t, _) = self._saved
+            feat_in = self.named['Mixed_6e']
+            f768 = feat_in.t[..., feat_in.coff:feat_in.coff + 768].float().contiguous()
+            pooled = pooled_t.t.view(img.shape[0], -1)[:, :2048].float().contiguous()
+        self.tape, self._grads, self._saved, self.named = [], {}, None, {}
+        return f768, pooled
+
     def backward(self, dfeat, dcode):
         (ishape, x299, a0, f, last, pooled_t, code) = self._saved
         N = ishape[0]

@@ -540,12 +540,16 @@ class RNN_ENCODER(nn.Module):
         z = lambda: w.new_zeros(self.nlayers * self.num_directions, bsz, self.nhidden)
         return (z(), z()) if self.rnn_type == 'LSTM' else z()
 
-    use_hip = True      # frozen-encoder forward (eval / no_grad, one-layer bi-LSTM, CUDA) through sba_lstm_bidir_fwd
+    use_hip = True      # the hand-written bi-LSTM (csrc/text.hip): frozen forward AND the training path
+
+    def _hip_shape_ok(self, captions):
+        return (self.use_hip and captions.is_cuda and self.rnn_type == 'LSTM' and self.nlayers == 1
+                and self.bidirectional and self.nhidden in (64, 128) and self.ninput % 4 == 0)
 
     def _hip_ok(self, captions):
-        return (self.use_hip and captions.is_cuda and not torch.is_grad_enabled()
-                and (not self.training or self.drop_prob == 0) and self.rnn_type == 'LSTM' and self.nlayers == 1
-                and self.bidirectional and self.nhidden in (64, 128) and self.ninput % 4 == 0)
+        """the inference kernel (embedding gather fused into the input projection, nothing saved)"""
+        return (self._hip_shape_ok(captions) and not torch.is_grad_enabled()
+                and (not self.training or self.drop_prob == 0))
 
     def _packed_lstm_weights(self):
         """[2][4H][*] stacks of the forward / reverse direction parameters, rebuilt when they change."""
@@ -568,6 +572,24 @@ class RNN_ENCODER(nn.Module):
             w_ih, w_hh, b_ih, b_hh = self._packed_lstm_weights()
             return ops.lstm_bidir_forward(captions, cap_lens, self.encoder.weight.detach().float(), w_ih, w_hh, b_ih,
                                           b_hh, hidden, max_len, out)
+        if self._hip_shape_ok(captions):
+            # training path (pretrain_DAMSM.py:79-81): embedding + dropout are ordinary autograd ops, the packed
+            # bi-LSTM and its back-propagation through time are the HIP kernels behind ops.LstmBidirTrainFn
+            r = self.rnn
+            emb = self.drop(self.encoder(captions))
+            w_ih = torch.stack((r.weight_ih_l0, r.weight_ih_l0_reverse))
+            w_hh = torch.stack((r.weight_hh_l0, r.weight_hh_l0_reverse))
+            b_ih = torch.stack((r.bias_ih_l0, r.bias_ih_l0_reverse))
+            b_hh = torch.stack((r.bias_hh_l0, r.bias_hh_l0_reverse))
+            L = captions.size(1) if max_len is None else int(max_len)
+            h0 = c0 = None
+            if hidden is not None:
+                h0, c0 = hidden[0].detach().float().contiguous(), hidden[1].detach().float().contiguous()
+            return ops.LstmBidirTrainFn.apply(emb, cap_lens, w_ih, w_hh, b_ih, b_hh, h0, c0, L)
+        if captions.is_cuda and self.use_hip:
+            raise RuntimeError('RNN_ENCODER on the GPU supports the one-layer bidirectional LSTM with nhidden 128 / 256 '
+                               '(cfg.TEXT.EMBEDDING_DIM) and ninput % 4 == 0; set use_hip = False to run this '
+                               'configuration through torch.nn.%s' % self.rnn_type)
         from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
         emb = self.drop(self.encoder(captions))
         lens = cap_lens.data.tolist()

@@ -1177,3 +1177,51 @@ def lstm_bidir_forward(captions, cap_lens, emb_weight, w_ih, w_hh, b_ih, b_hh, h
     call('sba_lstm_bidir_fwd', _p(captions), _p(cap_lens), _p(emb_weight), _p(w_ih), _p(w_hh), _p(b_ih), _p(b_hh),
          _p(h0), _p(c0), _p(gx), _p(words), _p(sent), B, T, L, emb_weight.shape[0], emb_weight.shape[1], H, _stream())
     return words, sent
+
+
+class LstmBidirTrainFn(torch.autograd.Function):
+    """One-layer bidirectional LSTM over packed sequences with gradients (RNN_ENCODER in training mode: DAMSM
+    pre-training, pretrain_DAMSM.py:79-100).  x [B][T][ninput] is the (dropped-out) embedded caption batch; the
+    recurrence and back-propagation through time are csrc/text.hip kernels, the dense projections around them are
+    plain GEMMs through the BLAS library (torch.matmul).  Returns (words_emb B x 2H x L, sent_emb B x 2H)."""
+
+    @staticmethod
+    def forward(ctx, x, cap_lens, w_ih, w_hh, b_ih, b_hh, h0, c0, L):
+        _need_gpu(x)
+        B, T, _ = x.shape
+        H = w_hh.shape[2]
+        dev = x.device
+        x2 = x.reshape(B * T, -1).float().contiguous()
+        gx = torch.matmul(x2.unsqueeze(0), w_ih.transpose(1, 2)) + (b_ih + b_hh).unsqueeze(1)     # [2][B*T][4H]
+        gx = gx.contiguous()
+        cap_lens = cap_lens.to(device=dev, dtype=torch.int64).contiguous()
+        words = torch.empty((B, 2 * H, L), dtype=torch.float32, device=dev)
+        sent = torch.empty((B, 2 * H), dtype=torch.float32, device=dev)
+        gates = torch.zeros((2, B * T, 4 * H), dtype=torch.float32, device=dev)
+        cs = torch.zeros((2, B * T, H), dtype=torch.float32, device=dev)
+        hs = torch.zeros((2, B * T, H), dtype=torch.float32, device=dev)
+        w_hh = w_hh.contiguous()
+        call('sba_lstm_recur_train', _p(gx), _p(cap_lens), _p(w_hh), _p(h0), _p(c0), _p(words), _p(sent), _p(gates),
+             _p(cs), _p(hs), B, T, L, H, _stream())
+        ctx.save_for_backward(x2, cap_lens, w_ih, w_hh, gates, cs, hs)
+        ctx.h0c0, ctx.dims = (h0, c0), (B, T, L, H)
+        return words, sent
+
+    @staticmethod
+    def backward(ctx, dwords, dsent):
+        x2, cap_lens, w_ih, w_hh, gates, cs, hs = ctx.saved_tensors
+        B, T, L, H = ctx.dims
+        h0, c0 = ctx.h0c0
+        dev = x2.device
+        dwords = torch.zeros((B, 2 * H, L), device=dev) if dwords is None else dwords.float().contiguous()
+        dsent = torch.zeros((B, 2 * H), device=dev) if dsent is None else dsent.float().contiguous()
+        dG = torch.zeros((2, B * T, 4 * H), dtype=torch.float32, device=dev)
+        hprev = torch.zeros((2, B * T, H), dtype=torch.float32, device=dev)
+        call('sba_lstm_recur_bwd', _p(cap_lens), _p(w_hh), _p(h0), _p(c0), _p(gates), _p(cs), _p(hs), _p(dwords),
+             _p(dsent), _p(dG), _p(hprev), B, T, L, H, _stream())
+        dGt = dG.transpose(1, 2)                                   # [2][4H][B*T]
+        dw_ih = torch.matmul(dGt, x2.unsqueeze(0))                 # [2][4H][ninput]
+        dw_hh = torch.matmul(dGt, hprev)                           # [2][4H][H]
+        db = dG.sum(1)                                             # [2][4H]
+        dx = torch.matmul(dG, w_ih).sum(0).view(B, T, -1) if ctx.needs_input_grad[0] else None
+        return dx, None, dw_ih, dw_hh, db, db, None, None, None

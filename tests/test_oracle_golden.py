@@ -272,3 +272,22 @@ def test_text_encoder_oracle_vs_reference_golden(golden_dir, name):
         w2, s2 = net(torch.from_numpy(cap), torch.from_numpy(lens), net.init_hidden(cap.shape[0]))
     np.testing.assert_allclose(w2.numpy(), T['%s/words_emb' % name], rtol=0, atol=2e-6)
     np.testing.assert_allclose(s2.numpy(), T['%s/sent_emb' % name], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize('name', ['small', 'bird'])
+def test_text_encoder_training_golden_vs_module(golden_dir, name):
+    """The module's CPU path (torch.nn.LSTM over packed sequences) in TRAINING mode reproduces the reference
+    module's outputs and parameter gradients (tests/golden/text_encoder_train.npz); the GPU test holds the HIP
+    back-propagation-through-time kernels to the same numbers."""
+    import model
+    T = load_golden(golden_dir, 'text_encoder_train.npz')
+    ntoken, ninput, nhidden = (int(v) for v in T['%s/dims' % name])
+    net = model.RNN_ENCODER(ntoken, ninput=ninput, drop_prob=0.0, nhidden=nhidden)
+    net.load_state_dict(fill.fill_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, salt=7))
+    net.train()
+    cap, lens = torch.from_numpy(T['%s/captions' % name]), torch.from_numpy(T['%s/cap_lens' % name])
+    words, sent = net(cap, lens, net.init_hidden(cap.size(0)))
+    np.testing.assert_allclose(words.detach().numpy(), T['%s/words_emb' % name], rtol=0, atol=2e-6)
+    ((words * fill.unit(tuple(words.shape), 801)).sum() + (sent * fill.unit(tuple(sent.shape), 802)).sum()).backward()
+    for n, p in net.named_parameters():
+        check(T, '%s/grad/%s' % (name, n), p.grad, rtol=1e-4, atol=1e-6)

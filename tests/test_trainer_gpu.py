@@ -79,3 +79,33 @@ def test_train_checkpoint_resume_and_sampling(tmp_path):
     base = algo3.gen_example(main.build_example_dic(ds_t.wordtoix, root))
     assert len(glob.glob(os.path.join(base, 'example_captions', '0_s_*_g1.png'))) == 3
     reset_cfg()
+
+
+def test_pretrain_damsm_entry_point(tmp_path, monkeypatch):
+    """pretrain_DAMSM.py main(): two updates on the toy data_dir, validation pass, encoder checkpoints under the
+    reference's file names, loadable by build_models."""
+    import yaml
+    from miscc.config import cfg, reset_cfg
+    reset_cfg()
+    root = str(tmp_path / 'toy')
+    _make_dataset(root, n_train=4, n_test=4)
+    yml = tmp_path / 'damsm_toy.yml'
+    yml.write_text(yaml.safe_dump({
+        'CONFIG_NAME': 'DAMSM', 'DATASET_NAME': 'toy', 'DATA_DIR': root, 'GPU_ID': 0, 'WORKERS': 0,
+        'TREE': {'BRANCH_NUM': 1, 'BASE_SIZE': 128},
+        'TRAIN': {'FLAG': True, 'NET_E': '', 'BATCH_SIZE': 4, 'MAX_EPOCH': 1, 'SNAPSHOT_INTERVAL': 1,
+                  'ENCODER_LR': 0.002, 'RNN_GRAD_CLIP': 0.25,
+                  'SMOOTH': {'GAMMA1': 4.0, 'GAMMA2': 5.0, 'GAMMA3': 10.0}},
+        'TEXT': {'EMBEDDING_DIM': 256, 'CAPTIONS_PER_IMAGE': 2, 'WORDS_NUM': 8}}))
+    monkeypatch.chdir(tmp_path / 'toy')          # the reference writes to ../output/<name>
+    import pretrain_DAMSM
+    from sbagan import ops
+    ops.set_compute_dtype(torch.bfloat16)
+    model_dir = pretrain_DAMSM.main(['--cfg', str(yml), '--gpu', '0', '--manualSeed', '7'], max_steps=2)
+    te, ie = os.path.join(model_dir, 'text_encoder0.pth'), os.path.join(model_dir, 'image_encoder0.pth')
+    assert os.path.isfile(te) and os.path.isfile(ie)
+    cfg.TRAIN.NET_E = te
+    text_encoder, image_encoder, labels, start_epoch = pretrain_DAMSM.build_models(
+        torch.load(te, map_location='cpu')['encoder.weight'].shape[0], 4)
+    assert start_epoch == 1 and labels.tolist() == [0, 1, 2, 3]
+    reset_cfg()

@@ -343,6 +343,39 @@ def gen_text(ref):
     print('text_encoder.npz: %d arrays' % len(S))
 
 
+def gen_text_train(ref):
+    """RNN_ENCODER (model.py:75-159) in TRAINING mode (dropout probability 0 so that the run is deterministic):
+    outputs and the gradients of every parameter for loss = sum(words * gw) + sum(sent * gs) -- what the DAMSM
+    pre-training loop back-propagates through (pretrain_DAMSM.py:79-100)."""
+    cfg, _, model, _, _ = ref
+    S = {}
+    for name, ntoken, ninput, nhidden, B, T, lens in (
+            ('small', 40, 12, 128, 4, 6, [6, 4, 3, 1]),
+            ('bird', 60, 300, 256, 5, 18, [18, 11, 11, 7, 2])):
+        cfg.TEXT.WORDS_NUM = T
+        net = model.RNN_ENCODER(ntoken, ninput=ninput, drop_prob=0.0, nhidden=nhidden)
+        load_filled(net, salt=7)
+        net.train()
+        cap = np.zeros((B, T), dtype=np.int64)
+        for b in range(B):
+            for t in range(lens[b]):
+                cap[b, t] = 1 + (7 * b + 3 * t + b * t) % (ntoken - 1)
+        words, sent = net(torch.from_numpy(cap), torch.tensor(lens), net.init_hidden(B))
+        gw, gs = fill.unit(tuple(words.shape), 801), fill.unit(tuple(sent.shape), 802)
+        loss = (words * gw).sum() + (sent * gs).sum()
+        names = [n for n, _ in net.named_parameters()]
+        grads = torch.autograd.grad(loss, list(net.parameters()))
+        S['%s/captions' % name] = cap
+        S['%s/cap_lens' % name] = np.asarray(lens, dtype=np.int64)
+        S['%s/dims' % name] = np.asarray([ntoken, ninput, nhidden], dtype=np.int64)
+        S['%s/words_emb' % name] = words.detach().contiguous().numpy()
+        S['%s/sent_emb' % name] = sent.detach().numpy()
+        for n, g in zip(names, grads):
+            put(S, '%s/grad/%s' % (name, n), g)
+    np.savez_compressed(os.path.join(OUT, 'text_encoder_train.npz'), **S)
+    print('text_encoder_train.npz: %d arrays' % len(S))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     what = sys.argv[1:] or ['units', 'step_tiny', 'step_full']
@@ -350,6 +383,8 @@ def main():
     ref = load_reference()
     if 'text' in what:
         gen_text(ref)
+    if 'text_train' in what:
+        gen_text_train(ref)
     if 'units' in what:
         gen_units(ref)
     if 'step_tiny' in what:
