@@ -43,9 +43,10 @@ def parse():
                     help='CNN_ENCODER inside the G step: the Inception-v3 trunk on the HIP kernels '
                          '(sbagan.inception_hip), the same module through PyTorch-ROCm/MIOpen, or the light '
                          'stand-in used by the parity fixtures')
-    ap.add_argument('--text-encoder', default='rnn', choices=['rnn', 'none'],
+    ap.add_argument('--text-encoder', default='rnn', choices=['rnn', 'bert', 'none'],
                     help="rnn: the frozen RNN_ENCODER forward (trainer.py:248-252) runs inside every timed step "
-                         "(hand-written bi-LSTM, caption lengths read on the device); none: embeddings are inputs")
+                         "(hand-written bi-LSTM, caption lengths read on the device); bert: the frozen BertEncoder of "
+                         "the bert / mix variants (BASELINE config 3, sbagan.bert_hip); none: embeddings are inputs")
     ap.add_argument('--graph', type=int, default=2,
                     help='0: eager launches; 1: replay the step from captured hipGraphs (hipGraphLaunch); 3: the '
                          'native multi-stream launch replayer (csrc/replay.hip) over the captured step; 2: build '
@@ -337,8 +338,24 @@ def main():
         torch.manual_seed(100 + rank)
         hid = txt.init_hidden(args.batch)
 
+    bert = None
+    if args.text_encoder == 'bert':
+        import model_bert
+        torch.manual_seed(102)
+        bert = model_bert.BertEncoder(b['sent_emb'].size(1)).to(dev).eval()
+        torch.manual_seed(100 + rank)
+        bert_caps = torch.randint(1000, 30522, (args.batch, 20), device=dev)
+        b['words_embs'] = torch.zeros((args.batch, b['sent_emb'].size(1), 20), device=dev)   # BERT path: L = 20 always
+        b['mask'] = torch.zeros((args.batch, 20), dtype=torch.bool, device=dev)
+        b['cap_lens'] = torch.full((args.batch,), 20, dtype=torch.int64, device=dev)
+
     def encode():
         # words_embs, sent_emb = text_encoder(captions, cap_lens, hidden) of trainer.py:248-252 (no_grad, eval)
+        if bert is not None:
+            with torch.no_grad():
+                w, s = bert(bert_caps)
+            b['words_embs'].copy_(w)
+            b['sent_emb'].copy_(s)
         if txt is not None:
             with torch.no_grad():       # written straight into the step's static input tensors
                 txt(b['captions'], b['cap_lens'], hid, max_len=b['words_embs'].size(2),
@@ -451,6 +468,7 @@ def main():
                                'image_encoder=%s' % (args.branch, 64 * 2 ** (args.branch - 1), args.batch,
                                                      args.variant, args.image_encoder)
                                + (', text_encoder=RNN_ENCODER in the step' if args.text_encoder == 'rnn' else '')
+                               + (', text_encoder=BertEncoder in the step' if args.text_encoder == 'bert' else '')
                                + (', attention key projection in fp8' if args.attn_fp8 else ''),
                    'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'launch': mode,
                    'losses_finite': finite},

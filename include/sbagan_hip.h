@@ -371,6 +371,22 @@ int sba_lstm_recur_train(const float* gx, const int64_t* cap_lens, const float* 
 int sba_lstm_recur_bwd(const int64_t* cap_lens, const float* w_hh, const float* h0, const float* c0,
                        const float* gates, const float* cs, const float* hs, const float* dwords,
                        const float* dsent, float* dG, float* hprev, int B, int T, int Lout, int H, void* stream);
+/* ---- BertEncoder forward (model_bert.py:161-189: frozen BERT-base trunk of the bert / mix variants) ----
+ * The dense layers are 1x1 convolutions on sba_conv_igemm_bias (rows = B*L tokens); these are the pieces between
+ * them.  Activations [B*L][C] of `dtype`; LayerNorm statistics and the softmax in f32.
+ *   embed_ln:  LayerNorm(word_emb[token] + pos_emb[position] + type_emb[0]), eps as given (BERT: 1e-12)
+ *   add_ln:    LayerNorm(x + residual)
+ *   attention: per (caption, head) softmax(q k^T / 8) v over L <= 32 tokens with NO mask (the reference passes
+ *              none, model_bert.py:181); qkv [B*L][3C] = q | k | v, heads of 64 channels
+ *   gelu:      exact (erf) GELU in place;  tanh_transpose: y[b][c][l] = tanh(x[b*L + l][c]) (f32 out). */
+int sba_bert_embed_ln(int dtype, const int64_t* tokens, const float* word_emb, const float* pos_emb,
+                      const float* type_emb, const float* gamma, const float* beta, void* out, int B, int L,
+                      int C, int ntoken, float eps, void* stream);
+int sba_bert_add_ln(int dtype, const void* x, const void* residual, const float* gamma, const float* beta,
+                    void* out, int rows, int C, float eps, void* stream);
+int sba_bert_attention(int dtype, const void* qkv, void* ctx, int B, int L, int C, int heads, void* stream);
+int sba_bert_gelu(int dtype, void* x, int64_t n, void* stream);
+int sba_bert_tanh_transpose(int dtype, const void* x, float* y, int B, int L, int C, void* stream);
 /* y = cast(x) between f32 and dtype, n elements. */
 int sba_cast(int dtype_dst, void* dst, int dtype_src, const void* src, int64_t n, void* stream);
 

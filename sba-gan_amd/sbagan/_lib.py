@@ -101,6 +101,11 @@ SIGNATURES = {
     'sba_lstm_bidir_fwd': [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     'sba_lstm_recur_train': [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     'sba_lstm_recur_bwd': [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    'sba_bert_embed_ln': [I, P, P, P, P, P, P, P, I, I, I, I, F, P],
+    'sba_bert_add_ln': [I, P, P, P, P, P, I, I, F, P],
+    'sba_bert_attention': [I, P, P, I, I, I, I, P],
+    'sba_bert_gelu': [I, P, L, P],
+    'sba_bert_tanh_transpose': [I, P, P, I, I, I, P],
     'sba_replay_create': [P, I, I, POINTER(c_void_p)],
     'sba_replay_launch': [P, P],
     'sba_replay_info': [P, POINTER(c_int)],

@@ -1,8 +1,8 @@
-"""Frozen encoders around the hot path.  Their arithmetic is third-party in the
-reference (torchvision Inception-v3, pytorch_pretrained_bert; SURVEY.md 8c: parity
-unpinned) and they are NOT hand-written-kernel targets this round:
-they run through PyTorch-ROCm (MIOpen / rocBLAS).  What is kept is the module API and the
-state_dict layout, so `image_encoder*.pth` / `text_encoder*.pth` checkpoints load.
+"""Encoder modules around the hot path: module API and state_dict layout of the reference, so that
+`image_encoder*.pth` / `text_encoder*.pth` checkpoints load.  Their arithmetic is third-party in the reference
+(torchvision Inception-v3, pytorch_pretrained_bert; SURVEY.md 8c: parity unpinned).  On the GPU the frozen forwards
+run on the hand-written kernels (sbagan.inception_hip.InceptionHIP, sbagan.bert_hip.BertHIP); the nn.Module
+forwards below are the definitions those are tested against, and the training path of BertEncoder.
 
 CNN_ENCODER carries its own Inception-v3 definition (torchvision is not installed on the
 GPU box and the pretrained-weights URL of model.py:171 is unreachable offline); attribute
@@ -192,7 +192,20 @@ class BertEncoder(nn.Module):
             for p in layer.parameters():
                 p.requires_grad = False
 
+    use_hip = True      # frozen forward (eval / no_grad, CUDA) on the HIP kernels: sbagan.bert_hip.BertHIP
+
+    def _hip_runner(self):
+        from . import ops
+        from .bert_hip import BertHIP
+        key = (ops.compute_dtype(), tuple(p._version for p in self.parameters()))
+        if getattr(self, '_hip_key', None) != key:
+            self.__dict__['_hip'] = BertHIP(self)
+            self.__dict__['_hip_key'] = key
+        return self.__dict__['_hip']
+
     def forward(self, captions):
+        if self.use_hip and captions.is_cuda and not torch.is_grad_enabled() and not self.training:
+            return self._hip_runner()(captions)
         out = self.model(captions)
         words_embs = out.last_hidden_state.transpose(1, 2).contiguous().unsqueeze(3)
         words_embs = self.tanh(self.conv_text(words_embs).squeeze(3))

@@ -570,3 +570,32 @@ def test_attention_key_projection_fp8(dev):
         ops.set_attention_fp8(False)
     torch.cuda.synchronize()
     assert 0 < rel_l2(o8, o32) <= 1e-1, rel_l2(o8, o32)      # measured 5.9e-2 (the softmax sharpens the key error)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_bert_encoder_hip_vs_module(dev, dt):
+    """BertEncoder.forward (model_bert.py:177-189) on the HIP kernels against the same module evaluated by
+    PyTorch (HuggingFace BertModel, the available substitute for pytorch_pretrained_bert: parity unpinned w.r.t.
+    the reference's dependency) on random-init BERT-base weights, no attention mask, L = 20:
+    f32 path 2e-4, bf16 path 3e-2 relative L2."""
+    import model_bert
+    from miscc.config import cfg
+    from sbagan import ops
+    ops.set_compute_dtype(dt)
+    cfg.TEXT.WORDS_NUM = 20
+    torch.manual_seed(3)
+    enc = model_bert.BertEncoder(256).to(dev).eval()
+    B, L = 6, 20
+    cap = torch.randint(1000, 30522, (B, L), device=dev)
+    cap[2, 12:] = 0                 # padded captions: no mask is applied (reference behaviour)
+    enc.use_hip = False
+    with torch.no_grad():
+        w_ref, s_ref = enc(cap)
+    enc.use_hip = True
+    with torch.no_grad():
+        w, s = enc(cap)
+    torch.cuda.synchronize()
+    assert w.shape == (B, 256, L) and s.shape == (B, 256) and w.dtype == torch.float32
+    tol = 2e-4 if dt == torch.float32 else 3e-2
+    assert rel_l2(w, w_ref) <= tol, rel_l2(w, w_ref)
+    assert rel_l2(s, s_ref) <= tol, rel_l2(s, s_ref)
