@@ -536,3 +536,41 @@ def test_image_encoder_hip_vs_torch(dev, dt):
     else:
         cos = float(torch.dot(ga, gr) / (ga.norm() * gr.norm()))
         assert cos >= 0.85 and rel_l2(ga, gr) <= 0.6, (cos, rel_l2(ga, gr))
+
+
+def test_torch_optimizer_on_hip_modules(dev):
+    """the reference's own optimizer loop works on the HIP modules -- the kernels
+    accumulate into p.grad, torch.optim.Adam(lr 2e-4, betas (0.5, 0.999)) (trainer.py:136-143) updates the
+    parameters, and the next forward sees the update (packed weights follow the parameter version)."""
+    import model
+    from miscc.losses import discriminator_loss
+    from sbagan import ops
+    ops.set_compute_dtype(torch.float32)
+    B = 3
+    net = model.D_NET64()
+    P = fill.fill_state_dict(d_shapes(FULL, 0), salt=0)
+    net.load_state_dict(P)
+    net.to(dev).train()
+    opt = torch.optim.Adam(net.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    real, fake = fill.uniform((B, 3, 64, 64), 950).to(dev), fill.uniform((B, 3, 64, 64), 951).to(dev)
+    sent = fill.unit((B, 256), 952).to(dev)
+    ones, zeros = torch.ones(B, device=dev), torch.zeros(B, device=dev)
+    p0 = {n: p.detach().clone() for n, p in net.named_parameters()}
+    net.zero_grad()
+    err0 = discriminator_loss(net, real, fake, sent, ones, zeros)
+    err0.backward()
+    g0 = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+    opt.step()
+    for n, p in net.named_parameters():      # Adam step 1 from zero moments: p - lr * g / (|g| + eps)
+        want = p0[n] - 2e-4 * g0[n] / (g0[n].abs() + 1e-8)
+        assert torch.allclose(p.detach(), want, rtol=0, atol=2e-7), n
+    net.zero_grad()
+    err1 = discriminator_loss(net, real, fake, sent, ones, zeros)
+    assert float(err1) < float(err0)          # the forward used the updated weights (and they help)
+    Q = {k: v.clone() for k, v in net.state_dict().items()}
+    for k in list(Q):
+        if k.endswith(('running_mean', 'running_var', 'num_batches_tracked')):
+            Q[k] = P[k].clone()             # oracle: fresh BN buffers do not matter in train mode
+    ref1 = O.discriminator_loss({k: v.cpu() for k, v in Q.items()}, real.cpu(), fake.cpu(), sent.cpu(), torch.ones(B),
+                                torch.zeros(B))
+    assert abs(float(err1) - float(ref1)) <= 2e-4 * abs(float(ref1)), (float(err1), float(ref1))
