@@ -1206,6 +1206,173 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const bf16_t* __restr
 }
 
 // ---------------------------------------------------------------------------
+// Persistent halo-tile 3x3 convolution (Cin = 64): the kernel above pays, per 8 x 32 output tile, a serialised
+// prologue (halo staging through registers, first weight tap), nine barriers for the double-buffered weight
+// taps and an epilogue -- 17.8 us per workgroup-round for 5.8 us of MFMA issue.  Here
+//   * a workgroup is PERSISTENT (one per CU, 160 KB of LDS) and walks tiles t = id, id + G, ...;
+//   * the weights of all nine taps stay in LDS for the whole launch (9 x 64 x 128 B = 72 KB, loaded once);
+//   * the halo tile of tile t+1 is fetched by LDS-DMA into the second halo buffer while tile t's 144 MFMAs per
+//     wave run -- no barrier inside a tile's main loop, one counted vmcnt wait + barrier per tile;
+//   * rows are 128 B (64 channels) with the chunk swizzle c ^ ((row >> 1) & 7): conflict-free ds_read_b128 for
+//     the shifted tap views and for the weight rows alike; out-of-image halo pixels are out-of-range DMA lanes
+//     (zeros).
+// Epilogue (BatchNorm statistics, bias / ReLU / mask, addend, LDS-transposed NHWC store) is the shared one and
+// stages through the halo buffer the tile has just finished reading.
+// ---------------------------------------------------------------------------
+template <int UPS>
+__global__ __launch_bounds__(256) void conv3x3_halo2_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                            bf16_t* __restrict__ y, const bf16_t* __restrict__ addend,
+                                                            float* __restrict__ stats, const sba_conv_geom g,
+                                                            const EpiX ex, const int tiles, const int wgs_per_nblock) {
+    typedef bf16_t T;
+    constexpr int TH = 8, TW = 32, BM = TH * TW, BN = 64;
+    constexpr int HR = UPS ? TH / 2 + 2 : TH + 2, HC = UPS ? TW / 2 + 2 : TW + 2, HP = HR * HC;
+    constexpr int W_BYTES = 9 * BN * 128;                       // 73,728
+    constexpr int OUT_BYTES = BM * (BN * 2 + 16);               // 36,864: the epilogue's staging tile
+    constexpr int HI = (HP * 8 + 255) / 256;                    // DMA instructions per wave per halo tile
+    constexpr int WI = 9 * BN * 8 / 256;                        // ... for the weights (18)
+    // a halo buffer holds the DMA image (HI * 4 slots of 1 KB: the last slots are partly out-of-range lanes, which
+    // write zeros) and, during the epilogue, the staging tile + the row table + the statistics accumulators
+    constexpr int EPI_OFF = OUT_BYTES;
+    constexpr int HALO_NEED = HI * 4 * 1024 > EPI_OFF + BM * 4 + BN * 8 ? HI * 4 * 1024 : EPI_OFF + BM * 4 + BN * 8;
+    constexpr int HALO_BYTES = (HALO_NEED + 1023) / 1024 * 1024;
+    constexpr int TM = 2, TN = 2;
+    constexpr int LDS_BYTES = W_BYTES + 2 * HALO_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(HI <= 63, "vmcnt field");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    unsigned char* const lW = lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = blockIdx.x / wgs_per_nblock, wg = blockIdx.x - nb * wgs_per_nblock;
+    const int n_base = nb * BN;
+    const int tiles_x = g.OW / TW, tiles_y = g.OH / TH;
+    const int xcs = g.x_cstride ? g.x_cstride : g.Cin;
+    const int ycs = g.y_cstride ? g.y_cstride : g.Cout;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    constexpr uint32_t OOB = 0xFFFFFFFFu;
+    const uint32_t x_bytes = (uint32_t)((int64_t)g.N * g.IH * g.IW * xcs * 2);
+    const uint32_t w_bytes = (uint32_t)((int64_t)g.Cout * 9 * 64 * 2);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, w_bytes, 0x00020000);
+
+    // ---- weights: LDS row R = tap * 64 + co (128 B), DMA instruction q of wave `wid` covers rows 8 * (wid + 4 q) ..
+#pragma unroll
+    for (int q = 0; q < WI; ++q) {
+        const int R = 8 * (wid + 4 * q) + (lane >> 3);
+        const int tap = R >> 6, co = n_base + (R & 63);
+        const uint32_t c = (uint32_t)((lane & 7) ^ ((R >> 1) & 7));
+        const uint32_t o = co < g.Cout ? ((uint32_t)co * 9u + (uint32_t)tap) * 128u + c * 16u : OOB;
+        lds_dma16(wr, o, 0u, lds_base + (uint32_t)((wid + 4 * q) * 1024));
+    }
+    // ---- halo tile of output tile `t` into buffer `buf`: lane slot idx = 64 * (wid + 4 q) + lane -> pixel idx >> 3
+    auto issue_halo = [&](const int t, const int buf) {
+        const int tx_ = t % tiles_x, ty_ = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+        const int oy0 = ty_ * TH, ox0 = tx_ * TW;
+        const int sy0 = UPS ? (oy0 >> 1) - 1 : oy0 - 1, sx0 = UPS ? (ox0 >> 1) - 1 : ox0 - 1;
+        const uint32_t dst = lds_base + (uint32_t)(W_BYTES + buf * HALO_BYTES + wid * 1024);
+        const bool live = t < tiles;
+#pragma unroll
+        for (int q = 0; q < HI; ++q) {
+            const int idx = 64 * (wid + 4 * q) + lane;
+            const int p = idx >> 3;
+            const int hr = p / HC, hc = p - hr * HC;
+            const int iy = sy0 + hr, ix = sx0 + hc;
+            const bool ok = live && p < HP && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+            const uint32_t c = (uint32_t)((idx & 7) ^ ((p >> 1) & 7));
+            const uint32_t o = ok ? (uint32_t)((n * g.IH + iy) * g.IW + ix) * (uint32_t)(xcs * 2) +
+                                        (uint32_t)(g.x_coff * 2) + c * 16u
+                                  : OOB;
+            lds_dma16(xr, o, 0u, dst + (uint32_t)(4 * q * 1024));
+        }
+    };
+    int t = wg;
+    issue_halo(t, 0);
+    const int rl = lane & 31, hf = lane >> 5;
+    int buf = 0;
+    for (; t < tiles; t += wgs_per_nblock, buf ^= 1) {
+        // next tile's halo into the other buffer (its last reader was tile t-1's epilogue, which ended with a barrier)
+        issue_halo(t + wgs_per_nblock, buf ^ 1);
+        wait_vmcnt<HI>();                   // everything but the HI loads just issued: this tile's halo (and the weights)
+        wg_barrier();
+        const unsigned char* lA = lds + W_BYTES + buf * HALO_BYTES;
+        f32x16_t acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int bsw = (rl >> 1) & 7;
+        // one wave per SIMD: nothing else hides the LDS latency, so the 16 fragments of tap t+1 are read into a
+        // second register set while the 16 MFMAs of tap t (512 cycles) run
+        struct TapFrags { bf16x8_t a[4][TM], b[4][TN]; };
+        auto load_tap = [&](TapFrags& F, const int tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            int hp[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                int hr, hc;
+                if (UPS) {
+                    hr = ((2 * wid + i + ky - 1) >> 1) + 1;
+                    hc = ((rl + kx - 1) >> 1) + 1;
+                } else {
+                    hr = 2 * wid + i + ky;
+                    hc = rl + kx;
+                }
+                hp[i] = hr * HC + hc;
+            }
+            const unsigned char* bp = lW + (tap * 64 + rl) * 128;
+#pragma unroll
+            for (int k16 = 0; k16 < 4; ++k16) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    F.a[k16][i] = *reinterpret_cast<const bf16x8_t*>(lA + hp[i] * 128 + (((2 * k16 + hf) ^ ((hp[i] >> 1) & 7)) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    F.b[k16][j] = *reinterpret_cast<const bf16x8_t*>(bp + j * 32 * 128 + (((2 * k16 + hf) ^ bsw) << 4));
+            }
+        };
+        auto mma_tap = [&](const TapFrags& F) {
+#pragma unroll
+            for (int k16 = 0; k16 < 4; ++k16)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[k16][i], F.b[k16][j], acc[i][j], 0, 0, 0);
+        };
+        TapFrags F0, F1;
+        load_tap(F0, 0);
+#pragma unroll
+        for (int tap = 0; tap < 8; tap += 2) {
+            load_tap(F1, tap + 1);
+            mma_tap(F0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_tap(F0, tap + 2);
+            mma_tap(F1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mma_tap(F0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wg_barrier();           // every wave has finished reading this tile's halo: the epilogue may stage through it
+        unsigned char* const stage = lds + W_BYTES + buf * HALO_BYTES;
+        int* rowoff = reinterpret_cast<int*>(stage + EPI_OFF);
+        float* s_stat = reinterpret_cast<float*>(stage + EPI_OFF + BM * 4);
+        {
+            const int tx_ = t % tiles_x, ty_ = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+            rowoff[tid] = (n * g.OH + ty_ * TH + (tid >> 5)) * g.OW + tx_ * TW + (tid & 31);      // BM == 256 threads
+            if (tid < 2 * BN) s_stat[tid] = 0.f;
+        }
+        __syncthreads();
+        tile_epilogue<T, BM, BN, TM, TN, 256, HALO_BYTES>(acc, true, stage, rowoff, s_stat, wid * 64, 0, lane, n_base, ycs,
+                                                          g, y, addend, stats, ex, t);
+        __syncthreads();        // staging tile / row table / accumulators free again (next tile's halo DMA lands here)
+    }
+    wait_vmcnt<0>();            // the dead halo issued for the tile past the end
+}
+
+// ---------------------------------------------------------------------------
 // weight gradient: dw[co][tap][ci] += sum_pixels dy[pixel][co] * x[gather(pixel,tap)][ci]
 // Workgroup = one 64(co) x 64(ci) tile of one tap; its 4 waves each walk their
 // own 16-pixel slices of the workgroup's pixel range, then reduce through LDS.
@@ -2016,9 +2183,24 @@ static bool halo_ok(const sba_conv_geom& g) {
 static void launch_halo(const sba_conv_geom& g, const bf16_t* x, const bf16_t* w, bf16_t* y, const bf16_t* addend,
                         float* stats, const EpiX ex, hipStream_t st) {
     const int tiles = g.N * (g.OH / 8) * (g.OW / 32);
+    // SBA_CONV_HALO2=1: the persistent variant (one workgroup per CU, weights resident, halo by LDS-DMA).  Measured
+    // SLOWER than the per-tile kernel at three workgroups per CU (G3 upBlock 151 vs 113 us, ResBlock 86 vs 80 us):
+    // with one wave per SIMD the epilogue of a tile overlaps nothing.  Kept as an experiment, off by default.
+    static int v2 = -1;
+    if (v2 < 0) { const char* e = getenv("SBA_CONV_HALO2"); v2 = (e && e[0] == '1') ? 1 : 0; }
+    const int nblocks = g.Cout / 64;
+    if (v2 && tiles >= 512) {
+        // persistent workgroups, one per CU, split evenly over the 64-channel blocks of Cout
+        int per = 256 / nblocks;
+        if (per > tiles) per = tiles;
+        dim3 grid(per * nblocks);
+        if (g.ups) SBA_LAUNCH((conv3x3_halo2_kernel<1>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, ex, tiles, per);
+        else SBA_LAUNCH((conv3x3_halo2_kernel<0>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, ex, tiles, per);
+        return;
+    }
     // BN = 64 for every Cout: the 128-wide variant needs 86 KB of LDS (one workgroup per CU) and
     // measured slower; re-staging the halo tile for the second channel block is cheap
-    dim3 grid(tiles, g.Cout / 64);
+    dim3 grid(tiles, nblocks);
     if (g.ups) SBA_LAUNCH((conv3x3_halo_kernel<64, 64, 1>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, ex);
     else SBA_LAUNCH((conv3x3_halo_kernel<64, 64, 0>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, ex);
 }

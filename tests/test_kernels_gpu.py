@@ -79,6 +79,9 @@ CONV_CASES = [
     ('3x3', 2, 64, 64, 128, 128),     # M = 32768, OW % 64 == 0: all-taps halo-tile wgrad
     ('3x3up', 2, 64, 128, 64, 64),    # same with the fused nearest x2 (output 128 x 128)
     ('3x3', 1, 128, 64, 128, 256),    # two ci tiles, non-square map
+    ('3x3', 8, 64, 64, 128, 128),     # 512 tiles: persistent halo-tile kernel (conv3x3_halo2_kernel), 2 tiles per workgroup
+    ('3x3', 5, 64, 128, 128, 128),    # ... two 64-channel blocks of Cout, 320 tiles per block: uneven tile counts
+    ('3x3up', 9, 64, 64, 64, 64),     # ... behind the nearest x2 upsample (576 tiles, 3 per workgroup for some)
 ]
 
 
@@ -130,6 +133,18 @@ def test_conv_addend_epilogue(dev, dt):
     add = fill.unit((2, 64, 8, 8), 3)
     wp = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
     dx = ops.conv_dgrad(act(x, dt, dev), ops.PackedWeight(wp), '3x3', (8, 8), addend=act(add, dt, dev))
+    ref = F.conv_transpose2d(rounded(x, dt), rounded(w, dt), None, 1, 1) + rounded(add, dt)
+    close(dx, ref, dt, 'dgrad+addend')
+
+
+def test_conv_addend_epilogue_persistent_halo(dev):
+    """the persistent halo-tile kernel with the residual-add epilogue (ResBlock skip gradient) and statistics"""
+    from sbagan import ops
+    dt = torch.bfloat16
+    x, w = fill.unit((8, 64, 128, 128), 1), fill.unit((64, 64, 3, 3), 2) / 24
+    add = fill.unit((8, 64, 128, 128), 3)
+    wp = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
+    dx = ops.conv_dgrad(act(x, dt, dev), ops.PackedWeight(wp), '3x3', (128, 128), addend=act(add, dt, dev))
     ref = F.conv_transpose2d(rounded(x, dt), rounded(w, dt), None, 1, 1) + rounded(add, dt)
     close(dx, ref, dt, 'dgrad+addend')
 
