@@ -12,6 +12,8 @@ Differences from the reference, none of which change a result:
     (losses.py:24-32,73-76) -- it is integer work on `class_ids`, a host array.
 """
 import numpy as np
+import os
+
 import torch
 
 from miscc.config import cfg
@@ -28,6 +30,7 @@ def cosine_similarity(x1, x2, dim=1, eps=1e-8):
 
 _MASK_CACHE = {}
 BATCH_REAL_FAKE = True
+FUSED_HEADS = os.environ.get('SBA_FUSED_HEADS', '1') != '0'   # ops.DHeadsFn: one autograd node per discriminator term
 
 
 def class_mask(class_ids, batch_size, device):
@@ -84,9 +87,19 @@ def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake
     else:
         real_features = netD(real_imgs)
         fake_features = netD(fake_imgs.detach())
+    batch_size = real_features.size(0)
+    if FUSED_HEADS and BATCH_REAL_FAKE and real_imgs.shape == fake_imgs.shape:
+        # the five heads + the BCE sum as one autograd node over the [real | fake] feature map (ops.DHeadsFn):
+        # evaluated in the reference's call order, summed in the order of the terms of errD
+        n = batch_size
+        if netD.UNCOND_DNET is not None:
+            heads = ((0, n, 0, 1., .5, 1), (n, n, 0, 0., 1. / 3, 3), (0, n - 1, 1, 0., 1. / 3, 4),
+                     (0, n, None, 1., .5, 0), (n, n, None, 0., 1. / 3, 2))
+        else:
+            heads = ((0, n, 0, 1., 1., 0), (n, n, 0, 0., .5, 1), (0, n - 1, 1, 0., .5, 2))
+        return ops.d_heads(netD, feats, conditions, heads)
     cond_real = netD.COND_DNET(real_features, conditions)
     cond_fake = netD.COND_DNET(fake_features, conditions)
-    batch_size = real_features.size(0)
     cond_wrong = netD.COND_DNET(real_features[:(batch_size - 1)], conditions[1:batch_size])
     if netD.UNCOND_DNET is not None:
         real = netD.UNCOND_DNET(real_features)
@@ -144,6 +157,15 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
     for i in range(numDs):
         with branch(i):
             features = netsD[i](fake_imgs[i])
+            if FUSED_HEADS:
+                n = features.size(0)
+                if netsD[i].UNCOND_DNET is not None:
+                    g_loss = ops.d_heads(netsD[i], features, sent_emb, ((0, n, 0, 1., 1., 1), (0, n, None, 1., 1., 0)))
+                else:
+                    g_loss = ops.d_heads(netsD[i], features, sent_emb, ((0, n, 0, 1., 1., 0),))
+                terms.append(g_loss)
+                logs['g_loss%d' % i] = g_loss.detach()
+                continue
             cond_logits = netsD[i].COND_DNET(features, sent_emb)
             if netsD[i].UNCOND_DNET is not None:
                 logits = netsD[i].UNCOND_DNET(features)

@@ -1050,6 +1050,159 @@ class BCEMultiFn(torch.autograd.Function):
 _BCE_META = {}
 
 
+def _bce_meta(offs, targets, weights, dev):
+    key = (tuple(offs), tuple(targets), tuple(weights), dev)
+    meta = _BCE_META.get(key)
+    if meta is None:
+        meta = (torch.tensor(offs, dtype=torch.int32, device=dev),
+                torch.tensor(targets, dtype=torch.float32, device=dev),
+                torch.tensor(weights, dtype=torch.float32, device=dev))
+        _BCE_META[key] = meta
+    return meta
+
+
+class DHeadsFn(torch.autograd.Function):
+    """Every head of one discriminator's loss term as ONE autograd node: the conditional heads
+    (cat with the sentence code, jointConv + BatchNorm + LeakyReLU, logits; model.py:594-607), the unconditional
+    heads (model.py:590-592) and the weighted BCE sum (losses.py:141-158 for the discriminator update,
+    :169-178 for the generator term).
+
+    `heads` = tuple of (row0, rows, cond_row0 | None, target, weight, segment): the head reads feats[row0:row0+rows]
+    (and cond[cond_row0:cond_row0+rows] when conditional); they are evaluated in the order given (the reference's
+    call order, which fixes the order of the jointConv BatchNorm running-statistic updates) and summed in `segment`
+    order (the reference's order of the terms of errD / g_loss).  The same kernels as the per-head Functions
+    run; what goes away is the autograd glue between them (row slices copied into zero-filled gradients, gradient sums
+    of the shared feature map, cat of the probabilities): each head's backward writes or accumulates straight into
+    its rows of d feats."""
+
+    @staticmethod
+    def forward(ctx, feats, cond, netD, heads, *params):
+        feats = as_act(feats)
+        dev = feats.device
+        dt = _dt(feats)
+        C = feats.shape[1]
+        assert feats.shape[2] == 4 and feats.shape[3] == 4
+        K = 16 * C
+        cnet, unet = netD.COND_DNET, netD.UNCOND_DNET
+        if cond is not None:
+            cond = cond.reshape(-1, cnet.ef_dim).float().contiguous()
+        sizes = [0] * len(heads)
+        for (r0, rows, c0, tgt, wt, seg) in heads:
+            sizes[seg] = rows
+        offs = [0]
+        for s in sizes:
+            offs.append(offs[-1] + s)
+        prob = torch.empty(offs[-1], dtype=torch.float32, device=dev)
+        tape = []
+        for (r0, rows, c0, tgt, wt, seg) in heads:
+            h = feats[r0:r0 + rows]
+            pslice = prob[offs[seg]:offs[seg] + rows]
+            if c0 is not None:
+                layer = cnet.jointConv._layer()
+                E = cond.shape[1]
+                xin = empty_act(rows, C + E, 4, 4, feats)
+                call('sba_cond_cat_fwd', dt, _p(h), _p(cond[c0:c0 + rows]), _p(xin), rows, C, E, _stream())
+                y, stats = conv_forward(xin, layer.pw, '3x3', want_stats=layer.bn.training)
+                hc, st = bn_act_forward(y, stats, layer.bn, ACT_LRELU)
+                o = cnet.outlogits[0]
+                call('sba_logits_fwd', dt, _p(hc), _p(o.weight), _p(o.bias), _p(pslice), rows, K, _stream())
+                tape.append((xin, y, st, hc))
+            else:
+                o = unet.outlogits[0]
+                call('sba_logits_fwd', dt, _p(h), _p(o.weight), _p(o.bias), _p(pslice), rows, K, _stream())
+                tape.append(None)
+        targets = [0.] * len(heads)
+        weights = [0.] * len(heads)
+        for (r0, rows, c0, tgt, wt, seg) in heads:
+            targets[seg], weights[seg] = tgt, wt
+        meta = _bce_meta(offs, targets, weights, dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dprob = torch.empty_like(prob)
+        call('sba_bce_multi', _p(prob), _p(meta[0]), _p(meta[1]), _p(meta[2]), len(heads), _p(loss), _p(dprob),
+             _stream())
+        ctx.netD, ctx.heads, ctx.offs, ctx.tape = netD, heads, offs, tape
+        ctx.has_cond = cond is not None
+        ctx.cond_shape = None if cond is None else tuple(cond.shape)
+        ctx.save_for_backward(feats, prob, dprob)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, prob, dprob = ctx.saved_tensors
+        netD, heads, offs = ctx.netD, ctx.heads, ctx.offs
+        cnet, unet = netD.COND_DNET, netD.UNCOND_DNET
+        dt = _dt(feats)
+        C = feats.shape[1]
+        K = 16 * C
+        d = dprob * g
+        need_feats = ctx.needs_input_grad[0]
+        need_cond = ctx.has_cond and ctx.needs_input_grad[1]
+        need_p = any(ctx.needs_input_grad[4:])
+        dfeats = torch.empty_like(feats) if need_feats else None
+        dcond = torch.zeros(ctx.cond_shape, dtype=torch.float32, device=feats.device) if need_cond else None
+        # a head whose rows nobody has written yet stores, one whose rows are all written accumulates; widest
+        # heads first, so that the row ranges of the reference's five heads never overlap partially
+        order = sorted(range(len(heads)), key=lambda i: -heads[i][1])
+        written = []
+
+        def mode(r0, rows):
+            inside = any(a <= r0 and r0 + rows <= b for a, b in written)
+            if not inside:
+                assert all(r0 + rows <= a or b <= r0 for a, b in written), 'partially overlapping head rows'
+                written.append((r0, r0 + rows))
+            return 1 if inside else 0
+
+        for i in order:
+            r0, rows, c0, tgt, wt, seg = heads[i]
+            ps, ds = prob[offs[seg]:offs[seg] + rows], d[offs[seg]:offs[seg] + rows]
+            if c0 is None:
+                o = unet.outlogits[0]
+                if not (need_feats or need_p):
+                    continue
+                dh = dfeats[r0:r0 + rows] if need_feats else torch.empty_like(feats[r0:r0 + rows])
+                call('sba_logits_bwd', dt, _p(feats[r0:r0 + rows]), _p(o.weight), _p(ps), _p(ds), _p(dh),
+                     _p(param_grad(o.weight)) if need_p else None, _p(param_grad(o.bias)) if need_p else None,
+                     rows, K, mode(r0, rows) if need_feats else 0, _stream())
+                continue
+            xin, y, st, hc = ctx.tape[i]
+            layer = cnet.jointConv._layer()
+            o = cnet.outlogits[0]
+            dhc = torch.empty_like(hc)
+            call('sba_logits_bwd', dt, _p(hc), _p(o.weight), _p(ps), _p(ds), _p(dhc),
+                 _p(param_grad(o.weight)) if need_p else None, _p(param_grad(o.bias)) if need_p else None,
+                 rows, K, 0, _stream())
+            dy = bn_act_backward(y, dhc, st, layer.bn, ACT_LRELU, need_p)
+            if need_p:
+                conv_wgrad_overlapped(xin, dy, layer.conv.weight, '3x3')
+            if need_feats or need_cond:
+                dxin = conv_dgrad(dy, layer.pw, '3x3', (4, 4))
+                E = xin.shape[1] - C
+                dh = dfeats[r0:r0 + rows] if need_feats else torch.empty_like(feats[r0:r0 + rows])
+                call('sba_cond_cat_bwd', dt, _p(dxin), _p(dh), _p(dcond[c0:c0 + rows]) if need_cond else None,
+                     rows, C, E, mode(r0, rows) if need_feats else 0, _stream())
+        if need_feats:
+            covered = sorted(written)
+            assert covered and covered[0][0] == 0 and covered[-1][1] == feats.shape[0] and \
+                all(covered[k][1] == covered[k + 1][0] for k in range(len(covered) - 1)), 'rows without a head'
+        return (dfeats, dcond, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+def d_heads(netD, feats, cond, heads):
+    """DHeadsFn with the parameters of netD's heads passed as autograd inputs (their gradients go to the flat
+    gradient buffers like every other layer's)."""
+    params = []
+    if netD.COND_DNET is not None:
+        c = netD.COND_DNET
+        if c.bcondition:
+            l = c.jointConv._layer()
+            params += [l.conv.weight, l.bn.weight, l.bn.bias]
+        params += [c.outlogits[0].weight, c.outlogits[0].bias]
+    if netD.UNCOND_DNET is not None:
+        u = netD.UNCOND_DNET
+        params += [u.outlogits[0].weight, u.outlogits[0].bias]
+    return DHeadsFn.apply(feats, cond, netD, tuple(heads), *params)
+
+
 class KLFn(torch.autograd.Function):
     """KL_loss (losses.py:210-214)."""
 

@@ -139,6 +139,61 @@ def test_discriminator_loss(dev, dt, which):
     assert allr <= (1e-3 if dt == torch.float32 else 5e-2), allr
 
 
+@pytest.mark.parametrize('b_jcu', [True, False])
+def test_fused_heads_equal_the_per_head_functions(dev, b_jcu):
+    """ops.DHeadsFn (one autograd node per discriminator term) against the per-head Functions it replaces: the loss,
+    every parameter gradient, the gradient that reaches the images and the sentence code, and the jointConv
+    BatchNorm running statistics -- for the discriminator term (five / three heads) and the generator term."""
+    import model
+    import miscc.losses as L
+    from sbagan import ops
+    ops.set_compute_dtype(torch.float32)
+    B, S = 5, 64
+    P = fill.fill_state_dict(d_shapes(FULL, 0), salt=0)
+    if not b_jcu:
+        P = {k: v for k, v in P.items() if not k.startswith('UNCOND_DNET')}
+    real = fill.uniform((B, 3, S, S), 960).to(dev)
+    sent0 = fill.unit((B, 256), 962).to(dev)
+    ones, zeros = torch.ones(B, device=dev), torch.zeros(B, device=dev)
+
+    def run(fused, term):
+        net = model.D_NET64(b_jcu=b_jcu)
+        net.load_state_dict(P)
+        net.to(dev).train()
+        fake = fill.uniform((B, 3, S, S), 961).to(dev).requires_grad_(True)
+        sent = sent0.clone().requires_grad_(True)
+        L.FUSED_HEADS = fused
+        try:
+            if term == 'D':
+                err = L.discriminator_loss(net, real, fake, sent, ones, zeros)
+            else:
+                feats = net(fake)
+                err = (ops.d_heads(net, feats, sent, ((0, B, 0, 1., 1., 1), (0, B, None, 1., 1., 0)) if b_jcu
+                                   else ((0, B, 0, 1., 1., 0),)) if fused else
+                       (ops.BCEMultiFn.apply((1., 1.), (1., 1.), net.UNCOND_DNET(feats), net.COND_DNET(feats, sent))
+                        if b_jcu else ops.BCEMultiFn.apply((1.,), (1.,), net.COND_DNET(feats, sent))))
+            err.backward()
+        finally:
+            L.FUSED_HEADS = True
+        ops.join_wgrads()
+        torch.cuda.synchronize()
+        out = {'loss': err.detach().reshape(1), 'dsent': sent.grad}
+        if term == 'G':
+            out['dfake'] = fake.grad
+        for n, p in net.named_parameters():
+            out['g.' + n] = p.grad.clone()
+        for n, b in net.named_buffers():
+            if n.endswith(('running_mean', 'running_var')):
+                out['b.' + n] = b.clone()
+        return out
+
+    for term in ('D', 'G'):
+        a, b = run(True, term), run(False, term)
+        assert set(a) == set(b)
+        bad = [(k, rel_l2(a[k], b[k])) for k in a if rel_l2(a[k], b[k]) > 2e-5]
+        assert not bad, (term, bad)
+
+
 def _build_step(dev, B, variant='model', branch=3, encoder='standin'):
     import model
     import model_bert
