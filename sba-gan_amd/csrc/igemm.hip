@@ -1678,6 +1678,178 @@ __global__ __launch_bounds__(256, 2) void wgrad_small_kernel(const T* __restrict
 }
 
 // ---------------------------------------------------------------------------
+// The same decomposition (one 64 x 64 tile of one tap per wave, the workgroup's waves share the dy slices) fed by
+// LDS-DMA through a D-deep ring instead of register staging.  The register-staged kernel above prefetches ONE
+// 16-pixel chunk (four MFMAs, ~0.1 us) ahead of an L2 round trip of ~1 us, so every chunk costs a full memory
+// latency: 320 pixels = 20 chunks ~ 30 us per workgroup whatever the MFMA work is.  Here a stage is 32 pixels
+// (two MFMA k-steps): per wave four 1 KB DMA instructions for its own x slice (the im2col gather is the per-lane
+// address) and CT for its share of the dy slices; D - 1 stages are in flight, completion is counted with
+// s_waitcnt vmcnt + one workgroup barrier per stage, exactly like igemm_dma_kernel.  Rows are 128 bytes (64
+// channels, no padding: the DMA writes lane l at M0 + 16 l); the 16-byte chunk position is XORed with bit 1 of the
+// row so that the four rows x 32 bytes a 16-lane group reads with ds_read_b64_tr_b16 fall in different banks.
+// ---------------------------------------------------------------------------
+struct WgFragDma {
+    // fragment of channels [c32, c32+32) over pixels [16 k16, 16 k16 + 16) of a 32-row slice
+    static __device__ __forceinline__ bf16x8_t load(const unsigned char* slice, int k16, int c32, int lane) {
+        const int g16 = lane >> 4, i16 = lane & 15;
+        const int cbase = c32 + 16 * (g16 & 1), row = 16 * k16 + 8 * (g16 >> 1) + (i16 >> 2), p = i16 & 3;
+        const int cpos = (cbase >> 3) ^ (((row >> 1) & 1) << 2);
+        const unsigned char* a0 = slice + row * 128 + cpos * 16 + p * 8;
+        typedef __attribute__((address_space(3))) s16x4_t* lptr;
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * 128));
+        bf16x8_t r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    }
+};
+
+template <int CT, int D>
+__global__ __launch_bounds__(256, 2) void wgrad_small_dma_kernel(const bf16_t* __restrict__ x,
+                                                              const bf16_t* __restrict__ dy,
+                                                              float* __restrict__ dw, const sba_conv_geom g,
+                                                              const int M, const int chunks_per_split,
+                                                              const int use_atomic, const FastDiv dsub,
+                                                              const FastDiv dow) {
+    constexpr int SL = 32 * 128;                 // one slice: 32 pixels x 64 channels
+    constexpr int STAGE = (CT + 4) * SL;         // [dy slices (shared)] [x slice of wave 0..3]
+    constexpr int LPS = 4 + CT;                  // DMA instructions per wave per stage
+    extern __shared__ __attribute__((aligned(1024))) unsigned char wg_lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = blockIdx.x * (64 * CT);
+    const int ci_tiles = (g.Cin + 63) / 64;
+    const int item = blockIdx.y * 4 + wid;
+    const bool active = item < g.ntaps * ci_tiles;
+    const int tap = active ? item / ci_tiles : 0;
+    const int ci0 = active ? (item - tap * ci_tiles) * 64 : 0;
+    int ty = 0, tx = 0;
+#pragma unroll
+    for (int t = 0; t < SBA_MAX_TAPS; ++t)
+        if (t == tap) { ty = g.ty[t]; tx = g.tx[t]; }
+    const int IHL = g.ups ? 2 * g.IH : g.IH, IWL = g.ups ? 2 * g.IW : g.IW;
+    const int sub = g.OHs * g.OWs;
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)wg_lds;
+    const uint32_t x_bytes = (uint32_t)((int64_t)g.N * g.IH * g.IW * g.Cin * 2);
+    const uint32_t dy_bytes = (uint32_t)((int64_t)g.N * g.OH * g.OW * g.Cout * 2);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
+    constexpr uint32_t OOB = 0xFFFFFFFFu;
+
+    // lane l of a DMA instruction fills 16-byte position (l & 7) of row (l >> 3) of its 8-row block; that position
+    // holds channel chunk (l & 7) ^ 4 * bit1(row)
+    const int rsub = lane >> 3, cg = (lane & 7) ^ (((lane >> 4) & 1) << 2);
+    const bool x_ok = active && ci0 + cg * 8 < g.Cin;
+    const uint32_t x_coff = (uint32_t)(ci0 + cg * 8) * 2u;
+    const int dslice = CT == 1 ? 0 : (wid >> 1);
+    const bool d_ok = co0 + dslice * 64 + cg * 8 < g.Cout;
+    const uint32_t d_coff = (uint32_t)(co0 + dslice * 64 + cg * 8) * 2u;
+    const uint32_t x_pix = (uint32_t)g.Cin * 2u, d_pix = (uint32_t)g.Cout * 2u;
+
+    const int total_chunks = (M + 31) / 32;
+    const int chunk_lo = blockIdx.z * chunks_per_split;
+    const int chunk_hi = min(chunk_lo + chunks_per_split, total_chunks);
+    int g_ck = chunk_lo;
+
+    auto issue = [&](const uint32_t dst) {
+        const bool live = g_ck < chunk_hi;
+        const int m0 = g_ck * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + 8 * i + rsub;
+            uint32_t off = OOB;
+            if (live && x_ok && m < M) {
+                const int n = (int)fdiv(m, dsub), rem = m - n * sub;
+                const int oy = (int)fdiv(rem, dow), ox = rem - oy * g.OWs;
+                int iy = oy * g.sy + ty, ix = ox * g.sx + tx;
+                const bool ok = (iy >= 0) & (iy < IHL) & (ix >= 0) & (ix < IWL);
+                if (g.ups) { iy >>= 1; ix >>= 1; }
+                if (ok) off = (uint32_t)((n * g.IH + iy) * g.IW + ix) * x_pix + x_coff;
+            }
+            lds_dma16(xr, off, 0u, dst + (uint32_t)((CT + wid) * SL + i * 1024));
+        }
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            const int i = CT == 1 ? wid : 2 * (wid & 1) + j;
+            const int m = m0 + 8 * i + rsub;
+            uint32_t off = OOB;
+            if (live && d_ok && m < M) {
+                const int n = (int)fdiv(m, dsub), rem = m - n * sub;
+                const int oy = (int)fdiv(rem, dow), ox = rem - oy * g.OWs;
+                off = (uint32_t)((n * g.OH + oy * g.osy + g.ooy) * g.OW + ox * g.osx + g.oox) * d_pix + d_coff;
+            }
+            lds_dma16(dr, off, 0u, dst + (uint32_t)(dslice * SL + i * 1024));
+        }
+        ++g_ck;
+    };
+
+    f32x16_t acc[CT][2][2];
+#pragma unroll
+    for (int s = 0; s < CT; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[s][i][j][r] = 0.f;
+
+    int islot = 0;
+#pragma unroll
+    for (int p = 0; p < D - 1; ++p) { issue(lds_base + (uint32_t)(islot * STAGE)); ++islot; }
+    if (islot == D) islot = 0;
+    int cslot = 0;
+    for (int ck = chunk_lo; ck < chunk_hi; ++ck) {
+        wait_vmcnt<(D - 2) * LPS>();         // this wave's part of stage ck has landed ...
+        wg_barrier();                        // ... and everybody else's; nobody reads slot (ck - 1) % D any more
+        issue(lds_base + (uint32_t)(islot * STAGE));
+        if (++islot == D) islot = 0;
+        const unsigned char* st = wg_lds + cslot * STAGE;
+        const unsigned char* sb = st + (CT + wid) * SL;
+#pragma unroll
+        for (int k16 = 0; k16 < 2; ++k16) {
+            bf16x8_t b[2];
+            b[0] = WgFragDma::load(sb, k16, 0, lane);
+            b[1] = WgFragDma::load(sb, k16, 32, lane);
+#pragma unroll
+            for (int s = 0; s < CT; ++s) {
+                bf16x8_t a[2];
+                a[0] = WgFragDma::load(st + s * SL, k16, 0, lane);
+                a[1] = WgFragDma::load(st + s * SL, k16, 32, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[s][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[s][i][j], 0, 0, 0);
+            }
+        }
+        if (++cslot == D) cslot = 0;
+    }
+    wait_vmcnt<0>();            // the dead stages issued past the end still write (zeros) into the ring
+    wg_barrier();
+
+    if (!active) return;
+    const int col_l = lane & 31, rsel = 4 * (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < CT; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + s * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
+                    const int ci = ci0 + j * 32 + col_l;
+                    if (co < g.Cout && ci < g.Cin) {
+                        float* p = dw + ((int64_t)co * g.ntaps + tap) * g.Cin + ci;
+                        if (use_atomic) atomicAdd(p, acc[s][i][j][r]);
+                        else *p += acc[s][i][j][r];
+                    }
+                }
+}
+
+// ---------------------------------------------------------------------------
 // weight gradient, large-map 3x3 stride-1 convs (optionally over a nearest-x2 upsampled input)
 // with OW % 64 == 0: the generator's 64..256 px layers, where ~all wgrad FLOPs are.
 // A workgroup owns one 64(co) x 64(ci) tile for ALL nine taps: per 64-pixel segment of an output
@@ -2398,6 +2570,52 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
             grid.x = co_tiles / 2;
             SBA_DISPATCH(dtype, SBA_LAUNCH((wgrad_small_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream,
                                                    (const T*)x, (const T*)dy, dw, *g, M, cps, 0, dsub, dow));
+            return SBA_CHECK_LAUNCH();
+        }
+        static int dma = -1;        // SBA_WGRAD_DMA: 0 = register-staged kernel; D = ring depth of the LDS-DMA kernel
+        if (dma < 0) { const char* e = getenv("SBA_WGRAD_DMA"); dma = e ? atoi(e) : 4; }
+        const int64_t xb = (int64_t)g->N * g->IH * g->IW * g->Cin * 2, db = (int64_t)g->N * g->OH * g->OW * g->Cout * 2;
+        // measured (tools/bench_wgrad.py, B = 20): 15-25 % faster than the register-staged kernel up to ~512
+        // workgroups (joint conv 29 -> 25 us, D s32 61 -> 50, s32_1 49 -> 37); beyond that the launches are bound by
+        // the L2 traffic of the operand slices either way and the 80 KB ring costs occupancy (s64 145 -> 175 us)
+        static int dma_wgs = -1;
+        if (dma_wgs < 0) { const char* e = getenv("SBA_WGRAD_DMA_WGS"); dma_wgs = e ? atoi(e) : 512; }
+        static int dma_ct2 = -1;    // SBA_WGRAD_DMA_CT2=1: beyond dma_wgs use the DMA kernel with TWO co tiles per wave
+        if (dma_ct2 < 0) { const char* e = getenv("SBA_WGRAD_DMA_CT2"); dma_ct2 = e ? atoi(e) : 0; }
+        if (dma > 0 && dma_ct2 > 0 && wgs > dma_wgs && g->Cout % 128 == 0 && dtype == SBA_BF16 && xb < (1ll << 32) &&
+            db < (1ll << 32)) {
+            const int tc32 = cdiv(M, 32);
+            dim3 gd(co_tiles / 2, cdiv(items, 4), 1);
+            constexpr int LDS = 3 * 6 * 32 * 128;
+            static bool once = false;
+            if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_small_dma_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
+            SBA_LAUNCH((wgrad_small_dma_kernel<2, 3>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
+                       (const bf16_t*)dy, dw, *g, M, tc32, 0, dsub, dow);
+            return SBA_CHECK_LAUNCH();
+        }
+        if (dma > 0 && wgs <= dma_wgs && dtype == SBA_BF16 && xb < (1ll << 32) && db < (1ll << 32)) {
+            // stages of 32 pixels; the same split rule restated in 32-pixel chunks
+            const int tc32 = cdiv(M, 32);
+            int sp = wgs >= tgt / 2 ? 1 : cdiv(tgt, wgs);
+            const int mc = minc / 2 > 0 ? minc / 2 : 1;
+            if (sp > tc32 / mc) sp = tc32 / mc > 0 ? tc32 / mc : 1;
+            const int cps32 = cdiv(tc32, sp);
+            sp = cdiv(tc32, cps32);
+            dim3 gd(co_tiles, cdiv(items, 4), sp);
+            if (gd.z > 65535) return SBA_E_ARG;
+            if (dma == 3) {
+                constexpr int LDS = 3 * 5 * 32 * 128;
+                static bool once = false;
+                if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_small_dma_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
+                SBA_LAUNCH((wgrad_small_dma_kernel<1, 3>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
+                           (const bf16_t*)dy, dw, *g, M, cps32, sp > 1 ? 1 : 0, dsub, dow);
+            } else {
+                constexpr int LDS = 4 * 5 * 32 * 128;
+                static bool once = false;
+                if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_small_dma_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
+                SBA_LAUNCH((wgrad_small_dma_kernel<1, 4>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
+                           (const bf16_t*)dy, dw, *g, M, cps32, sp > 1 ? 1 : 0, dsub, dow);
+            }
             return SBA_CHECK_LAUNCH();
         }
         SBA_DISPATCH(dtype, SBA_LAUNCH((wgrad_small_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream,
