@@ -145,12 +145,15 @@ int sba_bn_act_fwd(int dtype, const void* y, const float* stats, const float* ga
                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float* aux,
                    const void* residual, void* out, int64_t rows, int groups, int C, int act,
                    int out_cstride, int out_coff, float eps, float momentum, int training, void* stream);
-/* pass 1 of the backward: red[g][0..C) += sum dz, red[g][C..2C) += sum dz*xhat, where dz is the
- * gradient w.r.t. the BN output (activation backward applied to dout on the fly). */
+/* pass 1 of the backward: red[g][slot][0..C) += sum dz, red[g][slot][C..2C) += sum dz*xhat, where dz is the
+ * gradient w.r.t. the BN output (activation backward applied to dout on the fly).  Like the forward statistics the
+ * sums are spread over SBA_BN_STAT_SLOTS replicas: red is [groups][SBA_BN_STAT_SLOTS][2C] floats, zeroed by the
+ * caller; pass 2 adds the replicas up. */
 int sba_bn_act_bwd_reduce(int dtype, const void* y, const void* dout, const float* aux, float* red,
                           int64_t rows, int groups, int C, int act, int dout_cstride, int dout_coff,
                           void* stream);
-/* pass 2: dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); also dgamma += red[g][C+c], dbeta += red[g][c]. */
+/* pass 2: dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); also dgamma += sum_slots red[g][.][C+c],
+ * dbeta += sum_slots red[g][.][c]. */
 int sba_bn_act_bwd_apply(int dtype, const void* y, const void* dout, const float* aux, const float* red,
                          void* dy, float* dgamma, float* dbeta, int64_t rows, int groups, int C, int act,
                          int dout_cstride, int dout_coff, void* stream);

@@ -538,7 +538,7 @@ def bn_act_backward(y, dout, st, bn, act, need_param_grad=True):
         call('sba_bn_act_bwd_fused', _dt(y), _p(y), _p(dout), _p(st.aux), _p(dy), _p(dg), _p(db), st.rows, st.groups,
              C, act, Co, 0, _stream())
         return dy
-    red = zeros_f32((st.groups, 2 * C), y.device)
+    red = zeros_f32((st.groups, BN_STAT_SLOTS, 2 * C), y.device)
     call('sba_bn_act_bwd_reduce', _dt(y), _p(y), _p(dout), _p(st.aux), _p(red), st.rows, st.groups, C, act, Co, 0,
          _stream())
     call('sba_bn_act_bwd_apply', _dt(y), _p(y), _p(dout), _p(st.aux), _p(red), _p(dy), _p(dg), _p(db), st.rows,
