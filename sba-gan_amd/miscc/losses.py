@@ -28,6 +28,29 @@ def cosine_similarity(x1, x2, dim=1, eps=1e-8):
     return (w12 / (w1 * w2).clamp(min=eps)).squeeze()
 
 
+class LossLogs(dict):
+    """generator_loss's second return value.  The reference builds a string with five .item() host syncs inside the
+    step (losses.py:184,205: 'g_loss0: 1.23 ... w_loss: 4.56 s_loss: 7.89 '); here the values stay device scalars in
+    a dict, and the reference's string is produced on demand: str(logs), '%s' % logs, logs + '\n' all give the
+    reference's text (and synchronise only then)."""
+
+    def __str__(self):
+        out = ''
+        i = 0
+        while 'g_loss%d' % i in self:
+            out += 'g_loss%d: %.2f ' % (i, float(self['g_loss%d' % i]))
+            i += 1
+        if 'w_loss' in self and 's_loss' in self:
+            out += 'w_loss: %.2f s_loss: %.2f ' % (float(self['w_loss']), float(self['s_loss']))
+        return out
+
+    def __add__(self, other):
+        return str(self) + other
+
+    def __radd__(self, other):
+        return other + str(self)
+
+
 _MASK_CACHE = {}
 BATCH_REAL_FAKE = True
 FUSED_HEADS = os.environ.get('SBA_FUSED_HEADS', '1') != '0'   # ops.DHeadsFn: one autograd node per discriminator term
@@ -144,7 +167,7 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
     import contextlib
     numDs = len(netsD)
     batch_size = real_labels.size(0)
-    logs = {}
+    logs = LossLogs()
     main = torch.cuda.current_stream() if streams else None
 
     def branch(k):

@@ -280,3 +280,16 @@ def test_data_path_matches_reference_contract(tmp_path):
     arr, cl, order = dic['example_captions']
     assert list(cl) == sorted(cl, reverse=True) and arr.shape == (3, max(cl)) and list(order) == [2, 0, 1]
     reset_cfg()
+
+
+def test_generator_loss_logs_format_like_the_reference():
+    """losses.py:184,205 build 'g_loss0: 1.23 g_loss1: ... w_loss: 4.56 s_loss: 7.89 ' with .item() syncs inside
+    the step; miscc.losses.LossLogs keeps device scalars and renders the same text on demand."""
+    from miscc.losses import LossLogs
+    logs = LossLogs()
+    logs['g_loss0'], logs['g_loss1'] = torch.tensor(1.234), torch.tensor(0.5)
+    logs['w_loss'], logs['s_loss'] = torch.tensor(12.345), torch.tensor(0.004)
+    want = 'g_loss0: 1.23 g_loss1: 0.50 w_loss: 12.35 s_loss: 0.00 '
+    assert str(logs) == want and '%s' % logs == want
+    assert 'errD0: 0.70 ' + '\n' + logs == 'errD0: 0.70 \n' + want       # trainer.py:313 concatenates D_logs + G_logs
+    assert isinstance(logs, dict) and float(logs['w_loss']) == pytest.approx(12.345)

@@ -152,6 +152,79 @@ def test_conv_addend_epilogue_persistent_halo(dev):
     close(dx, ref, dt, 'dgrad+addend')
 
 
+# ------------------------------------------------------------------ the image encoder's conv geometries
+# (KH, KW, stride, pad_h, pad_w, input size): every distinct BasicConv2d shape of the Inception-v3 trunk
+# (model.py:170-267).  The module-level test (test_step_gpu.py::test_image_encoder_hip_vs_torch) pins the graph in f32;
+# in bf16 ReLU-mask flips blur the image gradient, so the bf16 kernels and the operand packing of
+# sbagan.inception_hip._Conv (BN fold, channel padding to 32, flipped / parity-split data-gradient taps) are pinned
+# here per geometry, elementwise-tight, on inputs already rounded to the storage type.
+INCEPTION_GEOMS = [
+    (1, 1, 1, 0, 0, 17), (3, 3, 2, 0, 0, 35), (3, 3, 1, 0, 0, 19), (3, 3, 1, 1, 1, 17), (5, 5, 1, 2, 2, 17),
+    (1, 7, 1, 0, 3, 17), (7, 1, 1, 3, 0, 17), (1, 3, 1, 0, 1, 8), (3, 1, 1, 1, 0, 8), (3, 3, 2, 0, 0, 17),
+]
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+@pytest.mark.parametrize('geom', INCEPTION_GEOMS)
+def test_inception_conv_geometries(dev, dt, geom):
+    import ctypes
+    from sbagan import _lib, ops
+    from sbagan.inception_hip import _Conv, _geom
+    KH, KW, s, ph, pw, S = geom
+    N, I, O = 2, 80, 112                     # 80 input channels: padded to 96 inside the packed operands
+    conv = torch.nn.Conv2d(I, O, (KH, KW), stride=s, padding=(ph, pw), bias=False)
+    bn = torch.nn.BatchNorm2d(O, eps=1e-3).eval()
+    with torch.no_grad():
+        conv.weight.copy_(fill.unit((O, I, KH, KW), 11) / np.sqrt(I * KH * KW))
+        bn.weight.copy_(1.0 + 0.2 * fill.uniform((O,), 12))
+        bn.bias.copy_(0.1 * fill.uniform((O,), 13))
+        bn.running_mean.copy_(0.1 * fill.uniform((O,), 14))
+        bn.running_var.copy_(1.0 + 0.3 * fill.uniform((O,), 15))
+    L = _Conv(conv.to(dev), bn.to(dev), dt, relu=True)
+    dtc = _lib.SBA_BF16 if dt == torch.bfloat16 else _lib.SBA_F32
+    ws = ops.workspace(dev)
+
+    def igemm(x, w, y, bias, g):
+        _lib.call('sba_conv_igemm_bias', dtc, x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None,
+                  None if bias is None else bias.data_ptr(), None, ctypes.byref(g), ws.data_ptr(),
+                  ops.WORKSPACE_BYTES, ops._stream())
+
+    x = fill.unit((N, I, S, S), 16)
+    xa = torch.zeros((N, S, S, L.Ip), dtype=dt, device=dev)
+    xa[..., :I] = x.permute(0, 2, 3, 1).to(dev).to(dt)
+    OH, OW = (S + 2 * ph - KH) // s + 1, (S + 2 * pw - KW) // s + 1
+    y = torch.empty((N, OH, OW, L.Op), dtype=dt, device=dev)
+    taps = [(t // KW - ph, t % KW - pw) for t in range(KH * KW)]
+    igemm(xa, L.w_fwd, y, L.bias, _geom(N, S, S, L.Ip, OH, OW, L.Op, taps, sy=s, xcs=L.Ip, ycs=L.Op, relu=1))
+    torch.cuda.synchronize()
+    # reference on the operands the kernel sees: the folded weight rounded to the storage type, f32 bias
+    wf = L.w_fwd.float().cpu()[:O, :, :I].reshape(O, KH, KW, I).permute(0, 3, 1, 2).contiguous()
+    xr = rounded(x, dt).requires_grad_(True)
+    pre = F.conv2d(xr, wf, None, s, (ph, pw))
+    yr = torch.relu(pre + L.bias.cpu()[:O].view(1, -1, 1, 1))
+    close(y[..., :O].permute(0, 3, 1, 2), yr, dt, 'y')
+    assert float(y[..., O:].float().abs().max()) == 0.0, 'padded output channels'
+    # data gradient of the linear part (the ReLU mask is a separate pass / epilogue, tested with the module)
+    dy = fill.unit((N, O, OH, OW), 17)
+    dyr = rounded(dy, dt)
+    (gx_ref,) = torch.autograd.grad(pre, xr, dyr)
+    dya = torch.zeros((N, OH, OW, L.Op), dtype=dt, device=dev)
+    dya[..., :O] = dy.permute(0, 2, 3, 1).to(dev).to(dt)
+    gx = torch.zeros((N, S, S, L.Ip), dtype=dt, device=dev)
+    if s == 1:
+        igemm(dya, L.w_dgrad[0], gx, None, _geom(N, OH, OW, L.Op, S, S, L.Ip, L.dtaps[0], xcs=L.Op, ycs=L.Ip))
+    else:
+        for cls in range(4):
+            py, px = cls // 2, cls % 2
+            OHs, OWs = (S - py + 1) // 2, (S - px + 1) // 2
+            if OHs <= 0 or OWs <= 0 or not L.dtaps[cls]:
+                continue
+            igemm(dya, L.w_dgrad[cls], gx, None, _geom(N, OH, OW, L.Op, S, S, L.Ip, L.dtaps[cls], OHs=OHs, OWs=OWs,
+                                                       osy=2, ooy=py, oox=px, xcs=L.Op, ycs=L.Ip))
+    torch.cuda.synchronize()
+    close(gx[..., :I].permute(0, 3, 1, 2), gx_ref, dt, 'dx')
+
+
 # ------------------------------------------------------------------ fused blocks vs the oracle
 def _load(mod, P, dev):
     mod.load_state_dict(P)
@@ -404,6 +477,66 @@ def test_damsm_losses(dev):
         assert abs(float(t0) - float(s0)) < 1e-4 * max(1, abs(float(s0)))
         assert abs(float(t1) - float(s1)) < 1e-4 * max(1, abs(float(s1)))
         close(ca.grad, cr.grad, torch.float32, 'dcnn', scale=10); close(sa.grad, sr.grad, torch.float32, 'drnn', scale=10)
+
+
+def test_public_func_attention_vs_reference_golden(dev, golden_dir):
+    """GlobalAttention.func_attention (GlobalAttention.py:31-69) as exported by the drop-in package, on the GPU,
+    against the output of the reference's own function (tests/golden/units_tiny.npz, tools/make_golden.py)."""
+    import GlobalAttention
+    from helpers import TINY, check, load_golden, make_inputs
+    G = load_golden(golden_dir, 'units_tiny.npz')
+    x = make_inputs(TINY, 3, 6, tag=100)
+    feat = fill.unit((3, TINY['nef'], 17, 17), 211)
+    wc, at = GlobalAttention.func_attention(x['words'].to(dev), feat.to(dev), 4.0)
+    torch.cuda.synchronize()
+    check(G, 'funcattn/wctx', wc.cpu())
+    check(G, 'funcattn/att', at.cpu())
+
+
+def test_generator_loss_vs_oracle(dev):
+    """miscc.losses.generator_loss (losses.py:164-206) stand-alone, 3 discriminators + stand-in image encoder, f32:
+    the total, every logged component (and the reference's log string format), and the gradient w.r.t. each fake
+    image against the oracle."""
+    import model
+    from helpers import FULL, d_shapes
+    from miscc import losses
+    from miscc.config import cfg
+    from sbagan import ops
+    ops.set_compute_dtype(torch.float32)
+    B, L = 3, 7
+    nets, Ps = [], []
+    for i, cls in enumerate((model.D_NET64, model.D_NET128, model.D_NET256)):
+        P = fill.fill_state_dict(d_shapes(FULL, i), salt=i)
+        for k in P:
+            if k.endswith('outlogits.0.weight'):
+                P[k] = P[k] * 0.1          # keep the sigmoids out of saturation (see test_discriminator_loss)
+        n = cls()
+        n.load_state_dict(P)
+        nets.append(n.to(dev).train())
+        Ps.append({k: v.clone() for k, v in P.items()})
+    enc = fill.StandInImageEncoder(256, device=dev)
+    enc_cpu = fill.StandInImageEncoder(256, device=torch.device('cpu'))
+    fakes = [fill.uniform((B, 3, 64 * 2 ** i, 64 * 2 ** i), 970 + i) for i in range(3)]
+    words, sent = fill.unit((B, 256, L), 975), fill.unit((B, 256), 976)
+    lens = torch.tensor([7, 5, 2])
+    labels, cids = torch.arange(B), np.array([0, 1, 0])
+    fr = [f.clone().requires_grad_(True) for f in fakes]
+    smooth = dict(GAMMA1=4.0, GAMMA2=5.0, GAMMA3=10.0, LAMBDA=5.0)
+    tot_r, logs_r = O.generator_loss(Ps, enc_cpu, fr, torch.ones(B), words, sent, labels, lens, cids, smooth)
+    tot_r.backward()
+    fa = [f.to(dev).requires_grad_(True) for f in fakes]
+    tot, logs = losses.generator_loss(nets, enc, fa, torch.ones(B, device=dev), words.to(dev), sent.to(dev),
+                                      labels.to(dev), lens.to(dev), cids)
+    tot.backward()
+    torch.cuda.synchronize()
+    assert abs(float(tot) - float(tot_r)) <= 2e-4 * abs(float(tot_r)), (float(tot), float(tot_r))
+    for k, v in logs_r.items():
+        assert abs(float(logs[k]) - float(v)) <= 2e-4 * max(1.0, abs(float(v))), (k, float(logs[k]), float(v))
+    ref_str = ''.join('g_loss%d: %.2f ' % (i, float(logs_r['g_loss%d' % i])) for i in range(3)) + \
+        'w_loss: %.2f s_loss: %.2f ' % (float(logs_r['w_loss']), float(logs_r['s_loss']))
+    assert str(logs) == ref_str and ('x' + logs) == 'x' + ref_str and (logs + '\n') == ref_str + '\n'
+    for i in range(3):
+        close(fa[i].grad, fr[i].grad, torch.float32, 'dfake%d' % i, scale=30)
 
 
 def test_bce_kl_adam(dev):
