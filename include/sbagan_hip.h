@@ -76,7 +76,10 @@ const char* sba_version(void);
  * stats[0..Cout) and stats[Cout..2Cout) (caller zeroes it) -- the BatchNorm batch statistics. */
 /* workspace (may be NULL): scratch for split-K of small-M / long-K layers, used when it holds
  * >= 4*M*Cout bytes.  It must be ZERO-FILLED when first handed in; every call leaves it zero-filled
- * again, so stream-ordered reuse of one buffer needs no further memsets. */
+ * again, so stream-ordered reuse of one buffer needs no further memsets.  With SBA_SPLITK_FUSED=1 in the environment
+ * (an experiment, off by default) and 64 KiB more room than the partial sums need, its LAST 64 KiB are arrival
+ * tickets (one int32 per output tile): the last K split to arrive finishes the tile inside the GEMM kernel instead of
+ * a separate finishing launch. */
 int sba_conv_igemm(int dtype, const void* x, const void* w, void* y, const void* addend,
                    float* stats, const sba_conv_geom* g, void* workspace, int64_t workspace_bytes,
                    void* stream);

@@ -541,6 +541,63 @@ __device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t rsrc, con
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
+// Split-K without a finishing launch: every split adds its partial tile into the zero-filled f32 workspace with
+// device-scope atomics, then takes a ticket for its output tile; the LAST arrival reads the complete sums back
+// (device-scope loads: the partial sums were performed at the memory side, not in this XCD's L2), leaves the
+// workspace and the ticket zero for the next user, and runs the ordinary epilogue (bias / ReLU / addend / mask / BN
+// statistics / y) as if it had computed the whole K range itself.  Nobody waits for anybody: a workgroup that is
+// not last simply exits.  Returns true for the workgroup that has to run the epilogue.
+constexpr int SPLITK_TICKET_BYTES = 64 * 1024;      // tail of the workspace: one int32 ticket per output tile
+template <int TM, int TN>
+__device__ __forceinline__ bool splitk_arrive(float* __restrict__ ws, int* __restrict__ tickets, f32x16_t (&acc)[TM][TN],
+                                              const int m0, const int n0, const int lane, const int M, const int Cout,
+                                              const int tile_id, int* s_ticket) {
+    const int col_s = lane & 31, rsel_s = 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = n0 + j * 32 + col_s;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel_s;
+                if (m < M && co < Cout) atomicAdd(&ws[(int64_t)m * Cout + co], acc[i][j][r]);
+            }
+    }
+    if (!tickets) return false;                 // the caller launches splitk_finish_kernel
+    // Order "my partial sums, then my ticket" WITHOUT a release fence: at agent scope a fence writes back and
+    // invalidates the whole L2 of this XCD (measured: the step went from 14.4 to 18.6 ms).  The partial sums are
+    // device-scope atomics, performed at the memory side and acknowledged once performed; vmcnt counts them, so after
+    // s_waitcnt vmcnt(0) they are visible to every later device-scope access -- the ticket, and the last arrival's
+    // device-scope loads, which bypass the L2 themselves.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) *s_ticket = atomicAdd(&tickets[tile_id], 1);
+    __syncthreads();
+    const int ticket = *s_ticket;
+    __syncthreads();                            // s_ticket is a word of the staging ring: the epilogue reuses it
+    if (ticket != (int)gridDim.z - 1) return false;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = n0 + j * 32 + col_s;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel_s;
+                float v = 0.f;
+                if (m < M && co < Cout) {
+                    float* p = &ws[(int64_t)m * Cout + co];
+                    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                acc[i][j][r] = v;
+            }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&tickets[tile_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
 #ifdef SBA_DMA_TRACE     // tools/trace_dma.py: per-stage s_memtime stamps of wave 0 of the first workgroups
 static unsigned long long* g_dma_trace = nullptr;
 extern "C" void sba_set_dma_trace(unsigned long long* p) { g_dma_trace = p; }
@@ -558,7 +615,8 @@ template <int BM, int BN, int WM, int WN, int KS, int D>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
     const bf16_t* __restrict__ addend, float* __restrict__ stats, const sba_conv_geom g, const int M,
-    float* __restrict__ ws, const int slabs_per_split, const EpiX ex, const int gx, const int gy DMA_TRACE_PARAM) {
+    float* __restrict__ ws, int* __restrict__ tickets, const int slabs_per_split, const EpiX ex, const int gx,
+    const int gy DMA_TRACE_PARAM) {
     typedef bf16_t T;
     constexpr int TM = WM / 32, TN = WN / 32, WAVES_N = BN / WN;
     constexpr int NW = (BM / WM) * (BN / WN), NT = NW * 64;
@@ -751,19 +809,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(
     wg_barrier();
 
     if (ws) {
-        const int col_s = lane & 31, rsel_s = 4 * (lane >> 5);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int co = n_base + wn0 + j * 32 + col_s;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m_base + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel_s;
-                    if (m < M && co < g.Cout) atomicAdd(&ws[(int64_t)m * g.Cout + co], acc[i][j][r]);
-                }
-        }
-        return;
+        if (!splitk_arrive<TM, TN>(ws, tickets, acc, m_base + wm0, n_base + wn0, lane, M, g.Cout, (int)blockIdx.x,
+                                   reinterpret_cast<int*>(lds_all)))
+            return;
     }
     for (int r = threadIdx.x; r < BM; r += NT) {
         const int m = m_base + r;
@@ -802,7 +850,8 @@ template <int BM, int BN, int WM, int WN, int D>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma2_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
     const bf16_t* __restrict__ addend, float* __restrict__ stats, const sba_conv_geom g, const int M,
-    float* __restrict__ ws, const int slabs_per_split, const EpiX ex, const int gx, const int gy DMA_TRACE_PARAM) {
+    float* __restrict__ ws, int* __restrict__ tickets, const int slabs_per_split, const EpiX ex, const int gx,
+    const int gy DMA_TRACE_PARAM) {
     typedef bf16_t T;
     constexpr int TM = WM / 32, TN = WN / 32, WAVES_N = BN / WN;
     constexpr int NW = (BM / WM) * (BN / WN), NT = NW * 64;
@@ -1022,19 +1071,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma2_kernel(
     wg_barrier();
 
     if (ws) {
-        const int col_s = lane & 31, rsel_s = 4 * (lane >> 5);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int co = n_base + wn0 + j * 32 + col_s;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m_base + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel_s;
-                    if (m < M && co < g.Cout) atomicAdd(&ws[(int64_t)m * g.Cout + co], acc[i][j][r]);
-                }
-        }
-        return;
+        if (!splitk_arrive<TM, TN>(ws, tickets, acc, m_base + wm0, n_base + wn0, lane, M, g.Cout, (int)blockIdx.x,
+                                   reinterpret_cast<int*>(lds_all)))
+            return;
     }
     for (int r = threadIdx.x; r < BM; r += NT) {
         const int m = m_base + r;
@@ -2283,9 +2322,23 @@ static void launch_cfg(const T* xp, const T* wp, T* yp, const T* ap, float* stat
     }
 }
 
+// SBA_SPLITK_FUSED=1: the last split to arrive finishes its tile inside the GEMM kernel (splitk_arrive); the tickets
+// live in the last SPLITK_TICKET_BYTES of the (zero-filled, left zero-filled) workspace.  Default 0 = separate
+// splitk_finish_kernel launch: the fused form passes the whole GPU suite but measured no gain on the step (14.96 vs
+// 14.78 ms, 75 finishing launches fewer): the last arrival's 16 KB device-scope reload + epilogue sits at the tail of
+// every tile, where the finishing launch spreads the same work over the whole chip.
+static int* splitk_tickets(float* ws, int64_t ws_bytes, int M, int Cout, int tiles) {
+    static int fused = -1;
+    if (fused < 0) { const char* e = getenv("SBA_SPLITK_FUSED"); fused = (e && e[0] == '1') ? 1 : 0; }
+    if (!fused || !ws || ws_bytes < 2 * SPLITK_TICKET_BYTES) return nullptr;
+    if ((int64_t)M * Cout * 4 > ws_bytes - SPLITK_TICKET_BYTES || tiles > SPLITK_TICKET_BYTES / 4) return nullptr;
+    return reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + ws_bytes - SPLITK_TICKET_BYTES);
+}
+
 template <int BM, int BN, int WM, int WN, int KS, int D>
 static void launch_dma(const bf16_t* xp, const bf16_t* wp, bf16_t* yp, const bf16_t* ap, float* stats,
-                       const sba_conv_geom& g, int M, int nslabs, int split, float* ws, hipStream_t st, const EpiX ex) {
+                       const sba_conv_geom& g, int M, int nslabs, int split, float* ws, int64_t ws_bytes, hipStream_t st,
+                       const EpiX ex) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     int sps = nslabs;
     if (split > 1) {
@@ -2294,9 +2347,10 @@ static void launch_dma(const bf16_t* xp, const bf16_t* wp, bf16_t* yp, const bf1
     }
     const int gx = cdiv(M, BM), gy = cdiv(g.Cout, BN);
     dim3 grid(8 * cdiv(gx, 8) * gy, 1, split);
+    int* tickets = splitk_tickets(ws, ws_bytes, M, g.Cout, (int)grid.x);
     SBA_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, KS, D>), grid, dim3(NT), 0, st, xp, wp, yp, ap, stats, g, M,
-               split > 1 ? ws : (float*)nullptr, sps, ex, gx, gy DMA_TRACE_ARG);
-    if (split > 1) {
+               split > 1 ? ws : (float*)nullptr, split > 1 ? tickets : (int*)nullptr, sps, ex, gx, gy DMA_TRACE_ARG);
+    if (split > 1 && !tickets) {
         dim3 fgrid(cdiv(g.Cout / 4, 256), cdiv(M, 8));
         SBA_LAUNCH((splitk_finish_kernel<bf16_t>), fgrid, dim3(256), 0, st, ws, yp, ap, stats, g, M, ex);
     }
@@ -2304,7 +2358,8 @@ static void launch_dma(const bf16_t* xp, const bf16_t* wp, bf16_t* yp, const bf1
 
 template <int BM, int BN, int WM, int WN, int D>
 static void launch_dma2(const bf16_t* xp, const bf16_t* wp, bf16_t* yp, const bf16_t* ap, float* stats,
-                        const sba_conv_geom& g, int M, int nslabs64, int split, float* ws, hipStream_t st, const EpiX ex) {
+                        const sba_conv_geom& g, int M, int nslabs64, int split, float* ws, int64_t ws_bytes, hipStream_t st,
+                        const EpiX ex) {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
     int sps = nslabs64;
     if (split > 1) {
@@ -2313,9 +2368,10 @@ static void launch_dma2(const bf16_t* xp, const bf16_t* wp, bf16_t* yp, const bf
     }
     const int gx = cdiv(M, BM), gy = cdiv(g.Cout, BN);
     dim3 grid(8 * cdiv(gx, 8) * gy, 1, split);
+    int* tickets = splitk_tickets(ws, ws_bytes, M, g.Cout, (int)grid.x);
     SBA_LAUNCH((igemm_dma2_kernel<BM, BN, WM, WN, D>), grid, dim3(NT), 0, st, xp, wp, yp, ap, stats, g, M,
-               split > 1 ? ws : (float*)nullptr, sps, ex, gx, gy DMA_TRACE_ARG);
-    if (split > 1) {
+               split > 1 ? ws : (float*)nullptr, split > 1 ? tickets : (int*)nullptr, sps, ex, gx, gy DMA_TRACE_ARG);
+    if (split > 1 && !tickets) {
         dim3 fgrid(cdiv(g.Cout / 4, 256), cdiv(M, 8));
         SBA_LAUNCH((splitk_finish_kernel<bf16_t>), fgrid, dim3(256), 0, st, ws, yp, ap, stats, g, M, ex);
     }
@@ -2450,31 +2506,31 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
             int sp = split;
             if (sp > ns64 / 2) sp = ns64 / 2 > 0 ? ns64 / 2 : 1;
             switch (tile) {
-                case 1: launch_dma2<64, 64, 32, 32, 4>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
-                case 2: launch_dma2<64, 64, 32, 32, 8>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
-                case 3: launch_dma2<96, 64, 32, 64, 3>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
-                case 4: launch_dma2<96, 64, 32, 64, 6>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
-                case 5: launch_dma2<128, 64, 32, 64, 3>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
-                case 6: launch_dma2<128, 64, 32, 64, 6>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
-                case 7: launch_dma2<128, 128, 64, 64, 3>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
-                case 8: launch_dma2<128, 128, 64, 64, 4>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
-                case 9: launch_dma2<256, 64, 64, 64, 3>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
-                case 10: launch_dma2<256, 64, 64, 64, 4>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
-                default: launch_dma2<96, 128, 32, 128, 5>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, st, ex); return SBA_CHECK_LAUNCH();
+                case 1: launch_dma2<64, 64, 32, 32, 4>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+                case 2: launch_dma2<64, 64, 32, 32, 8>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+                case 3: launch_dma2<96, 64, 32, 64, 3>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+                case 4: launch_dma2<96, 64, 32, 64, 6>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+                case 5: launch_dma2<128, 64, 32, 64, 3>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+                case 6: launch_dma2<128, 64, 32, 64, 6>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+                case 7: launch_dma2<128, 128, 64, 64, 3>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+                case 8: launch_dma2<128, 128, 64, 64, 4>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+                case 9: launch_dma2<256, 64, 64, 64, 3>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+                case 10: launch_dma2<256, 64, 64, 64, 4>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+                default: launch_dma2<96, 128, 32, 128, 5>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
             }
         }
         switch (tile) {
-            case 1: launch_dma<64, 64, 32, 32, 2, 4>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
-            case 2: launch_dma<64, 64, 32, 32, 2, 8>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
-            case 3: launch_dma<96, 64, 32, 64, 2, 3>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
-            case 4: launch_dma<96, 64, 32, 64, 2, 6>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
-            case 5: launch_dma<128, 64, 32, 64, 1, 4>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
-            case 6: launch_dma<128, 64, 32, 64, 2, 6>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
-            case 7: launch_dma<128, 128, 64, 64, 1, 4>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
-            case 8: launch_dma<128, 128, 64, 64, 1, 8>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
-            case 9: launch_dma<256, 64, 64, 64, 1, 3>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
-            case 10: launch_dma<256, 64, 64, 64, 1, 6>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
-            case 12: launch_dma<96, 128, 32, 128, 1, 8>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, st, ex); return SBA_CHECK_LAUNCH();
+            case 1: launch_dma<64, 64, 32, 32, 2, 4>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+            case 2: launch_dma<64, 64, 32, 32, 2, 8>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+            case 3: launch_dma<96, 64, 32, 64, 2, 3>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+            case 4: launch_dma<96, 64, 32, 64, 2, 6>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+            case 5: launch_dma<128, 64, 32, 64, 1, 4>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+            case 6: launch_dma<128, 64, 32, 64, 2, 6>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+            case 7: launch_dma<128, 128, 64, 64, 1, 4>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+            case 8: launch_dma<128, 128, 64, 64, 1, 8>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+            case 9: launch_dma<256, 64, 64, 64, 1, 3>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+            case 10: launch_dma<256, 64, 64, 64, 1, 6>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+            case 12: launch_dma<96, 128, 32, 128, 1, 8>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
             default: best = 4; best_split = split; break;      // 11: the register-staged 320x128 tile below
         }
     }
