@@ -2679,11 +2679,17 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
                                                dow));
         return SBA_CHECK_LAUNCH();
     }
-    // generator-style 3x3 stride-1 conv on a wide map: all nine taps per workgroup from halo tiles
+    // generator-style 3x3 stride-1 conv on a wide map: all nine taps per workgroup from halo tiles.  From 128x128 maps
+    // up (B = 20: M >= 327 k) it beats the LDS-DMA decomposition below (upBlock -> 256 px 189 vs 349 us); at 64x64
+    // (M = 82 k) the DMA kernel wins (ResBlock 51 -> 40 us, 64->128: 69 -> 60), tools/bench_wgrad.py.
+    static int rows_m = -1;
+    if (rows_m < 0) { const char* e = getenv("SBA_WGRAD_ROWS_M"); rows_m = e ? atoi(e) : 131072; }
     bool rows_ok = g->ntaps == 9 && g->sy == 1 && g->sx == 1 && g->osy == 1 && g->osx == 1 && g->ooy == 0 &&
-                   g->oox == 0 && g->OHs == g->OH && g->OWs == g->OW && g->OW % 64 == 0 && M >= 32768;
+                   g->oox == 0 && g->OHs == g->OH && g->OWs == g->OW && g->OW % 64 == 0 && M >= rows_m;
     for (int t = 0; t < 9 && rows_ok; ++t) rows_ok = g->ty[t] == t / 3 - 1 && g->tx[t] == t % 3 - 1;
-    if (rows_ok) {
+    static int rows_en = -1;        // SBA_WGRAD_ROWS=0: skip the all-taps halo-row kernel (A/B aid)
+    if (rows_en < 0) { const char* e = getenv("SBA_WGRAD_ROWS"); rows_en = (e && e[0] == '0') ? 0 : 1; }
+    if (rows_ok && rows_en) {
         const int total_segs = g->N * g->OH * (g->OW / 64);
         const int ci_t = cdiv(g->Cin, 64);
         // every pixel split adds a full copy of the tile's 9 x 64 x 64 outputs to the f32 atomics
@@ -2698,6 +2704,46 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
         SBA_DISPATCH(dtype, SBA_LAUNCH((wgrad_rows_kernel<T>), grid, dim3(192), 0, (hipStream_t)stream,
                                                (const T*)x, (const T*)dy, dw, *g, total_segs, spw));
         return SBA_CHECK_LAUNCH();
+    }
+    {
+        // Big-M layers that are not 3x3 / OW % 64 == 0 (the discriminators' 4x4/s2 down blocks at 32..128 px): the
+        // register-staged kernel below shares nothing between its waves (1 KB of operands per MFMA from L2 = the
+        // 300 TFLOP/s on-chip-bandwidth roofline of a 64x64 tile); the small-pixel-count decomposition shares the dy
+        // slices between the four (tap, ci tile) items of a workgroup (0.625 KB, CT = 2: 0.375 KB per MFMA) and walks
+        // its pixel split through the LDS-DMA ring.  Measured (tools/bench_wgrad.py, B = 20): D256 down 64->128 @128 px
+        // 200 -> 110 us, 128->256 @64 193 -> 107, D128 down @64 99 -> 48, D64 down @32 43 -> 24; CT = 2 is no better.
+        // SBA_WGRAD_GEN_DMA: 0 = off, 1 = CT 1 (default), 2 = CT 2 where Cout % 128 == 0.
+        static int gen = -1, gen_wgs = -1;
+        if (gen < 0) { const char* e = getenv("SBA_WGRAD_GEN_DMA"); gen = e ? atoi(e) : 1; }
+        if (gen_wgs < 0) { const char* e = getenv("SBA_WGRAD_GEN_WGS"); gen_wgs = e ? atoi(e) : 512; }
+        const int64_t xb = (int64_t)g->N * g->IH * g->IW * g->Cin * 2, db = (int64_t)g->N * g->OH * g->OW * g->Cout * 2;
+        if (gen > 0 && dtype == SBA_BF16 && xb < (1ll << 32) && db < (1ll << 32)) {
+            const bool ct2 = gen >= 2 && g->Cout % 128 == 0;
+            const int cot = ct2 ? co_tiles / 2 : co_tiles;
+            const int wgs = cot * cdiv(items, 4);
+            const int tc32 = cdiv(M, 32);
+            int sp = cdiv(gen_wgs, wgs);
+            if (sp > tc32 / 12) sp = tc32 / 12 > 0 ? tc32 / 12 : 1;
+            const int cps32 = cdiv(tc32, sp);
+            sp = cdiv(tc32, cps32);
+            dim3 gd(cot, cdiv(items, 4), sp);
+            if (gd.y <= 65535 && gd.z <= 65535) {
+                if (ct2) {
+                    constexpr int LDS = 3 * 6 * 32 * 128;
+                    static bool once = false;
+                    if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_small_dma_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
+                    SBA_LAUNCH((wgrad_small_dma_kernel<2, 3>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
+                               (const bf16_t*)dy, dw, *g, M, cps32, sp > 1 ? 1 : 0, dsub, dow);
+                } else {
+                    constexpr int LDS = 4 * 5 * 32 * 128;
+                    static bool once = false;
+                    if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_small_dma_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
+                    SBA_LAUNCH((wgrad_small_dma_kernel<1, 4>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
+                               (const bf16_t*)dy, dw, *g, M, cps32, sp > 1 ? 1 : 0, dsub, dow);
+                }
+                return SBA_CHECK_LAUNCH();
+            }
+        }
     }
     const int total_chunks = cdiv(M, 64);
     if (ksplit > total_chunks) ksplit = total_chunks;

@@ -533,7 +533,15 @@ def test_graph_replay_equals_eager_step_from_same_state(dev, encoder, dt):
     e1 = es[0]
     g1, g2 = run(replay), run(replay)
     n1, n2 = run(replay_native), run(replay_native)
-    floor = {'loss': 1e-5, 'grad': 1e-3, 'buf': 1e-5, 'fake': 1e-5}
+    # floors: four eager runs can happen to be nearly deterministic (same launch timing, same atomic order) where a
+    # replay, whose kernels overlap differently, is not -- e.g. the 64-way pixel-split weight gradient of D_NET64's
+    # down blocks: g_loss0 moved 4.8e-4 in a replay against 4e-5 among the eager runs.  In bf16 a floor below the
+    # storage resolution (2^-9 = 2e-3 per activation) is not a statement about the replay; the f32 parametrisation of
+    # this test is the one that pins replay defects (1e-4 absolute below).
+    if dt == torch.float32:
+        floor = {'loss': 1e-5, 'grad': 1e-3, 'buf': 1e-5, 'fake': 1e-5}
+    else:
+        floor = {'loss': 1e-3, 'grad': 1e-2, 'buf': 1e-4, 'fake': 1e-3}
     worst = {}
     for k in e1:
         noise_k = max(rel_l2(es[i][k], es[j][k]) for i in range(4) for j in range(i))

@@ -24,6 +24,17 @@ SHAPES = [
     ('3x3up', 20, 256, 256, 16, 16, 'G upsample3'),
     ('3x3up', 20, 128, 128, 32, 32, 'G upsample4'),
     ('4x4s2', 40, 128, 256, 16, 16, 'D s16 third down block'),
+    ('4x4s2', 40, 64, 128, 128, 128, 'D256 down 64->128 @128'),
+    ('4x4s2', 40, 128, 256, 64, 64, 'D256 down 128->256 @64'),
+    ('4x4s2', 40, 256, 512, 32, 32, 'D256 down 256->512 @32'),
+    ('4x4s2', 40, 64, 128, 64, 64, 'D128 down 64->128 @64'),
+    ('4x4s2', 40, 64, 128, 32, 32, 'D64 down 64->128 @32'),
+    ('3x3', 20, 64, 64, 64, 64, 'G ResBlock 64x64'),
+    ('3x3', 20, 64, 128, 128, 128, 'G ResBlock 128x128 conv1 (64->128)'),
+    ('3x3', 20, 64, 64, 128, 128, 'G ResBlock 128x128 conv2 (64->64)'),
+    ('3x3up', 20, 64, 64, 128, 128, 'G upBlock -> 256x256 (64->64)'),
+    ('3x3up', 20, 64, 128, 64, 64, 'G upBlock -> 128x128 (64->128)'),
+    ('3x3', 20, 64, 128, 64, 64, 'G ResBlock 64x64 conv1 (64->128)'),
 ]
 
 
@@ -31,7 +42,7 @@ def main():
     from sbagan import ops
     dev = torch.device('cuda:0')
     ops.set_compute_dtype(torch.bfloat16)
-    print('SBA_WGRAD_DMA=%s' % os.environ.get('SBA_WGRAD_DMA', '(default)'))
+    print('SBA_WGRAD_DMA=%s SBA_WGRAD_GEN_DMA=%s' % (os.environ.get('SBA_WGRAD_DMA', '(default)'), os.environ.get('SBA_WGRAD_GEN_DMA', '(default)')))
     for kind, N, Cin, Cout, H, W, name in SHAPES:
         k = 4 if kind == '4x4s2' else 3
         w = torch.nn.Parameter(torch.randn(Cout, Cin, k, k, device=dev).contiguous(memory_format=torch.channels_last))
