@@ -65,6 +65,11 @@ typedef struct sba_conv_geom {
      * (measured per layer shape by tools/tune_igemm.py into sbagan/igemm_table.json; bf16 only, an id the
      * geometry cannot use falls back to the rules).  ksplit: 0 = the library decides, n >= 1 = split K n ways. */
     int32_t tile, ksplit;
+    /* sba_conv_wgrad only: non-zero = the caller knows dw is all zeros (just cleared, nothing accumulated yet):
+     * kernel paths whose workgroups own their outputs exclusively then STORE instead of read-modify-write (the
+     * GEMM-like layers' weight gradients are bound by that traffic: 268 MB for D_NET256's widest layer).  Paths
+     * that add with atomics ignore it.  0 = always accumulate. */
+    int32_t first_write;
 } sba_conv_geom;
 #define SBA_IGEMM_TILES 12
 

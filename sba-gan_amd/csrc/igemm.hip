@@ -1710,7 +1710,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_small_kernel(const T* __restrict
                     const int ci = ci0 + j * 32 + col_l;
                     if (co < g.Cout && ci < g.Cin) {
                         float* p = dw + ((int64_t)co * g.ntaps + tap) * g.Cin + ci;
-                        if (use_atomic) atomicAdd(p, acc[s][i][j][r]);
+                        if (use_atomic == 1) atomicAdd(p, acc[s][i][j][r]);
+                        else if (use_atomic == 2) *p = acc[s][i][j][r];       // first write of a cleared gradient
                         else *p += acc[s][i][j][r];
                     }
                 }
@@ -1882,7 +1883,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_small_dma_kernel(const bf16_t* _
                     const int ci = ci0 + j * 32 + col_l;
                     if (co < g.Cout && ci < g.Cin) {
                         float* p = dw + ((int64_t)co * g.ntaps + tap) * g.Cin + ci;
-                        if (use_atomic) atomicAdd(p, acc[s][i][j][r]);
+                        if (use_atomic == 1) atomicAdd(p, acc[s][i][j][r]);
+                        else if (use_atomic == 2) *p = acc[s][i][j][r];       // first write of a cleared gradient
                         else *p += acc[s][i][j][r];
                     }
                 }
@@ -2598,6 +2600,7 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
     if (g->x_cstride || g->x_coff || g->y_cstride || g->y_coff || g->ntaps > 16) return SBA_E_ARG;
     const int M = g->N * g->OHs * g->OWs;
     if (ksplit < 1) ksplit = 1;
+    const int fw = g->first_write ? 2 : 0;       // epilogue mode of the exclusive-owner kernels: 0 = +=, 1 = atomic, 2 = store
     const int co_tiles = cdiv(g->Cout, 64), items = cdiv(g->Cin, 64) * g->ntaps;
     const FastDiv dsub = make_fastdiv((uint32_t)(g->OHs * g->OWs), (int64_t)M + 64);
     const FastDiv dow = make_fastdiv((uint32_t)g->OWs, (int64_t)M + 64);
@@ -2625,7 +2628,7 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
         if (ct2 > 0 && split == 1 && g->Cout % 128 == 0 && (co_tiles / 2) * (int)grid.y >= ct2) {
             grid.x = co_tiles / 2;
             SBA_DISPATCH(dtype, SBA_LAUNCH((wgrad_small_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream,
-                                                   (const T*)x, (const T*)dy, dw, *g, M, cps, 0, dsub, dow));
+                                                   (const T*)x, (const T*)dy, dw, *g, M, cps, fw, dsub, dow));
             return SBA_CHECK_LAUNCH();
         }
         static int dma = -1;        // SBA_WGRAD_DMA: 0 = register-staged kernel; D = ring depth of the LDS-DMA kernel
@@ -2646,7 +2649,7 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
             static bool once = false;
             if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_small_dma_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
             SBA_LAUNCH((wgrad_small_dma_kernel<2, 3>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
-                       (const bf16_t*)dy, dw, *g, M, tc32, 0, dsub, dow);
+                       (const bf16_t*)dy, dw, *g, M, tc32, fw, dsub, dow);
             return SBA_CHECK_LAUNCH();
         }
         if (dma > 0 && wgs <= dma_wgs && dtype == SBA_BF16 && xb < (1ll << 32) && db < (1ll << 32)) {
@@ -2664,18 +2667,18 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
                 static bool once = false;
                 if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_small_dma_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
                 SBA_LAUNCH((wgrad_small_dma_kernel<1, 3>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
-                           (const bf16_t*)dy, dw, *g, M, cps32, sp > 1 ? 1 : 0, dsub, dow);
+                           (const bf16_t*)dy, dw, *g, M, cps32, sp > 1 ? 1 : fw, dsub, dow);
             } else {
                 constexpr int LDS = 4 * 5 * 32 * 128;
                 static bool once = false;
                 if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_small_dma_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
                 SBA_LAUNCH((wgrad_small_dma_kernel<1, 4>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
-                           (const bf16_t*)dy, dw, *g, M, cps32, sp > 1 ? 1 : 0, dsub, dow);
+                           (const bf16_t*)dy, dw, *g, M, cps32, sp > 1 ? 1 : fw, dsub, dow);
             }
             return SBA_CHECK_LAUNCH();
         }
         SBA_DISPATCH(dtype, SBA_LAUNCH((wgrad_small_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream,
-                                               (const T*)x, (const T*)dy, dw, *g, M, cps, split > 1 ? 1 : 0, dsub,
+                                               (const T*)x, (const T*)dy, dw, *g, M, cps, split > 1 ? 1 : fw, dsub,
                                                dow));
         return SBA_CHECK_LAUNCH();
     }
@@ -2733,13 +2736,13 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
                     static bool once = false;
                     if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_small_dma_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
                     SBA_LAUNCH((wgrad_small_dma_kernel<2, 3>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
-                               (const bf16_t*)dy, dw, *g, M, cps32, sp > 1 ? 1 : 0, dsub, dow);
+                               (const bf16_t*)dy, dw, *g, M, cps32, sp > 1 ? 1 : fw, dsub, dow);
                 } else {
                     constexpr int LDS = 4 * 5 * 32 * 128;
                     static bool once = false;
                     if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_small_dma_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
                     SBA_LAUNCH((wgrad_small_dma_kernel<1, 4>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
-                               (const bf16_t*)dy, dw, *g, M, cps32, sp > 1 ? 1 : 0, dsub, dow);
+                               (const bf16_t*)dy, dw, *g, M, cps32, sp > 1 ? 1 : fw, dsub, dow);
                 }
                 return SBA_CHECK_LAUNCH();
             }

@@ -30,7 +30,7 @@ class ConvGeom(Structure):
                 ('ups', c_int32), ('ntaps', c_int32),
                 ('ty', c_int8 * MAX_TAPS), ('tx', c_int8 * MAX_TAPS),
                 ('x_cstride', c_int32), ('x_coff', c_int32), ('y_cstride', c_int32), ('y_coff', c_int32),
-                ('relu', c_int32), ('tile', c_int32), ('ksplit', c_int32)]
+                ('relu', c_int32), ('tile', c_int32), ('ksplit', c_int32), ('first_write', c_int32)]
 
 
 if not os.path.exists(LIB_PATH):

@@ -438,6 +438,9 @@ def _ksplit(tiles, M):
     return max(1, min(want, chunks // _KSPLIT_MIN_CHUNKS if chunks >= 2 * _KSPLIT_MIN_CHUNKS else 1))
 
 
+FIRST_WRITE = os.environ.get('SBA_WGRAD_FIRST_WRITE', '1') != '0'
+
+
 def conv_wgrad(x, dy, param, kind):
     """param.grad[O][KH][KW][I] += dy^T (*) x."""
     N, Cin, H, W = x.shape
@@ -446,6 +449,15 @@ def conv_wgrad(x, dy, param, kind):
     gbuf = param_grad(param)
     M = N * g.OHs * g.OWs
     tiles = ((O + 63) // 64) * ((Cin + 63) // 64) * g.ntaps
+    # first weight gradient of this parameter since its flat gradient buffer was cleared (trainer.FlatParams.zero_grad
+    # bumps the cell): the kernel may store instead of read-modify-write.  Parameters outside a FlatParams never
+    # qualify (somebody else owns their .grad).
+    cell = getattr(param, '_sba_gepoch', None)
+    first = 0
+    if FIRST_WRITE and cell is not None and getattr(param, '_sba_wepoch', None) != cell[0]:
+        param._sba_wepoch = cell[0]
+        first = 1
+    g.first_write = first
     call('sba_conv_wgrad', _dt(x), _p(x), _p(dy), _p(gbuf), ctypes.byref(g), _ksplit(tiles, M), _stream())
 
 

@@ -53,12 +53,16 @@ class FlatParams(object):
         self.avg = self.data.clone() if with_ema else None
         self.epoch = [0]
         ops.register_epoch(params, self.epoch)
+        self.gepoch = [1]                      # bumped by zero_grad: ops.conv_wgrad's first-write bookkeeping
+        for p in params:
+            p._sba_gepoch = self.gepoch
         ops.weights_changed()
         from . import nets
         self.packs = nets.pack_group(net)      # all packed conv weights of the network: one launch per step
 
     def zero_grad(self):
         self.grad.zero_()
+        self.gepoch[0] += 1
 
     def ema_params(self):
         """EMA shadow as a list of tensors shaped like the parameters (copy_G_params order)."""

@@ -127,6 +127,21 @@ def test_conv_fwd_dgrad_wgrad(dev, dt, case):
     ops.conv_wgrad(xa, dya, wp, kind)        # accumulates: twice -> 2x
     torch.cuda.synchronize()
     close(wp.grad * 0.5, gw, dt, 'dw')
+    # a parameter whose cleared gradient buffer is tracked (trainer.FlatParams): the first launch may STORE
+    # (sba_conv_geom.first_write), the second accumulates; a clear + epoch bump re-arms the store
+    wq = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
+    wq.grad = torch.zeros_like(wq)
+    wq._sba_gepoch = [1]
+    ops.conv_wgrad(xa, dya, wq, kind)
+    assert wq._sba_wepoch == 1
+    ops.conv_wgrad(xa, dya, wq, kind)
+    torch.cuda.synchronize()
+    close(wq.grad * 0.5, gw, dt, 'dw (first write + accumulate)')
+    wq.grad.zero_()
+    wq._sba_gepoch[0] += 1
+    ops.conv_wgrad(xa, dya, wq, kind)
+    torch.cuda.synchronize()
+    close(wq.grad, gw, dt, 'dw (first write after a clear)')
 
 
 @pytest.mark.parametrize('dt', DTYPES)
