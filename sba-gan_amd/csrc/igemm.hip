@@ -2639,10 +2639,14 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
         // the L2 traffic of the operand slices either way and the 80 KB ring costs occupancy (s64 145 -> 175 us)
         static int dma_wgs = -1;
         if (dma_wgs < 0) { const char* e = getenv("SBA_WGRAD_DMA_WGS"); dma_wgs = e ? atoi(e) : 512; }
-        static int dma_ct2 = -1;    // SBA_WGRAD_DMA_CT2=1: beyond dma_wgs use the DMA kernel with TWO co tiles per wave
-        if (dma_ct2 < 0) { const char* e = getenv("SBA_WGRAD_DMA_CT2"); dma_ct2 = e ? atoi(e) : 0; }
-        if (dma > 0 && dma_ct2 > 0 && wgs > dma_wgs && g->Cout % 128 == 0 && dtype == SBA_BF16 && xb < (1ll << 32) &&
-            db < (1ll << 32)) {
+        // beyond dma_wgs: the DMA kernel with TWO co tiles per wave (0.375 KB of operands per MFMA) -- pays once the
+        // epilogue is a plain store (first write: D256 s64 119 -> 95 us, s64_1 89 -> 79, G upsample1 84 -> 72); with the
+        // read-modify-write epilogue it is no faster than the register-staged kernel (148 vs 146 us).
+        // SBA_WGRAD_DMA_CT2: 1 = always, 0 = never, unset = on first writes.
+        static int dma_ct2 = -2;
+        if (dma_ct2 == -2) { const char* e = getenv("SBA_WGRAD_DMA_CT2"); dma_ct2 = e ? atoi(e) : -1; }
+        if (dma > 0 && (dma_ct2 > 0 || (dma_ct2 < 0 && fw == 2)) && wgs > dma_wgs && g->Cout % 128 == 0 &&
+            dtype == SBA_BF16 && xb < (1ll << 32) && db < (1ll << 32)) {
             const int tc32 = cdiv(M, 32);
             dim3 gd(co_tiles / 2, cdiv(items, 4), 1);
             constexpr int LDS = 3 * 6 * 32 * 128;

@@ -307,8 +307,11 @@ def _golden_case(dev, dt, case, launch, golden_dir):
                     # ... and in this fixture the updated discriminators reject the fakes with g_loss ~ 31 > -log(1e-12):
                     # BCELoss is in its clamped regime, where the gradient is proportional to p = exp(logit)
                     # (losses.py:175-182 on sigmoid outputs), so a bf16 logit error of 0.25 at |logit| ~ 30 moves
-                    # the generator gradient by 28 % (measured: 4e-2 ... 2.9e-1 from run to run)
-                    tolk = 0.5
+                    # the generator gradient by 28 %.  Measured spread of this deviation over 14 identical runs
+                    # (tools/golden_spread.py bert_b4 bfloat16 eager 14, profiles/r02_golden_spread.txt): 8.6e-3 ...
+                    # 0.497, median 0.16 (model_b4: <= 4.6e-2) -- chaotic, so bf16 only asserts the order of magnitude
+                    # here; the f32 run of the same case holds it to 8e-2 and every other bf16 quantity has >= 2x margin
+                    tolk = 1.0
             assert rel <= tolk, (case, launch, step, k, vals[k], ref, rel)
         for i, f in enumerate(st.fake_imgs):
             if f32 and step == 0:
