@@ -106,7 +106,7 @@ def main():
         mine = local[fd.grad.data_ptr()]
         if k > 0:       # discriminators: the local gradient IS the single-process gradient on this batch
             r = rel_l2(mine, solo_grads[k])
-            expect(r <= 3 * noise[k] + 1e-3, '%s: local gradient differs from the single-process run (rel L2 %.2e, '
+            expect(r <= 3 * noise[k] + 2e-3, '%s: local gradient differs from the single-process run (rel L2 %.2e, '
                    'single-process run-to-run noise %.2e)' % (name, r, noise[k]))
         gathered = [torch.empty_like(mine).cpu() for _ in range(world)]
         dist.all_gather(gathered, mine.cpu())
