@@ -1138,48 +1138,56 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const bf16_t* __restr
     constexpr uint32_t OOB = 0xFFFFFFFFu;
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
     const uint32_t x_bytes = (uint32_t)((int64_t)g.N * g.IH * g.IW * xcs * 2);
-    const uint32_t w_bytes = (uint32_t)((int64_t)g.Cout * 9 * CIN * 2);
+    const uint32_t w_bytes = (uint32_t)((int64_t)g.Cout * 9 * g.Cin * 2);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, w_bytes, 0x00020000);
+    // Cin = nchunks x CIN: the halo tile is staged and walked once per CIN-channel chunk (same LDS footprint and
+    // occupancy as Cin = CIN); the weight taps stream through the two B buffers across the chunk boundary
+    const int nchunks = g.Cin / CIN, ntaps_all = 9 * nchunks;
 
     // ---- halo tile: source rows sy0 .. sy0+HR-1, columns sx0 .. sx0+HC-1 (zeros outside the image)
     const int sy0 = UPS ? (oy0 >> 1) - 1 : oy0 - 1, sx0 = UPS ? (ox0 >> 1) - 1 : ox0 - 1;
     // (loads are issued in batches of HB before the first LDS write: a load -> wait -> ds_write loop pays the
     // global latency once per iteration, 4 (upsampling) to 11 times per workgroup)
     constexpr int NCH = HR * HC * CPP, NI = (NCH + 255) / 256, HB = 6;
+    auto stage_halo = [&](const int chunk) {
+        const uint32_t cbytes = (uint32_t)(g.x_coff * 2 + chunk * CIN * 2);
 #pragma unroll
-    for (int i0 = 0; i0 < NI; i0 += HB) {
-        u32x4_t hv[HB];
+        for (int i0 = 0; i0 < NI; i0 += HB) {
+            u32x4_t hv[HB];
 #pragma unroll
-        for (int u = 0; u < HB; ++u) {
-            const int idx = tid + 256 * (i0 + u);
-            const int p = idx / CPP, ch = idx - p * CPP;
-            const int hr = p / HC, hc = p - hr * HC;
-            const int iy = sy0 + hr, ix = sx0 + hc;
-            const bool ok = i0 + u < NI && idx < NCH && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
-            const uint32_t o = ok ? (uint32_t)((n * g.IH + iy) * g.IW + ix) * (uint32_t)(xcs * 2) +
-                                        (uint32_t)(g.x_coff * 2) + (uint32_t)ch * 16u
-                                  : OOB;
-            hv[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, o, 0, 0);
+            for (int u = 0; u < HB; ++u) {
+                const int idx = tid + 256 * (i0 + u);
+                const int p = idx / CPP, ch = idx - p * CPP;
+                const int hr = p / HC, hc = p - hr * HC;
+                const int iy = sy0 + hr, ix = sx0 + hc;
+                const bool ok = i0 + u < NI && idx < NCH && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+                const uint32_t o = ok ? (uint32_t)((n * g.IH + iy) * g.IW + ix) * (uint32_t)(xcs * 2) + cbytes +
+                                            (uint32_t)ch * 16u
+                                      : OOB;
+                hv[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, o, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < HB; ++u) {
+                const int idx = tid + 256 * (i0 + u);
+                const int p = idx / CPP, ch = idx - p * CPP;
+                if (i0 + u < NI && idx < NCH)
+                    *reinterpret_cast<uint4*>(lA + p * PIXB + ch * 16) = make_uint4(hv[u][0], hv[u][1], hv[u][2], hv[u][3]);
+            }
         }
-#pragma unroll
-        for (int u = 0; u < HB; ++u) {
-            const int idx = tid + 256 * (i0 + u);
-            const int p = idx / CPP, ch = idx - p * CPP;
-            if (i0 + u < NI && idx < NCH)
-                *reinterpret_cast<uint4*>(lA + p * PIXB + ch * 16) = make_uint4(hv[u][0], hv[u][1], hv[u][2], hv[u][3]);
-        }
-    }
-    // ---- weights of one tap: BN rows of CIN channels
+    };
+    // ---- weights of one (chunk, tap): BN rows of CIN channels; t = chunk * 9 + tap
     uint4 rb[BI];
-    auto bload = [&](int tap) {
+    auto bload = [&](const int t) {
+        const int chunk = t / 9, tap = t - chunk * 9;
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
             const int idx = tid + 256 * i;
             const int row = idx / CPP, ch = idx - row * CPP;
             const int co = n_base + row;
             const uint32_t o = (row < BN && co < g.Cout)
-                                   ? ((uint32_t)co * 9u + (uint32_t)tap) * (uint32_t)(CIN * 2) + (uint32_t)ch * 16u
+                                   ? (((uint32_t)co * 9u + (uint32_t)tap) * (uint32_t)g.Cin + (uint32_t)(chunk * CIN)) * 2u +
+                                         (uint32_t)ch * 16u
                                    : OOB;
             const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wr, o, 0, 0);
             rb[i] = make_uint4(v[0], v[1], v[2], v[3]);
@@ -1203,42 +1211,47 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const bf16_t* __restr
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    __syncthreads();
 
     const int rl = lane & 31, hf = lane >> 5;
 #pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-        if (tap + 1 < 9) bload(tap + 1);
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const unsigned char* ap[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            int hr, hc;
-            if (UPS) {
-                hr = ((2 * wid + i + ky - 1) >> 1) + 1;
-                hc = ((rl + kx - 1) >> 1) + 1;
-            } else {
-                hr = 2 * wid + i + ky;
-                hc = rl + kx;
-            }
-            ap[i] = lA + (hr * HC + hc) * PIXB + hf * 16;
-        }
-        const unsigned char* bp = lB + (tap & 1) * B_BYTES + rl * PIXB + hf * 16;
-#pragma unroll
-        for (int k16 = 0; k16 < CIN / 16; ++k16) {
-            bf16x8_t a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(ap[i] + k16 * 32);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(bp + j * 32 * PIXB + k16 * 32);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (tap + 1 < 9) bstore((tap + 1) & 1);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        stage_halo(chunk);          // (chunk > 0: the barrier that ended the previous chunk's last tap freed lA)
         __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int t = chunk * 9 + tap;
+            if (t + 1 < ntaps_all) bload(t + 1);
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const unsigned char* ap[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                int hr, hc;
+                if (UPS) {
+                    hr = ((2 * wid + i + ky - 1) >> 1) + 1;
+                    hc = ((rl + kx - 1) >> 1) + 1;
+                } else {
+                    hr = 2 * wid + i + ky;
+                    hc = rl + kx;
+                }
+                ap[i] = lA + (hr * HC + hc) * PIXB + hf * 16;
+            }
+            const unsigned char* bp = lB + (t & 1) * B_BYTES + rl * PIXB + hf * 16;
+#pragma unroll
+            for (int k16 = 0; k16 < CIN / 16; ++k16) {
+                bf16x8_t a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(ap[i] + k16 * 32);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(bp + j * 32 * PIXB + k16 * 32);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (t + 1 < ntaps_all) bstore((t + 1) & 1);
+            __syncthreads();
+        }
     }
     tile_epilogue<T, BM, BN, TM, TN, 256, STAGE>(acc, true, lds, rowoff, s_stat, wid * 64, 0, lane, n_base, ycs, g, y,
                                                  addend, stats, ex);
@@ -2401,7 +2414,11 @@ static bool halo_ok(const sba_conv_geom& g) {
     if (enabled < 0) { const char* e = getenv("SBA_CONV_HALO"); enabled = (e && e[0] == '0') ? 0 : 1; }
     if (!enabled) return false;
     if (g.ntaps != 9 || g.sy != 1 || g.sx != 1 || g.osy != 1 || g.osx != 1 || g.ooy || g.oox) return false;
-    if (g.OHs != g.OH || g.OWs != g.OW || g.Cin != 64 || g.Cout % 64) return false;
+    // Cin = 128 (data gradient of the ResBlocks' 64 -> 128 conv): the kernel walks the tile once per 64-channel chunk
+    static int halo128 = -1;
+    if (halo128 < 0) { const char* e = getenv("SBA_CONV_HALO128"); halo128 = (e && e[0] == '0') ? 0 : 1; }
+    const bool cin_ok = g.Cin == 64 || (g.Cin == 128 && halo128);
+    if (g.OHs != g.OH || g.OWs != g.OW || !cin_ok || g.Cout % 64) return false;
     if (g.OH % 8 || g.OW % 32) return false;
     if (g.ups ? (g.IH * 2 != g.OH || g.IW * 2 != g.OW) : (g.IH != g.OH || g.IW != g.OW)) return false;
     for (int t = 0; t < 9; ++t)
@@ -2419,7 +2436,7 @@ static void launch_halo(const sba_conv_geom& g, const bf16_t* x, const bf16_t* w
     static int v2 = -1;
     if (v2 < 0) { const char* e = getenv("SBA_CONV_HALO2"); v2 = (e && e[0] == '1') ? 1 : 0; }
     const int nblocks = g.Cout / 64;
-    if (v2 && tiles >= 512) {
+    if (v2 && tiles >= 512 && g.Cin == 64) {
         // persistent workgroups, one per CU, split evenly over the 64-channel blocks of Cout
         int per = 256 / nblocks;
         if (per > tiles) per = tiles;

@@ -82,6 +82,8 @@ CONV_CASES = [
     ('3x3', 8, 64, 64, 128, 128),     # 512 tiles: persistent halo-tile kernel (conv3x3_halo2_kernel), 2 tiles per workgroup
     ('3x3', 5, 64, 128, 128, 128),    # ... two 64-channel blocks of Cout, 320 tiles per block: uneven tile counts
     ('3x3up', 9, 64, 64, 64, 64),     # ... behind the nearest x2 upsample (576 tiles, 3 per workgroup for some)
+    ('3x3up', 2, 128, 128, 64, 64),   # halo-tile kernel walking TWO 64-channel chunks of Cin = 128, behind the nearest x2 upsample
+    ('3x3', 8, 128, 64, 64, 64),      # ... plain 3x3 (the shape of the data gradient of the ResBlocks' 64 -> 128 conv)
     ('3x3', 20, 768, 512, 4, 4),      # D_GET_LOGITS.jointConv at B = 20 (M = 320): LDS-DMA small-pixel-count wgrad, 10 stages
     ('3x3', 3, 224, 544, 4, 4),       # ... ragged: last ci / co tiles 32 channels wide, M = 48 (half-empty second stage)
     ('3x3', 16, 256, 512, 8, 8),      # ... M = 1024: two pixel splits, f32 atomics
