@@ -87,6 +87,7 @@ CONV_CASES = [
     ('3x3', 20, 768, 512, 4, 4),      # D_GET_LOGITS.jointConv at B = 20 (M = 320): LDS-DMA small-pixel-count wgrad, 10 stages
     ('3x3', 3, 224, 544, 4, 4),       # ... ragged: last ci / co tiles 32 channels wide, M = 48 (half-empty second stage)
     ('3x3', 16, 256, 512, 8, 8),      # ... M = 1024: two pixel splits, f32 atomics
+    ('3x3', 2, 1024, 1024, 4, 4),     # ... 576 workgroups: register-staged kernel when accumulating, two co tiles per wave (CT = 2) on a first write
 ]
 
 
