@@ -106,7 +106,12 @@ def main():
         mine = local[fd.grad.data_ptr()]
         if k > 0:       # discriminators: the local gradient IS the single-process gradient on this batch
             r = rel_l2(mine, solo_grads[k])
-            expect(r <= 3 * noise[k] + 2e-3, '%s: local gradient differs from the single-process run (rel L2 %.2e, '
+            # floor: the run-to-run difference of a discriminator's gradient on this fixture is bimodal -- ~1e-6 when
+            # two runs happen to add in the same order, ~2e-3 when an atomic-order perturbation moves a saturated logit
+            # across BCELoss's log clamp (the gradient of that sample switches on or off) -- and one pair of solo runs
+            # often shows only the quiet mode.  Anything this test is after (wrong batch, wrong scaling, a missing
+            # exchange) is O(0.1 .. 1).
+            expect(r <= 3 * noise[k] + 1e-2, '%s: local gradient differs from the single-process run (rel L2 %.2e, '
                    'single-process run-to-run noise %.2e)' % (name, r, noise[k]))
         gathered = [torch.empty_like(mine).cpu() for _ in range(world)]
         dist.all_gather(gathered, mine.cpu())
