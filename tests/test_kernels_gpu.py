@@ -554,7 +554,9 @@ def test_generator_loss_vs_oracle(dev):
         'w_loss: %.2f s_loss: %.2f ' % (float(logs_r['w_loss']), float(logs_r['s_loss']))
     assert str(logs) == ref_str and ('x' + logs) == 'x' + ref_str and (logs + '\n') == ref_str + '\n'
     for i in range(3):
-        close(fa[i].grad, fr[i].grad, torch.float32, 'dfake%d' % i, scale=30)
+        # through four train-mode BatchNorms at B = 3: the f32 atomic order of the batch statistics moves this gradient by
+        # up to ~2e-3 from run to run (seen 2.1e-3 once in six runs); a wrong head / tap / scale is >= 1e-1
+        assert rel_l2(fa[i].grad, fr[i].grad) <= 1e-2, ('dfake%d' % i, rel_l2(fa[i].grad, fr[i].grad))
 
 
 def test_bce_kl_adam(dev):
