@@ -190,7 +190,11 @@ def test_fused_heads_equal_the_per_head_functions(dev, b_jcu):
     for term in ('D', 'G'):
         a, b = run(True, term), run(False, term)
         assert set(a) == set(b)
-        bad = [(k, rel_l2(a[k], b[k])) for k in a if rel_l2(a[k], b[k]) > 2e-5]
+        # two separate f32 runs: gradients that pass through the train-mode BatchNorms differ by the atomic order of
+        # the batch statistics (typically 1e-6, rarely up to ~2e-3 at these batch sizes); a head wired to the wrong rows,
+        # a missing accumulation or a wrong BCE weight is O(0.1 .. 1)
+        bad = [(k, rel_l2(a[k], b[k])) for k in a
+               if rel_l2(a[k], b[k]) > (1e-4 if k == 'loss' or k.startswith('b.') else 1e-2)]
         assert not bad, (term, bad)
 
 
