@@ -57,7 +57,10 @@ __global__ __launch_bounds__(256) void img_head_bwd_kernel(const T* __restrict__
                                                            float* __restrict__ dw, int N, int H, int W,
                                                            int accumulate) {
     constexpr int V = Vec16<T>::N;
-    constexpr int HS = (C % 64 == 32) ? C : C + 32, DS = 32;     // row strides = 32 mod 64 floats (half-waves on disjoint banks)
+    // row strides ODD: the per-pixel scalar writes of a wave (lane = pixel, stride = row) then spread over all 64 banks
+    // (strides of 32 floats put the 64 lanes on two banks: 32 + C 32-way conflicting ds_write_b32 per lane), and the
+    // MFMA operand reads (32 consecutive floats of one row per half-wave, rows one apart) overlap on a single bank
+    constexpr int HS = C + 1, DS = 33;
     constexpr int NTL = C / 32;                  // 32-channel tiles of dw
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* s_w = sm;                 // [27][C]
@@ -513,7 +516,7 @@ extern "C" int sba_img_head_bwd(int dtype, const void* h, const float* w, const 
     if (C_ > 64) return SBA_E_ARG;       // LDS budget of the fused wgrad contraction
     const int64_t total = (int64_t)N * H * W;
     SBA_DISPATCH(dtype, CH_SWITCH(C_, {
-        const size_t sh = sizeof(float) * (27 * C + 256 * ((C % 64 == 32) ? C : C + 32) + 256 * 32 + 32 * C);
+        const size_t sh = sizeof(float) * (27 * C + 256 * (C + 1) + 256 * 33 + 32 * C);
         set_lds(img_head_bwd_kernel<T, C>, sh);
         SBA_LAUNCH((img_head_bwd_kernel<T, C>), dim3(cdiv(total, 256)), dim3(256), sh, (hipStream_t)stream,
                            (const T*)h, w, img, dimg, (T*)dh, dw, N, H, W, accumulate);
