@@ -173,6 +173,92 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, i
     }
 }
 
+// forward that also stores the window position (kh * 3 + kw, FIRST maximum in scan order: torch's tie rule) of every
+// output element: the backward then reads <= 4 argmax bytes + 4 dy vectors per input vector instead of re-reading the
+// 9 inputs of each of its <= 4 windows (36 loads) to recompute them
+template <typename T>
+__global__ void maxpool_fwd_arg_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ arg, int N,
+                                       int H, int W, int C, int xcs, int xco, int ycs, int yco) {
+    constexpr int V = Vec16<T>::N;
+    const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1, cv = C / V;
+    const int64_t total = (int64_t)N * OH * OW * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V;
+        const int64_t p = i / cv;
+        const int ox = (int)(p % OW), oy = (int)((p / OW) % OH), n = (int)(p / ((int64_t)OW * OH));
+        float m[V];
+        uint8_t a[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { m[k] = -INFINITY; a[k] = 255; }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                Vec16<T> v = ld16(x + (((int64_t)n * H + 2 * oy + kh) * W + 2 * ox + kw) * xcs + xco + c);
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const float f = v.get(k);
+                    if (f > m[k]) { m[k] = f; a[k] = (uint8_t)(kh * 3 + kw); }
+                }
+            }
+        Vec16<T> o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) o.set(k, m[k]);
+        st16(y + p * ycs + yco + c, o);
+        uint8_t* ap = arg + p * C + c;          // V bytes, V-aligned (C % V == 0)
+        if (V == 8) {
+            uint2 w;
+            w.x = a[0] | (a[1] << 8) | (a[2] << 16) | ((uint32_t)a[3] << 24);
+            w.y = a[4] | (a[5] << 8) | (a[6] << 16) | ((uint32_t)a[7] << 24);
+            *reinterpret_cast<uint2*>(ap) = w;
+        } else {
+            *reinterpret_cast<uint32_t*>(ap) = a[0] | (a[1] << 8) | (a[2] << 16) | ((uint32_t)a[3] << 24);
+        }
+    }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_arg_kernel(const uint8_t* __restrict__ arg, const T* __restrict__ dy, T* __restrict__ dx,
+                                       int N, int H, int W, int C, int dycs, int dyco, int dxcs, int dxco,
+                                       int accumulate) {
+    constexpr int V = Vec16<T>::N;
+    const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1, cv = C / V;
+    const int64_t total = (int64_t)N * H * W * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V;
+        const int64_t p = i / cv;
+        const int ix = (int)(p % W), iy = (int)((p / W) % H), n = (int)(p / ((int64_t)W * H));
+        float g[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) g[k] = 0.f;
+        for (int oy = max(0, (iy - 1) >> 1); oy <= min(OH - 1, iy >> 1); ++oy) {
+            if (iy - 2 * oy > 2) continue;
+            for (int ox = max(0, (ix - 1) >> 1); ox <= min(OW - 1, ix >> 1); ++ox) {
+                if (ix - 2 * ox > 2) continue;
+                const uint32_t mypos = (uint32_t)((iy - 2 * oy) * 3 + (ix - 2 * ox));
+                const int64_t q = ((int64_t)n * OH + oy) * OW + ox;
+                uint32_t aw[2] = {0u, 0u};
+                if (V == 8) {
+                    const uint2 w = *reinterpret_cast<const uint2*>(arg + q * C + c);
+                    aw[0] = w.x; aw[1] = w.y;
+                } else {
+                    aw[0] = *reinterpret_cast<const uint32_t*>(arg + q * C + c);
+                }
+                Vec16<T> d = ld16(dy + q * dycs + dyco + c);
+#pragma unroll
+                for (int k = 0; k < V; ++k)
+                    if (((aw[k >> 2] >> (8 * (k & 3))) & 255u) == mypos) g[k] += d.get(k);
+            }
+        }
+        T* op = dx + p * dxcs + dxco + c;
+        Vec16<T> o;
+        if (accumulate) o = ld16(op);
+#pragma unroll
+        for (int k = 0; k < V; ++k) o.set(k, g[k] + (accumulate ? o.get(k) : 0.f));
+        st16(op, o);
+    }
+}
+
 // dx[p] (+)= sum over the windows containing p whose FIRST maximum (scan order kh, kw: torch's tie rule)
 // is p, of dy[window]
 template <typename T>
@@ -376,6 +462,30 @@ extern "C" int sba_maxpool3x3s2_bwd(int dtype, const void* x, const void* dy, vo
     SBA_DISPATCH(dtype, SBA_LAUNCH((maxpool_bwd_kernel<T>), dim3(grid_for((int64_t)N * H * W * (C / V))),
                                            dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, N, H,
                                            W, C, xcs, xco, dycs, dyco, dxcs, dxco, accumulate));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_maxpool3x3s2_fwd_arg(int dtype, const void* x, void* y, uint8_t* argmax, int N, int H, int W, int C,
+                                        int xcs, int xco, int ycs, int yco, void* stream) {
+    if (!x || !y || !argmax || N <= 0 || H < 3 || W < 3 || !slice_ok(dtype, C, xcs, xco) || !slice_ok(dtype, C, ycs, yco))
+        return SBA_E_ARG;
+    const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1, V = dtype == SBA_BF16 ? 8 : 4;
+    if (((uintptr_t)argmax & 7) != 0) return SBA_E_ARG;
+    SBA_DISPATCH(dtype, SBA_LAUNCH((maxpool_fwd_arg_kernel<T>), dim3(grid_for((int64_t)N * OH * OW * (C / V))),
+                                           dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, argmax, N, H, W, C,
+                                           xcs, xco, ycs, yco));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_maxpool3x3s2_bwd_arg(int dtype, const uint8_t* argmax, const void* dy, void* dx, int N, int H, int W,
+                                        int C, int dycs, int dyco, int dxcs, int dxco, int accumulate, void* stream) {
+    if (!argmax || !dy || !dx || N <= 0 || H < 3 || W < 3 || !slice_ok(dtype, C, dycs, dyco) ||
+        !slice_ok(dtype, C, dxcs, dxco) || ((uintptr_t)argmax & 7) != 0)
+        return SBA_E_ARG;
+    const int V = dtype == SBA_BF16 ? 8 : 4;
+    SBA_DISPATCH(dtype, SBA_LAUNCH((maxpool_bwd_arg_kernel<T>), dim3(grid_for((int64_t)N * H * W * (C / V))),
+                                           dim3(256), 0, (hipStream_t)stream, argmax, (const T*)dy, (T*)dx, N, H, W, C,
+                                           dycs, dyco, dxcs, dxco, accumulate));
     return SBA_CHECK_LAUNCH();
 }
 

@@ -20,6 +20,7 @@ from . import _lib, ops
 from ._lib import ConvGeom, call
 
 BN_EPS = 1e-3
+SAVE_ARGMAX = os.environ.get('SBA_ENC_SAVE_ARGMAX', '1') != '0'    # max-pool forward keeps the window argmax for the backward
 
 
 def _pad32(c):
@@ -272,17 +273,27 @@ class InceptionHIP(object):
         OH, OW = (H - 3) // 2 + 1, (W - 3) // 2 + 1
         if out is None:
             out = _Act(self._new(N, OH, OW, x.C))
-        call('sba_maxpool3x3s2_fwd', self._dt(), x.t.data_ptr(), out.t.data_ptr(), N, H, W, x.C, Ct, x.coff,
-             out.shape[3], out.coff, ops._stream())
-        self._record(('maxpool', None, x, out))
+        arg = None
+        if SAVE_ARGMAX and getattr(self, '_want_grad', False):
+            arg = torch.empty((N, OH, OW, x.C), dtype=torch.uint8, device=self.device)
+            call('sba_maxpool3x3s2_fwd_arg', self._dt(), x.t.data_ptr(), out.t.data_ptr(), arg.data_ptr(), N, H, W, x.C,
+                 Ct, x.coff, out.shape[3], out.coff, ops._stream())
+        else:
+            call('sba_maxpool3x3s2_fwd', self._dt(), x.t.data_ptr(), out.t.data_ptr(), N, H, W, x.C, Ct, x.coff,
+                 out.shape[3], out.coff, ops._stream())
+        self._record(('maxpool', arg, x, out))
         self._consume(x)
         return out
 
-    def _maxpool_bwd(self, x, out):
+    def _maxpool_bwd(self, x, out, arg=None):
         gy, gx = self._grad_of(out), self._grad_of(x)
         N, H, W, Ct = x.shape
-        call('sba_maxpool3x3s2_bwd', self._dt(), x.t.data_ptr(), gy[0].data_ptr(), gx[0].data_ptr(), N, H, W, x.C, Ct,
-             x.coff, out.shape[3], out.coff, Ct, x.coff, 1 if self._has_grad(x) else 0, ops._stream())
+        if arg is not None:
+            call('sba_maxpool3x3s2_bwd_arg', self._dt(), arg.data_ptr(), gy[0].data_ptr(), gx[0].data_ptr(), N, H, W, x.C,
+                 out.shape[3], out.coff, Ct, x.coff, 1 if self._has_grad(x) else 0, ops._stream())
+        else:
+            call('sba_maxpool3x3s2_bwd', self._dt(), x.t.data_ptr(), gy[0].data_ptr(), gx[0].data_ptr(), N, H, W, x.C, Ct,
+                 x.coff, out.shape[3], out.coff, Ct, x.coff, 1 if self._has_grad(x) else 0, ops._stream())
         self._filled.add(self._key(x))
         self._readers[self._key(x)] -= 1
 
@@ -555,7 +566,7 @@ class InceptionHIP(object):
                     call('sba_global_avgpool', dt, gl[0].data_ptr(), gp.data_ptr(), N, 64, 2048, 1, st)
                     self._filled.add(self._key(last))
             elif kind == 'maxpool':
-                self._maxpool_bwd(x, out)
+                self._maxpool_bwd(x, out, L)
             else:
                 self._avgpool_bwd(x, out)
 
@@ -611,6 +622,7 @@ class _InceptionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, runner):
         ctx.runner = runner
+        runner._want_grad = bool(ctx.needs_input_grad[0])      # a backward will follow: keep the max-pool argmax
         feats, code = runner.forward(img)
         return feats.contiguous(), code.contiguous()
 
