@@ -243,6 +243,46 @@ def test_inception_conv_geometries(dev, dt, geom):
     close(gx[..., :I].permute(0, 3, 1, 2), gx_ref, dt, 'dx')
 
 
+@pytest.mark.parametrize('dt', DTYPES)
+def test_maxpool3x3s2_pairs(dev, dt):
+    """max_pool2d(3, 2) of the image encoder (model.py:215,221 and the reduction blocks): forward, the backward that
+    re-derives the argmax from x, and the pair that keeps the argmax (one byte per element) -- on a channel slice of a
+    wider NHWC tensor, accumulating into an existing gradient, with ties (torch's rule: first maximum in scan order)."""
+    from sbagan import _lib
+    from sbagan import ops
+    N, C, H, W, Ct, co = 2, 32, 19, 17, 48, 8
+    dtc = _lib.SBA_BF16 if dt == torch.bfloat16 else _lib.SBA_F32
+    x = (fill.uniform((N, C, H, W), 31) * 4).round() / 4           # quantised: plenty of exact ties
+    xr = rounded(x, dt).requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2)
+    OH, OW = yr.shape[2:]
+    dy = rounded(fill.unit((N, C, OH, OW), 32), dt)
+    (gref,) = torch.autograd.grad(yr, xr, dy)
+    base = rounded(fill.unit((N, C, H, W), 33), dt)                 # existing gradient to accumulate into
+    xa = torch.zeros((N, H, W, Ct), dtype=dt, device=dev)
+    xa[..., co:co + C] = x.permute(0, 2, 3, 1).to(dev).to(dt)
+    dya = dy.permute(0, 2, 3, 1).contiguous().to(dev).to(dt)
+    st = ops._stream()
+    for keep in (False, True):
+        y = torch.empty((N, OH, OW, C), dtype=dt, device=dev)
+        gx = torch.zeros((N, H, W, Ct), dtype=dt, device=dev)
+        gx[..., co:co + C] = base.permute(0, 2, 3, 1).to(dev).to(dt)
+        if keep:
+            arg = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=dev)
+            _lib.call('sba_maxpool3x3s2_fwd_arg', dtc, xa.data_ptr(), y.data_ptr(), arg.data_ptr(), N, H, W, C, Ct, co,
+                      C, 0, st)
+            _lib.call('sba_maxpool3x3s2_bwd_arg', dtc, arg.data_ptr(), dya.data_ptr(), gx.data_ptr(), N, H, W, C, C, 0,
+                      Ct, co, 1, st)
+        else:
+            _lib.call('sba_maxpool3x3s2_fwd', dtc, xa.data_ptr(), y.data_ptr(), N, H, W, C, Ct, co, C, 0, st)
+            _lib.call('sba_maxpool3x3s2_bwd', dtc, xa.data_ptr(), dya.data_ptr(), gx.data_ptr(), N, H, W, C, Ct, co, C, 0,
+                      Ct, co, 1, st)
+        torch.cuda.synchronize()
+        assert torch.equal(y.float().cpu().permute(0, 3, 1, 2), yr.detach()), 'max is exact'
+        close(gx[..., co:co + C].permute(0, 3, 1, 2), gref + base, dt, 'dx keep=%s' % keep)
+        assert float(gx[..., :co].float().abs().max()) == 0.0 and float(gx[..., co + C:].float().abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------ fused blocks vs the oracle
 def _load(mod, P, dev):
     mod.load_state_dict(P)
