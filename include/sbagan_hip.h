@@ -75,6 +75,29 @@ typedef struct sba_conv_geom {
 
 const char* sba_version(void);
 
+/* ---- deterministic-reduction mode ----------------------------------------------------------------------------
+ * The one piece of process-wide state in the library.  Off (default): partial sums of BatchNorm / InstanceNorm
+ * statistics, split-K tiles, pixel-split weight gradients, the attention / DAMSM gradients etc. meet in f32 atomics
+ * (LDS and global), so results depend on workgroup arrival order in the last bits (like cuDNN's default algorithms
+ * under the reference, torch.backends.cudnn.deterministic = False).  On: every such kernel writes its partial sums
+ * to a private slot of the caller's `scratch` ring (plain stores) and an ordered fold adds the slots in slot order,
+ * in-workgroup accumulation is done wave by wave, split-K is disabled and the conv epilogue's BatchNorm statistics
+ * are replaced by the ordered sba_bn_stats pass over the stored tensor: two runs of the same launches on the same
+ * inputs are BIT-IDENTICAL, whatever the stream / graph / replayer issues them.  Slower (about 1.3x on the step);
+ * meant for parity tests and debugging, not for the benchmark.
+ *   scratch: device memory, 256-byte aligned, >= 1 MiB; size it for the partial sums of one whole step (the
+ *   B = 20 step uses about 0.6 GiB; sba_det_high_water() reports the largest amount handed out between two resets).
+ *   An allocation that does not fit before the end of the ring wraps to its start; one that exceeds the ring
+ *   fails (SBA_E_ARG from the launching entry point).  sba_det_reset() rewinds the ring (call it at the start of a
+ *   step, before capture: the addresses are baked into captured graphs).  Switch the mode only while the device is
+ *   idle. */
+int sba_set_deterministic(int on, void* scratch, int64_t scratch_bytes);
+int sba_get_deterministic(void);
+int sba_det_reset(void);
+int64_t sba_det_high_water(void);
+/* SBA_BN_STAT_SLOTS the library was compiled with (the host sizes its statistics buffers with it) */
+int sba_bn_stat_slots(void);
+
 /* ---- convolutions (replace nn.Conv2d fwd / autograd bwd; model.py:32-35,552,563-574) ---- */
 /* y[pixel][co] = sum_t sum_ci x[gather(pixel,t)][ci] * w[co][t][ci]  (+ addend[pixel][co]).
  * stats != NULL: also accumulates per-channel sum(y), sum(y^2) of the f32 accumulators into

@@ -148,7 +148,7 @@ template <typename T, int IDF>
 __global__ __launch_bounds__(AttnMma<T>::NW * 64) void word_attn_bwd_kernel(
     const T* __restrict__ h, const float* __restrict__ src, const uint8_t* __restrict__ mask,
     const T* __restrict__ dctx, T* __restrict__ dh, float* __restrict__ dsrc, int B, int Q, int L,
-    int mask_mode, int dcs, int dco, int accumulate, int chunks) {
+    int mask_mode, int dcs, int dco, int accumulate, int chunks, float* __restrict__ det_part) {
     constexpr int V = Vec16<T>::N;
     constexpr int NW = AttnMma<T>::NW;                   // waves per workgroup (LDS budget: 4 bf16, 2 f32)
     constexpr int NT = NW * 64;
@@ -164,7 +164,6 @@ __global__ __launch_bounds__(AttnMma<T>::NW * 64) void word_attn_bwd_kernel(
         const int c = i / LMAX, l = i - c * LMAX;
         s_src[i] = l < L ? src[((int64_t)b * IDF + c) * L + l] : 0.f;
     }
-    for (int i = tid; i < IDF * 32; i += NT) s_red[i] = 0.f;
     __syncthreads();
     unsigned char* XH = s_t + wid * WAVE_BYTES;          // [CT][64 q][32 ch] of h
     unsigned char* XD = XH + CT * TILE;                  // [CT][64 q][32 ch] of dctx
@@ -260,15 +259,27 @@ __global__ __launch_bounds__(AttnMma<T>::NW * 64) void word_attn_bwd_kernel(
         }
         __syncthreads();                            // tiles consumed before the next chunk overwrites them
     }
-    // acc[t]: rows = channel (r&3)+8(r>>2)+4(lane>>5) of tile t, column = l = lane&31
+    // acc[t]: rows = channel (r&3)+8(r>>2)+4(lane>>5) of tile t, column = l = lane&31; the waves' tiles are added
+    // wave by wave (a fixed order: no LDS atomics)
+#pragma unroll 1
+    for (int wv = 0; wv < NW; ++wv) {
+        if (wid == wv) {
 #pragma unroll
-    for (int t = 0; t < CT; ++t)
+            for (int t = 0; t < CT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int c = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            atomicAdd(&s_red[c * 32 + (lane & 31)], acc[t][r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int c = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float* q = &s_red[c * 32 + (lane & 31)];
+                    *q = wv == 0 ? acc[t][r] : *q + acc[t][r];
+                }
         }
-    __syncthreads();
+        __syncthreads();
+    }
+    if (det_part) {         // deterministic mode: this workgroup's own slot; sba_det_fold adds the slots in order
+        float* part = det_part + ((int64_t)b * gridDim.x + blockIdx.x) * IDF * L;
+        for (int o = tid; o < IDF * L; o += NT) part[o] = s_red[(o / L) * 32 + (o - (o / L) * L)];
+        return;
+    }
     for (int o = tid; o < IDF * L; o += NT) {
         const int c = o / L, l = o - c * L;
         atomicAdd(&dsrc[((int64_t)b * IDF + c) * L + l], s_red[c * 32 + l]);
@@ -290,8 +301,14 @@ int launch_bwd(const void* h, const float* src, const uint8_t* mask, const void*
     constexpr int NT = AttnMma<T>::NW * 64;
     int chunks = Q >= 16384 ? 4 : (Q >= 4096 ? 2 : 1);           // NT-query chunks per workgroup
     dim3 grid(cdiv(Q, NT * chunks), B);
+    float* part = nullptr;
+    if (sba_det_on()) {
+        part = sba_det_alloc((int64_t)B * grid.x * IDF * L);
+        if (!part) return SBA_E_ARG;
+    }
     SBA_LAUNCH((word_attn_bwd_kernel<T, IDF>), grid, dim3(NT), 0, st, (const T*)h, src, mask,
-                       (const T*)dctx, (T*)dh, dsrc, B, Q, L, mode, dcs, dco, acc, chunks);
+                       (const T*)dctx, (T*)dh, dsrc, B, Q, L, mode, dcs, dco, acc, chunks, part);
+    if (part) sba_det_fold(part, B, (int)grid.x, (int64_t)IDF * L, dsrc, (int64_t)IDF * L, 0, st);
     return SBA_CHECK_LAUNCH();
 }
 

@@ -111,3 +111,16 @@ static inline void sba_zero_f32(float* a, float* b, int64_t n, hipStream_t st) {
     (void)hipGetLastError();
     hipLaunchKernelGGL(sba_zero_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, n);
 }
+
+// ---------------------------------------------------------------------------
+// Deterministic-reduction mode (det.hip; sba_set_deterministic in sbagan_hip.h).  When on, no result depends on
+// the order in which workgroups or waves reach an f32 atomic: every kernel that adds partial sums into a shared
+// destination writes them to a private slot of the scratch ring instead (plain stores), and sba_det_fold adds the
+// slots up in slot order; in-workgroup LDS accumulation is done wave by wave; split-K is off.
+// ---------------------------------------------------------------------------
+bool sba_det_on();
+// `nfloats` f32 of scratch for ONE launch (+ its fold), 256-byte aligned; nullptr when the ring is smaller than that
+float* sba_det_alloc(int64_t nfloats);
+// dst[j * dst_stride + i] (+)= sum_{p < P, in order} part[(j * P + p) * n + i]   for j < J, i < n
+//   mode 0: dst += sum;  mode 1: dst = sum
+void sba_det_fold(const float* part, int J, int P, int64_t n, float* dst, int64_t dst_stride, int mode, hipStream_t st);

@@ -184,10 +184,15 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
     const float* __restrict__ feat, const float* __restrict__ words, const int64_t* __restrict__ cap_lens,
     const float* __restrict__ sim, const float* __restrict__ attn, const float* __restrict__ attn1,
     const float* __restrict__ wctx_i, const float* __restrict__ dsim, float* __restrict__ dfeat,
-    float* __restrict__ dwords, int B, int nef, int R, int Lw, float gamma1, float gamma2) {
+    float* __restrict__ dwords, int B, int nef, int R, int Lw, float gamma1, float gamma2,
+    float* __restrict__ det_feat, float* __restrict__ det_words) {
+    // deterministic mode: pair (i, j) owns slot [j][i] of det_feat ([nef][R]) and slot [i][j] of det_words
+    // ([nef][Lw]) and fills them with plain stores; sba_det_fold adds the slots of an image / a caption in order
     extern __shared__ __attribute__((aligned(16))) float sm[];
     Lds L = carve(sm, nef, LP, Lw, R);
     const int i = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+    float* const pfeat = det_feat ? det_feat + ((int64_t)j * B + i) * nef * R : nullptr;
+    float* const pwords = det_words ? det_words + ((int64_t)i * B + j) * nef * Lw : nullptr;
     const int lane = tid & 63, wid = tid >> 6, nw = NT / 64;
     int T = (int)cap_lens[i];
     T = T < 1 ? 1 : (T > Lw ? Lw : T);
@@ -228,10 +233,12 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
         const int c = k / LP, t = k - c * LP;
         if (t < T) {
             const float qv = L.q[k], wv = L.w[k];
-            if (dwords)
+            if (pwords) pwords[c * Lw + t] = L.t[t] * wv - L.t[2 * TMAX + t] * qv;
+            else if (dwords)
                 atomicAdd(&dwords[((int64_t)i * nef + c) * Lw + t], L.t[t] * wv - L.t[2 * TMAX + t] * qv);
             L.w[k] = L.t[t] * qv - L.t[TMAX + t] * wv;
         } else {
+            if (pwords && t < Lw) pwords[c * Lw + t] = 0.f;
             L.w[k] = 0.f;
         }
     }
@@ -326,7 +333,8 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
 #pragma unroll
                 for (int q2 = 0; q2 < 16; ++q2) {
                     const int c = ct * 32 + (q2 & 3) + 8 * (q2 >> 2) + 4 * hf;
-                    atomicAdd(&dfeat[((int64_t)j * nef + c) * R + r], acc[q2]);
+                    if (pfeat) pfeat[c * R + r] = acc[q2];
+                    else atomicAdd(&dfeat[((int64_t)j * nef + c) * R + r], acc[q2]);
                 }
             }
         }
@@ -341,7 +349,9 @@ __global__ __launch_bounds__(NT) void damsm_words_bwd_kernel(
                 const int cl = o / T, t = o - cl * T;
                 float acc = 0.f;
                 for (int r = 0; r < R; ++r) acc += L.f[cl * R + r] * L.z[t * R + r];
-                atomicAdd(&dwords[((int64_t)i * nef + c0 + cl) * Lw + t], acc);
+                // (deterministic mode: the direct term was stored before the barriers above, by another thread)
+                if (pwords) pwords[(c0 + cl) * Lw + t] += acc;
+                else atomicAdd(&dwords[((int64_t)i * nef + c0 + cl) * Lw + t], acc);
             }
             __syncthreads();
         }
@@ -382,6 +392,37 @@ __global__ void damsm_sent_bwd_kernel(const float* __restrict__ cnn, const float
         const float a = cnn[j * nef + c], b = rnn[i * nef + c];
         if (dcnn) atomicAdd(&dcnn[j * nef + c], k0 * b - ka * a);
         if (drnn) atomicAdd(&drnn[i * nef + c], k0 * a - kb * b);
+    }
+}
+
+// deterministic mode: blockIdx.y = 0: dcnn[j = blockIdx.x] += sum_i ..., blockIdx.y = 1: drnn[i = blockIdx.x] += sum_j ...
+// (one workgroup per output row, the partners walked in order, no atomics)
+__global__ __launch_bounds__(64) void damsm_sent_bwd_det_kernel(const float* __restrict__ cnn, const float* __restrict__ rnn,
+                                                                const float* __restrict__ ds, float* __restrict__ dcnn,
+                                                                float* __restrict__ drnn, int B, int nef, float gamma3,
+                                                                float eps) {
+    const int lane = threadIdx.x, side = blockIdx.y, o = blockIdx.x;
+    float* out = side == 0 ? dcnn : drnn;
+    if (!out) return;
+    for (int p = 0; p < B; ++p) {
+        const int j = side == 0 ? o : p, i = side == 0 ? p : o;
+        float w12 = 0.f, n0 = 0.f, n1 = 0.f;
+        for (int c = lane; c < nef; c += 64) {
+            const float a = cnn[j * nef + c], b = rnn[i * nef + c];
+            w12 += a * b; n0 += a * a; n1 += b * b;
+        }
+        w12 = wave_sum(w12); n0 = wave_sum(n0); n1 = wave_sum(n1);
+        const float den = sqrtf(n0) * sqrtf(n1);
+        const bool clamped = den < eps;
+        const float g = ds[j * B + i] * gamma3;
+        const float k0 = g / fmaxf(den, eps);
+        const float ka = clamped ? 0.f : g * (w12 / den) / n0;
+        const float kb = clamped ? 0.f : g * (w12 / den) / n1;
+        for (int c = lane; c < nef; c += 64) {
+            const float a = cnn[j * nef + c], b = rnn[i * nef + c];
+            if (side == 0) out[j * nef + c] += k0 * b - ka * a;
+            else out[i * nef + c] += k0 * a - kb * b;
+        }
     }
 }
 
@@ -459,17 +500,25 @@ extern "C" int sba_damsm_words_bwd(const float* feat, const float* words, const 
     const int LP = L <= 20 ? 20 : 32;
     const size_t sh = lds_bytes(nef, LP, L, R);
     if (sh > 160 * 1024) return SBA_E_ARG;
+    float *pf = nullptr, *pw = nullptr;
+    if (sba_det_on()) {
+        pf = sba_det_alloc((int64_t)B * B * nef * R);
+        if (!pf) return SBA_E_ARG;
+        if (dwords) { pw = sba_det_alloc((int64_t)B * B * nef * L); if (!pw) return SBA_E_ARG; }
+    }
     if (LP == 20) {
         (void)hipFuncSetAttribute((const void*)damsm_words_bwd_kernel<20>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         SBA_LAUNCH(damsm_words_bwd_kernel<20>, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words,
-                           cap_lens, sim, attn, attn1, wctx, dsim, dfeat, dwords, B, nef, R, L, gamma1, gamma2);
+                           cap_lens, sim, attn, attn1, wctx, dsim, dfeat, dwords, B, nef, R, L, gamma1, gamma2, pf, pw);
     } else {
         (void)hipFuncSetAttribute((const void*)damsm_words_bwd_kernel<32>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         SBA_LAUNCH(damsm_words_bwd_kernel<32>, dim3(B, B), dim3(NT), sh, (hipStream_t)stream, feat, words,
-                           cap_lens, sim, attn, attn1, wctx, dsim, dfeat, dwords, B, nef, R, L, gamma1, gamma2);
+                           cap_lens, sim, attn, attn1, wctx, dsim, dfeat, dwords, B, nef, R, L, gamma1, gamma2, pf, pw);
     }
+    if (pf) sba_det_fold(pf, B, B, (int64_t)nef * R, dfeat, (int64_t)nef * R, 0, (hipStream_t)stream);
+    if (pw) sba_det_fold(pw, B, B, (int64_t)nef * L, dwords, (int64_t)nef * L, 0, (hipStream_t)stream);
     return SBA_CHECK_LAUNCH();
 }
 
@@ -484,6 +533,11 @@ extern "C" int sba_damsm_sent_fwd(const float* cnn, const float* rnn, float* s, 
 extern "C" int sba_damsm_sent_bwd(const float* cnn, const float* rnn, const float* ds, float* dcnn, float* drnn,
                                   int B, int nef, float gamma3, float eps, void* stream) {
     if (!cnn || !rnn || !ds || B <= 0 || B > 1024 || nef <= 0) return SBA_E_ARG;
+    if (sba_det_on()) {
+        SBA_LAUNCH(damsm_sent_bwd_det_kernel, dim3(B, 2), dim3(64), 0, (hipStream_t)stream, cnn, rnn, ds, dcnn, drnn, B,
+                   nef, gamma3, eps);
+        return SBA_CHECK_LAUNCH();
+    }
     SBA_LAUNCH(damsm_sent_bwd_kernel, dim3(B, B), dim3(64), 0, (hipStream_t)stream, cnn, rnn, ds, dcnn, drnn,
                        B, nef, gamma3, eps);
     return SBA_CHECK_LAUNCH();

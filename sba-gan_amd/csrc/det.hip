@@ -1,0 +1,72 @@
+// Deterministic-reduction mode: the scratch ring and the ordered fold (see common.h).
+//
+// The reference is PyTorch on cuDNN, whose default algorithms are not run-to-run reproducible either; this mode
+// exists so that the parity tests can tell a race from floating-point reassociation: with it on, two runs of the
+// same step from the same state are bit-identical in every launch mode (tests/test_step_gpu.py).
+#include <mutex>
+
+#include "common.h"
+
+namespace {
+std::mutex g_mu;
+bool g_on = false;
+char* g_ring = nullptr;
+int64_t g_bytes = 0, g_off = 0, g_used_since_reset = 0, g_high_water = 0;
+
+__global__ __launch_bounds__(256) void det_fold_kernel(const float* __restrict__ part, const int P, const int64_t n,
+                                                       float* __restrict__ dst, const int64_t dst_stride,
+                                                       const int mode) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int j = blockIdx.y;
+    const float* p = part + (int64_t)j * P * n + i;
+    float s = 0.f;
+    for (int q = 0; q < P; ++q) s += p[(int64_t)q * n];
+    float* d = dst + (int64_t)j * dst_stride + i;
+    *d = mode == 1 ? s : *d + s;
+}
+}  // namespace
+
+bool sba_det_on() { return g_on; }
+
+float* sba_det_alloc(int64_t nfloats) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int64_t bytes = ((nfloats * 4 + 255) / 256) * 256;
+    if (!g_ring || bytes > g_bytes) return nullptr;
+    if (g_off + bytes > g_bytes) g_off = 0;             // wrap: callers size the ring for more than one step
+    float* p = reinterpret_cast<float*>(g_ring + g_off);
+    g_off += bytes;
+    g_used_since_reset += bytes;
+    if (g_used_since_reset > g_high_water) g_high_water = g_used_since_reset;
+    return p;
+}
+
+void sba_det_fold(const float* part, int J, int P, int64_t n, float* dst, int64_t dst_stride, int mode, hipStream_t st) {
+    if (J <= 0 || P <= 0 || n <= 0) return;
+    SBA_LAUNCH(det_fold_kernel, dim3((unsigned)((n + 255) / 256), J), dim3(256), 0, st, part, P, n, dst, dst_stride, mode);
+}
+
+extern "C" int sba_set_deterministic(int on, void* scratch, int64_t scratch_bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (on && (!scratch || scratch_bytes < (1 << 20) || ((uintptr_t)scratch & 255) != 0)) return SBA_E_ARG;
+    g_on = on != 0;
+    g_ring = on ? reinterpret_cast<char*>(scratch) : nullptr;
+    g_bytes = on ? scratch_bytes : 0;
+    g_off = g_used_since_reset = 0;
+    return SBA_OK;
+}
+
+extern "C" int sba_get_deterministic(void) { return g_on ? 1 : 0; }
+
+extern "C" int sba_det_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_off = g_used_since_reset = 0;
+    return SBA_OK;
+}
+
+extern "C" int64_t sba_det_high_water(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_high_water;
+}
+
+extern "C" int sba_bn_stat_slots(void) { return SBA_BN_STAT_SLOTS; }

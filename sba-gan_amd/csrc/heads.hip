@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void img_head_bwd_kernel(const T* __restrict__
                                                            const float* __restrict__ img,
                                                            const float* __restrict__ dimg, T* __restrict__ dh,
                                                            float* __restrict__ dw, int N, int H, int W,
-                                                           int accumulate) {
+                                                           int accumulate, float* __restrict__ det_part) {
     constexpr int V = Vec16<T>::N;
     // row strides ODD: the per-pixel scalar writes of a wave (lane = pixel, stride = row) then spread over all 64 banks
     // (strides of 32 floats put the 64 lanes on two banks: 32 + C 32-way conflicting ds_write_b32 per lane), and the
@@ -69,7 +69,6 @@ __global__ __launch_bounds__(256) void img_head_bwd_kernel(const T* __restrict__
     float* s_r = s_d + 256 * DS;     // [32][C]     dw partial sums of the workgroup
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < 27 * C; i += 256) s_w[i] = w[i];
-    for (int i = tid; i < 32 * C; i += 256) s_r[i] = 0.f;
     const int64_t total = (int64_t)N * H * W;
     const int64_t p = blockIdx.x * (int64_t)256 + tid;
     const bool live = p < total;
@@ -127,27 +126,42 @@ __global__ __launch_bounds__(256) void img_head_bwd_kernel(const T* __restrict__
         if (live) st16(op + cv * V, o);
     }
     __syncthreads();
-    // dw tile(s): rows = i (27 of 32), columns = ci; this wave contracts its own 64 pixels
+    // dw tile(s): rows = i (27 of 32), columns = ci; this wave contracts its own 64 pixels; the four waves' tiles
+    // are then added wave by wave (a fixed order: no LDS atomics)
     {
         const int rl = lane & 31, hf = lane >> 5;
         const float* ap = s_d + (wid * 64 + hf) * DS + rl;
+        f32x16_t acc[NTL];
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
-            f32x16_t acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
             const float* bp = s_h + (wid * 64 + hf) * HS + nt * 32 + rl;
 #pragma unroll 8
             for (int kk = 0; kk < 32; ++kk)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk * DS], bp[2 * kk * HS], acc, 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kk * DS], bp[2 * kk * HS], acc[nt], 0, 0, 0);
+        }
+#pragma unroll 1
+        for (int wv = 0; wv < 4; ++wv) {
+            if (wid == wv) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * hf;
-                if (i < 27) atomicAdd(&s_r[i * C + nt * 32 + rl], acc[r]);
+                for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = (r & 3) + 8 * (r >> 2) + 4 * hf;
+                        if (i < 27) {
+                            float* q = &s_r[i * C + nt * 32 + rl];
+                            *q = wv == 0 ? acc[nt][r] : *q + acc[nt][r];
+                        }
+                    }
             }
+            __syncthreads();
         }
     }
-    __syncthreads();
+    if (det_part) {         // deterministic mode: this workgroup's own slot; sba_det_fold adds the slots in order
+        for (int o = tid; o < 27 * C; o += 256) det_part[(int64_t)blockIdx.x * 27 * C + o] = s_r[o];
+        return;
+    }
     for (int o = tid; o < 27 * C; o += 256) atomicAdd(&dw[o], s_r[o]);
 }
 
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(256) void d_stem_fwd_kernel(const float* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void d_stem_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ out,
                                                            const T* __restrict__ dout, float* __restrict__ dw, int N,
-                                                           int S, int C, int tiles_per_block) {
+                                                           int S, int C, int tiles_per_block, int det) {
     constexpr int V = Vec16<T>::N;
     constexpr int PS = 96;                       // patch row stride (64 columns used, 48 real)
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -295,7 +309,11 @@ __global__ __launch_bounds__(256) void d_stem_wgrad_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (k < 48) atomicAdd(&dw[co * 48 + k], acc[a][r]);
+                // deterministic mode: dw = the scratch ring, one [C][48] slot per workgroup, folded in order afterwards
+                if (k < 48) {
+                    if (det) dw[(int64_t)blockIdx.x * C * 48 + co * 48 + k] = acc[a][r];
+                    else atomicAdd(&dw[co * 48 + k], acc[a][r]);
+                }
             }
         }
     }
@@ -395,9 +413,9 @@ __global__ __launch_bounds__(256) void logits_bwd_kernel(const T* __restrict__ h
                                                          const float* __restrict__ prob,
                                                          const float* __restrict__ dprob, T* __restrict__ dh,
                                                          float* __restrict__ dw, float* __restrict__ dbias, int B,
-                                                         int K, int accumulate) {
+                                                         int K, int accumulate, int chunk0) {
     constexpr int V = Vec16<T>::N;
-    const int b0 = blockIdx.y * LOGITS_LB;
+    const int b0 = (chunk0 + blockIdx.y) * LOGITS_LB;
     float dl[LOGITS_LB];
 #pragma unroll
     for (int j = 0; j < LOGITS_LB; ++j) {
@@ -518,8 +536,12 @@ extern "C" int sba_img_head_bwd(int dtype, const void* h, const float* w, const 
     SBA_DISPATCH(dtype, CH_SWITCH(C_, {
         const size_t sh = sizeof(float) * (27 * C + 256 * (C + 1) + 256 * 33 + 32 * C);
         set_lds(img_head_bwd_kernel<T, C>, sh);
-        SBA_LAUNCH((img_head_bwd_kernel<T, C>), dim3(cdiv(total, 256)), dim3(256), sh, (hipStream_t)stream,
-                           (const T*)h, w, img, dimg, (T*)dh, dw, N, H, W, accumulate);
+        const int blocks = cdiv(total, 256);
+        float* part = nullptr;
+        if (sba_det_on()) { part = sba_det_alloc((int64_t)blocks * 27 * C); if (!part) return SBA_E_ARG; }
+        SBA_LAUNCH((img_head_bwd_kernel<T, C>), dim3(blocks), dim3(256), sh, (hipStream_t)stream,
+                           (const T*)h, w, img, dimg, (T*)dh, dw, N, H, W, accumulate, part);
+        if (part) sba_det_fold(part, 1, blocks, 27 * C, dw, 0, 0, (hipStream_t)stream);
     }));
     return SBA_CHECK_LAUNCH();
 }
@@ -548,11 +570,14 @@ extern "C" int sba_d_stem_bwd(int dtype, const float* img, const float* w, const
         if (tpb < 1) tpb = 1;
         const int blocks = (int)((tiles + tpb - 1) / tpb);
         const size_t sh = sizeof(float) * (64 * (C + (C % 64 == 0 ? 32 : 0)) + 64 * 96);
+        float* part = nullptr;
+        if (sba_det_on()) { part = sba_det_alloc((int64_t)blocks * C * 48); if (!part) return SBA_E_ARG; }
         SBA_DISPATCH(dtype, {
             set_lds(d_stem_wgrad_kernel<T>, sh);
             SBA_LAUNCH((d_stem_wgrad_kernel<T>), dim3(blocks), dim3(256), sh, st, img, (const T*)out,
-                               (const T*)dout, dw, N, S, C, tpb);
+                               (const T*)dout, part ? part : dw, N, S, C, tpb, part ? 1 : 0);
         });
+        if (part) sba_det_fold(part, 1, blocks, (int64_t)C * 48, dw, 0, 0, st);
     }
     if (dimg) {
         const size_t sh = sizeof(float) * (48 * C + 100 * (C + 4));
@@ -579,9 +604,17 @@ extern "C" int sba_logits_bwd(int dtype, const void* h, const float* w, const fl
                               void* dh, float* dw, float* dbias, int B, int K, int accumulate, void* stream) {
     if (!h || !w || !prob || !dprob || !dh || B <= 0 || B > 4096 || K <= 0 || K % 8) return SBA_E_ARG;
     const int V = dtype == SBA_BF16 ? 8 : 4;
+    if (sba_det_on() && (dw || dbias)) {
+        // the sample chunks add into the same dw / dbias: one launch per chunk, in order
+        for (int ck = 0; ck < cdiv(B, LOGITS_LB); ++ck)
+            SBA_DISPATCH(dtype, SBA_LAUNCH((logits_bwd_kernel<T>), dim3(cdiv(K / V, 256), 1), dim3(256), 0,
+                                           (hipStream_t)stream, (const T*)h, w, prob, dprob, (T*)dh, dw, dbias, B, K,
+                                           accumulate, ck));
+        return SBA_CHECK_LAUNCH();
+    }
     SBA_DISPATCH(dtype, SBA_LAUNCH((logits_bwd_kernel<T>), dim3(cdiv(K / V, 256), cdiv(B, LOGITS_LB)), dim3(256),
                                            0, (hipStream_t)stream, (const T*)h, w, prob, dprob,
-                                           (T*)dh, dw, dbias, B, K, accumulate));
+                                           (T*)dh, dw, dbias, B, K, accumulate, 0));
     return SBA_CHECK_LAUNCH();
 }
 

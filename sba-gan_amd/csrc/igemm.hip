@@ -1490,7 +1490,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                     float* __restrict__ dw, const sba_conv_geom g,
                                                     const int M, const int chunks_per_split,
-                                                    const int use_atomic, const FastDiv dsub, const FastDiv dow) {
+                                                    const int use_atomic, const FastDiv dsub, const FastDiv dow,
+                                                    const int64_t zstride) {
     constexpr int ROWS = WgFrag<T>::ROWS;
     constexpr int CH = 16 / (int)sizeof(T);          // elements per 16-byte chunk
     constexpr int CPR = 64 / CH;                     // chunks per 64-channel pixel row
@@ -1569,27 +1570,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const T* __restrict__ x, con
         WgFrag<T>::mma(sa, sb, lane, acc);
     }
 
-    // cross-wave reduction through LDS, then one (atomic) add per element
+    // cross-wave reduction through LDS, wave by wave (a fixed order: no LDS atomics), then one add per element
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds);
-    for (int i = tid; i < 64 * 64; i += 256) red[i] = 0.f;
-    __syncthreads();
     const int col_l = lane & 31, rsel = 4 * (lane >> 5);
+#pragma unroll 1
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wid == wv) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + rsel;   // co
-                atomicAdd(&red[row * 64 + j * 32 + col_l], acc[i][j][r]);
-            }
-    __syncthreads();
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + rsel;   // co
+                        float* q = &red[row * 64 + j * 32 + col_l];
+                        *q = wv == 0 ? acc[i][j][r] : *q + acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float* dwz = dw + (int64_t)blockIdx.z * zstride;    // deterministic mode: this pixel split's own partial tensor
     for (int i = tid; i < 64 * 64; i += 256) {
         const int co = co0 + (i >> 6), ci = ci0 + (i & 63);
         if (co < g.Cout && ci < g.Cin) {
-            float* p = dw + ((int64_t)co * g.ntaps + tap) * g.Cin + ci;
-            if (use_atomic) atomicAdd(p, red[i]);
+            float* p = dwz + ((int64_t)co * g.ntaps + tap) * g.Cin + ci;
+            if (use_atomic == 1) atomicAdd(p, red[i]);
+            else if (use_atomic == 2) *p = red[i];
             else *p += red[i];
         }
     }
@@ -1608,7 +1615,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_small_kernel(const T* __restrict
                                                           float* __restrict__ dw, const sba_conv_geom g,
                                                           const int M, const int chunks_per_split,
                                                           const int use_atomic, const FastDiv dsub,
-                                                          const FastDiv dow) {
+                                                          const FastDiv dow, const int64_t zstride) {
     constexpr int ROWS = WgFrag<T>::ROWS;
     constexpr int CH = 16 / (int)sizeof(T);
     constexpr int CPR = 64 / CH;
@@ -1722,7 +1729,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_small_kernel(const T* __restrict
                     const int co = co0 + s * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
                     const int ci = ci0 + j * 32 + col_l;
                     if (co < g.Cout && ci < g.Cin) {
-                        float* p = dw + ((int64_t)co * g.ntaps + tap) * g.Cin + ci;
+                        float* p = dw + (int64_t)blockIdx.z * zstride + ((int64_t)co * g.ntaps + tap) * g.Cin + ci;
                         if (use_atomic == 1) atomicAdd(p, acc[s][i][j][r]);
                         else if (use_atomic == 2) *p = acc[s][i][j][r];       // first write of a cleared gradient
                         else *p += acc[s][i][j][r];
@@ -1764,7 +1771,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_small_dma_kernel(const bf16_t* _
                                                               float* __restrict__ dw, const sba_conv_geom g,
                                                               const int M, const int chunks_per_split,
                                                               const int use_atomic, const FastDiv dsub,
-                                                              const FastDiv dow) {
+                                                              const FastDiv dow, const int64_t zstride) {
     constexpr int SL = 32 * 128;                 // one slice: 32 pixels x 64 channels
     constexpr int STAGE = (CT + 4) * SL;         // [dy slices (shared)] [x slice of wave 0..3]
     constexpr int LPS = 4 + CT;                  // DMA instructions per wave per stage
@@ -1895,7 +1902,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_small_dma_kernel(const bf16_t* _
                     const int co = co0 + s * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
                     const int ci = ci0 + j * 32 + col_l;
                     if (co < g.Cout && ci < g.Cin) {
-                        float* p = dw + ((int64_t)co * g.ntaps + tap) * g.Cin + ci;
+                        float* p = dw + (int64_t)blockIdx.z * zstride + ((int64_t)co * g.ntaps + tap) * g.Cin + ci;
                         if (use_atomic == 1) atomicAdd(p, acc[s][i][j][r]);
                         else if (use_atomic == 2) *p = acc[s][i][j][r];       // first write of a cleared gradient
                         else *p += acc[s][i][j][r];
@@ -1916,7 +1923,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_small_dma_kernel(const bf16_t* _
 template <typename T>
 __global__ __launch_bounds__(192) void wgrad_rows_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                          float* __restrict__ dw, const sba_conv_geom g,
-                                                         const int total_segs, const int segs_per_wg) {
+                                                         const int total_segs, const int segs_per_wg,
+                                                         const int store, const int64_t zstride) {
     constexpr int ROWS = WgFrag<T>::ROWS;
     constexpr int CH = 16 / (int)sizeof(T);
     constexpr int CPR = 64 / CH;                       // 16-byte chunks per 64-channel pixel row
@@ -2029,8 +2037,11 @@ __global__ __launch_bounds__(192) void wgrad_rows_kernel(const T* __restrict__ x
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
                     const int ci = ci0 + j * 32 + col_l;
-                    if (co < g.Cout && ci < g.Cin)
-                        atomicAdd(dw + ((int64_t)co * 9 + tap) * g.Cin + ci, acc[kw][i][j][r]);
+                    if (co < g.Cout && ci < g.Cin) {
+                        float* p = dw + (int64_t)blockIdx.z * zstride + ((int64_t)co * 9 + tap) * g.Cin + ci;
+                        if (store) *p = acc[kw][i][j][r];       // deterministic mode: this split's own partial tensor
+                        else atomicAdd(p, acc[kw][i][j][r]);
+                    }
                 }
     }
 }
@@ -2498,6 +2509,8 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
             if (split > 1) best_split = split;
         }
     }
+    const bool det = sba_det_on();      // deterministic mode: no split-K (its partial sums meet in f32 atomics)
+    if (det) best_split = 1;
     float* ws = (float*)workspace;
     if (sizeof(T) == 2 && dma_enabled()) {
         const bf16_t* xb = (const bf16_t*)x; const bf16_t* wb = (const bf16_t*)w; bf16_t* yb = (bf16_t*)y;
@@ -2517,6 +2530,7 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
             if (split > 1 && !(workspace && g.Cout % 4 == 0 && (int64_t)M * g.Cout * 4 <= ws_bytes)) split = 1;
             if (split > nslabs / 2) split = nslabs / 2 > 0 ? nslabs / 2 : 1;
         }
+        if (det) split = 1;
         static int gen2 = -1;       // SBA_IGEMM_DMA2=0: first-generation kernels only (A/B aid)
         if (gen2 < 0) { const char* e = getenv("SBA_IGEMM_DMA2"); gen2 = (e && e[0] == '0') ? 0 : 1; }
         if (gen2 && g.Cin % 64 == 0 && tile != 11) {
@@ -2588,6 +2602,12 @@ bool geom_ok(const sba_conv_geom* g, int dtype) {
     return true;
 }
 
+// the launch writes every pixel and channel of a dense [N*OH*OW][Cout] tensor
+bool dense_output(const sba_conv_geom& g) {
+    return g.OHs == g.OH && g.OWs == g.OW && g.osy == 1 && g.osx == 1 && g.ooy == 0 && g.oox == 0 &&
+           (g.y_cstride == 0 || g.y_cstride == g.Cout) && g.y_coff == 0;
+}
+
 }  // namespace
 
 extern "C" int sba_conv_igemm(int dtype, const void* x, const void* w, void* y, const void* addend,
@@ -2595,6 +2615,16 @@ extern "C" int sba_conv_igemm(int dtype, const void* x, const void* w, void* y, 
                               void* stream) {
     if (!x || !w || !y || !geom_ok(g, dtype)) return SBA_E_ARG;
     if (((uintptr_t)workspace & 15) != 0) return SBA_E_ARG;
+    if (sba_det_on() && stats) {
+        // deterministic mode: the epilogue's statistics meet in f32 atomics (LDS and global); take them from the
+        // stored tensor with the ordered bn_stats pass instead (needs a dense output: it is one BatchNorm batch)
+        if (!dense_output(*g) || addend) return SBA_E_ARG;
+        int rc = SBA_E_ARG;
+        SBA_DISPATCH(dtype, rc = launch_igemm<T>(x, w, y, addend, nullptr, *g, workspace, workspace_bytes,
+                                                 (hipStream_t)stream));
+        if (rc != SBA_OK) return rc;
+        return sba_bn_stats(dtype, y, stats, (int64_t)g->N * g->OH * g->OW, 1, g->Cout, stream);
+    }
     SBA_DISPATCH(dtype, return launch_igemm<T>(x, w, y, addend, stats, *g, workspace, workspace_bytes,
                                                (hipStream_t)stream));
     return SBA_E_ARG;
@@ -2605,6 +2635,7 @@ extern "C" int sba_conv_igemm_bias(int dtype, const void* x, const void* w, void
                                    const sba_conv_geom* g, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!x || !w || !y || !geom_ok(g, dtype)) return SBA_E_ARG;
     if (((uintptr_t)workspace & 15) != 0) return SBA_E_ARG;
+    if (sba_det_on() && stats) return SBA_E_ARG;        // (no caller asks for statistics behind a bias / ReLU epilogue)
     SBA_DISPATCH(dtype, return launch_igemm<T>(x, w, y, addend, stats, *g, workspace, workspace_bytes,
                                                (hipStream_t)stream, EpiX{bias, relu_mask}));
     return SBA_E_ARG;
@@ -2621,6 +2652,17 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
     const int co_tiles = cdiv(g->Cout, 64), items = cdiv(g->Cin, 64) * g->ntaps;
     const FastDiv dsub = make_fastdiv((uint32_t)(g->OHs * g->OWs), (int64_t)M + 64);
     const FastDiv dow = make_fastdiv((uint32_t)g->OWs, (int64_t)M + 64);
+    // Deterministic mode: pixel splits do not meet in f32 atomics -- split z STORES its partial gradient into its own
+    // tensor of the scratch ring (mode 2, offset z * zstride) and sba_det_fold adds the splits up in order.
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t dwn = (int64_t)g->Cout * g->ntaps * g->Cin;
+    float* part = nullptr;
+    auto det_begin = [&](int nsplit) -> bool {
+        part = nullptr;
+        if (sba_det_on() && nsplit > 1) { part = sba_det_alloc((int64_t)nsplit * dwn); return part != nullptr; }
+        return true;
+    };
+    auto det_end = [&](int nsplit) { if (part) sba_det_fold(part, 1, nsplit, dwn, dw, 0, fw == 2 ? 1 : 0, st); };
     static int small_m = -1;
     if (small_m < 0) { const char* e = getenv("SBA_WGRAD_SMALL_M"); small_m = e ? atoi(e) : 12000; }
     if (M <= small_m && co_tiles * items >= 256) {
@@ -2645,7 +2687,7 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
         if (ct2 > 0 && split == 1 && g->Cout % 128 == 0 && (co_tiles / 2) * (int)grid.y >= ct2) {
             grid.x = co_tiles / 2;
             SBA_DISPATCH(dtype, SBA_LAUNCH((wgrad_small_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream,
-                                                   (const T*)x, (const T*)dy, dw, *g, M, cps, fw, dsub, dow));
+                                                   (const T*)x, (const T*)dy, dw, *g, M, cps, fw, dsub, dow, (int64_t)0));
             return SBA_CHECK_LAUNCH();
         }
         static int dma = -1;        // SBA_WGRAD_DMA: 0 = register-staged kernel; D = ring depth of the LDS-DMA kernel
@@ -2670,7 +2712,7 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
             static bool once = false;
             if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_small_dma_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
             SBA_LAUNCH((wgrad_small_dma_kernel<2, 3>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
-                       (const bf16_t*)dy, dw, *g, M, tc32, fw, dsub, dow);
+                       (const bf16_t*)dy, dw, *g, M, tc32, fw, dsub, dow, (int64_t)0);
             return SBA_CHECK_LAUNCH();
         }
         if (dma > 0 && wgs <= dma_wgs && dtype == SBA_BF16 && xb < (1ll << 32) && db < (1ll << 32)) {
@@ -2683,24 +2725,31 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
             sp = cdiv(tc32, cps32);
             dim3 gd(co_tiles, cdiv(items, 4), sp);
             if (gd.z > 65535) return SBA_E_ARG;
+            if (!det_begin(sp)) return SBA_E_ARG;
+            float* dwa = part ? part : dw;
+            const int md = part ? 2 : (sp > 1 ? 1 : fw);
+            const int64_t zs = part ? dwn : 0;
             if (dma == 3) {
                 constexpr int LDS = 3 * 5 * 32 * 128;
                 static bool once = false;
                 if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_small_dma_kernel<1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
                 SBA_LAUNCH((wgrad_small_dma_kernel<1, 3>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
-                           (const bf16_t*)dy, dw, *g, M, cps32, sp > 1 ? 1 : fw, dsub, dow);
+                           (const bf16_t*)dy, dwa, *g, M, cps32, md, dsub, dow, zs);
             } else {
                 constexpr int LDS = 4 * 5 * 32 * 128;
                 static bool once = false;
                 if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_small_dma_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
                 SBA_LAUNCH((wgrad_small_dma_kernel<1, 4>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
-                           (const bf16_t*)dy, dw, *g, M, cps32, sp > 1 ? 1 : fw, dsub, dow);
+                           (const bf16_t*)dy, dwa, *g, M, cps32, md, dsub, dow, zs);
             }
+            det_end(sp);
             return SBA_CHECK_LAUNCH();
         }
+        if (!det_begin(split)) return SBA_E_ARG;
         SBA_DISPATCH(dtype, SBA_LAUNCH((wgrad_small_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream,
-                                               (const T*)x, (const T*)dy, dw, *g, M, cps, split > 1 ? 1 : fw, dsub,
-                                               dow));
+                                               (const T*)x, (const T*)dy, part ? part : dw, *g, M, cps,
+                                               part ? 2 : (split > 1 ? 1 : fw), dsub, dow, part ? dwn : (int64_t)0));
+        det_end(split);
         return SBA_CHECK_LAUNCH();
     }
     // generator-style 3x3 stride-1 conv on a wide map: all nine taps per workgroup from halo tiles.  From 128x128 maps
@@ -2725,8 +2774,13 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
         nz = cdiv(total_segs, spw);
         dim3 grid(co_tiles, ci_t, nz);
         if (grid.z > 65535) return SBA_E_ARG;
+        // (deterministic mode: also for nz == 1 -- every workgroup's three waves store, nothing adds)
+        part = nullptr;
+        if (sba_det_on()) { part = sba_det_alloc((int64_t)nz * dwn); if (!part) return SBA_E_ARG; }
         SBA_DISPATCH(dtype, SBA_LAUNCH((wgrad_rows_kernel<T>), grid, dim3(192), 0, (hipStream_t)stream,
-                                               (const T*)x, (const T*)dy, dw, *g, total_segs, spw));
+                                               (const T*)x, (const T*)dy, part ? part : dw, *g, total_segs, spw,
+                                               part ? 1 : 0, part ? dwn : (int64_t)0));
+        det_end(nz);
         return SBA_CHECK_LAUNCH();
     }
     {
@@ -2752,19 +2806,24 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
             sp = cdiv(tc32, cps32);
             dim3 gd(cot, cdiv(items, 4), sp);
             if (gd.y <= 65535 && gd.z <= 65535) {
+                if (!det_begin(sp)) return SBA_E_ARG;
+                float* dwa = part ? part : dw;
+                const int md = part ? 2 : (sp > 1 ? 1 : fw);
+                const int64_t zs = part ? dwn : 0;
                 if (ct2) {
                     constexpr int LDS = 3 * 6 * 32 * 128;
                     static bool once = false;
                     if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_small_dma_kernel<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
                     SBA_LAUNCH((wgrad_small_dma_kernel<2, 3>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
-                               (const bf16_t*)dy, dw, *g, M, cps32, sp > 1 ? 1 : fw, dsub, dow);
+                               (const bf16_t*)dy, dwa, *g, M, cps32, md, dsub, dow, zs);
                 } else {
                     constexpr int LDS = 4 * 5 * 32 * 128;
                     static bool once = false;
                     if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_small_dma_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
                     SBA_LAUNCH((wgrad_small_dma_kernel<1, 4>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
-                               (const bf16_t*)dy, dw, *g, M, cps32, sp > 1 ? 1 : fw, dsub, dow);
+                               (const bf16_t*)dy, dwa, *g, M, cps32, md, dsub, dow, zs);
                 }
+                det_end(sp);
                 return SBA_CHECK_LAUNCH();
             }
         }
@@ -2775,9 +2834,11 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
     ksplit = cdiv(total_chunks, cps);
     dim3 grid(co_tiles, items, ksplit);
     if (grid.y > 65535 || grid.z > 65535) return SBA_E_ARG;
+    if (!det_begin(ksplit)) return SBA_E_ARG;
     SBA_DISPATCH(dtype, SBA_LAUNCH((wgrad_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
-                                           (const T*)x, (const T*)dy, dw, *g, M, cps, ksplit > 1 ? 1 : 0, dsub,
-                                           dow));
+                                           (const T*)x, (const T*)dy, part ? part : dw, *g, M, cps,
+                                           part ? 2 : (ksplit > 1 ? 1 : 0), dsub, dow, part ? dwn : (int64_t)0));
+    det_end(ksplit);
     return SBA_CHECK_LAUNCH();
 }
 

@@ -426,11 +426,11 @@ extern "C" int sba_linear_bwd(const float* x, const float* w, const float* dy, f
     }
     if (dx && B <= 32 && N % 32 == 0) {    // wide layer (INIT_STAGE_G.fc): the reduction sliced over workgroups
         sba_zero_f32(dx, nullptr, (int64_t)B * K, st);
-        const int nper = 512;
+        const int nper = sba_det_on() ? N : 512;       // deterministic mode: one slice, no atomics
         SBA_LAUNCH(linear_bwd_x_mfma_kernel, dim3(cdiv(K, 32), cdiv(N, nper)), dim3(64), 0, st, w, dy, dx, B, K, N, nper);
     } else if (dx) {
         sba_zero_f32(dx, nullptr, (int64_t)B * K, st);
-        const int nper = N >= 4096 ? 64 : (N >= 512 ? 16 : 4);
+        const int nper = sba_det_on() ? N : (N >= 4096 ? 64 : (N >= 512 ? 16 : 4));    // deterministic: one workgroup
         SBA_LAUNCH(linear_bwd_x_kernel, dim3(cdiv(N, nper)), dim3(256), 0, st, w, dy, dx, B, K, N, nper);
     }
     return SBA_CHECK_LAUNCH();

@@ -32,14 +32,17 @@ __device__ __forceinline__ BnCoef bn_coef(const float* __restrict__ stats, const
 // ---- batch statistics of an NHWC tensor (used when the conv epilogue cannot provide them:
 //      grouped passes, where one conv launch covers several BatchNorm batches); blockIdx.y = group ----
 template <typename T>
-__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y_all, float* __restrict__ stats_all, int64_t rows, int C) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y_all, float* __restrict__ stats_all, int64_t rows, int C,
+                                                       float* __restrict__ det_part) {
     constexpr int V = Vec16<T>::N;
     const T* y = y_all + (int64_t)blockIdx.y * rows * C;
     float* stats = stats_all + ((int64_t)blockIdx.y * SBA_BN_STAT_SLOTS + (blockIdx.x & (SBA_BN_STAT_SLOTS - 1))) * 2 * C;
     const int cv = C / V;
-    extern __shared__ float s_acc[];                        // [2*C]
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.f;
-    __syncthreads();
+    extern __shared__ float s_acc[];                        // [2*C]; deterministic mode: [rows per iteration][2*C]
+    if (!det_part) {
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.f;
+        __syncthreads();
+    }
     const int tpr = cv < (int)blockDim.x ? cv : (int)blockDim.x;
     const int rpi = blockDim.x / tpr;
     const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
@@ -53,13 +56,30 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y_a
 #pragma unroll
             for (int k = 0; k < V; ++k) { const float v = a.get(k); s0[k] += v; s1[k] += v * v; }
         }
+        if (det_part) {                                     // private LDS row per row-group: no atomics
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            atomicAdd(&s_acc[c + k], s0[k]);
-            atomicAdd(&s_acc[C + c + k], s1[k]);
+            for (int k = 0; k < V; ++k) {
+                s_acc[tr * 2 * C + c + k] = s0[k];
+                s_acc[tr * 2 * C + C + c + k] = s1[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                atomicAdd(&s_acc[c + k], s0[k]);
+                atomicAdd(&s_acc[C + c + k], s1[k]);
+            }
         }
     }
     __syncthreads();
+    if (det_part) {         // this workgroup's partial sums, row-groups added in order; sba_det_fold adds the workgroups
+        float* part = det_part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C;
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+            float v = 0.f;
+            for (int r = 0; r < rpi; ++r) v += s_acc[r * 2 * C + i];
+            part[i] = v;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&stats[i], s_acc[i]);
 }
 
@@ -150,7 +170,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ y_all, const T* __restrict__ dout_all,
                                      const float* __restrict__ aux_all, float* __restrict__ red_all,
-                                     int64_t rows, int C, int dcs, int dco) {
+                                     int64_t rows, int C, int dcs, int dco, float* __restrict__ det_part) {
     constexpr int V = Vec16<T>::N;
     const int g = blockIdx.y;
     const T* y = y_all + (int64_t)g * rows * C;
@@ -163,9 +183,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     float* red = red_all + ((int64_t)g * SBA_BN_STAT_SLOTS + (blockIdx.x & (SBA_BN_STAT_SLOTS - 1))) * 2 * C;
     const int Co = ACT == SBA_ACT_GLU ? C / 2 : C;
     const int cv = Co / V;                                  // power of two
-    extern __shared__ float s_acc[];                        // [2*C]
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.f;
-    __syncthreads();
+    extern __shared__ float s_acc[];                        // [2*C]; deterministic mode: [rows per iteration][2*C]
+    if (!det_part) {
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.f;
+        __syncthreads();
+    }
     const int tpr = cv < (int)blockDim.x ? cv : (int)blockDim.x;   // threads per row
     const int rpi = blockDim.x / tpr;                               // rows per iteration
     const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
@@ -212,17 +234,39 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 }
             }
         }
+        if (det_part) {
+            float* row = s_acc + tr * 2 * C;
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            atomicAdd(&s_acc[c + k], s0[k]);
-            atomicAdd(&s_acc[C + c + k], s1[k]);
-            if (ACT == SBA_ACT_GLU) {
-                atomicAdd(&s_acc[Co + c + k], g0[k]);
-                atomicAdd(&s_acc[C + Co + c + k], g1[k]);
+            for (int k = 0; k < V; ++k) {
+                row[c + k] = s0[k];
+                row[C + c + k] = s1[k];
+                if (ACT == SBA_ACT_GLU) {
+                    row[Co + c + k] = g0[k];
+                    row[C + Co + c + k] = g1[k];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                atomicAdd(&s_acc[c + k], s0[k]);
+                atomicAdd(&s_acc[C + c + k], s1[k]);
+                if (ACT == SBA_ACT_GLU) {
+                    atomicAdd(&s_acc[Co + c + k], g0[k]);
+                    atomicAdd(&s_acc[C + Co + c + k], g1[k]);
+                }
             }
         }
     }
     __syncthreads();
+    if (det_part) {
+        float* part = det_part + ((int64_t)g * gridDim.x + blockIdx.x) * 2 * C;
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+            float v = 0.f;
+            for (int r = 0; r < rpi; ++r) v += s_acc[r * 2 * C + i];
+            part[i] = v;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&red[i], s_acc[i]);
 }
 
@@ -570,14 +614,16 @@ __global__ __launch_bounds__(256) void bn1d_glu_bwd_kernel(const float* __restri
 // grid (N, splits); threads [rows][C/V]; accumulates (sum, sumsq) into mean/rstd buffers
 template <typename T>
 __global__ __launch_bounds__(256) void instnorm_accum_kernel(const T* __restrict__ h, float* __restrict__ sum,
-                                      float* __restrict__ sumsq, int HW, int C) {
+                                      float* __restrict__ sumsq, int HW, int C, int det) {
     constexpr int V = Vec16<T>::N;
     const int cv = C / V, n = blockIdx.x;
     const int rpi = blockDim.x / cv;
     const int tc = threadIdx.x % cv, tr = threadIdx.x / cv;
-    extern __shared__ float s_acc[];   // [2*C]
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.f;
-    __syncthreads();
+    extern __shared__ float s_acc[];   // [2*C]; deterministic mode (one workgroup per image): [rpi][2*C]
+    if (!det) {
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.f;
+        __syncthreads();
+    }
     float s0[V], s1[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) s0[k] = s1[k] = 0.f;
@@ -589,11 +635,24 @@ __global__ __launch_bounds__(256) void instnorm_accum_kernel(const T* __restrict
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            atomicAdd(&s_acc[tc * V + k], s0[k]);
-            atomicAdd(&s_acc[C + tc * V + k], s1[k]);
+            if (det) {
+                s_acc[tr * 2 * C + tc * V + k] = s0[k];
+                s_acc[tr * 2 * C + C + tc * V + k] = s1[k];
+            } else {
+                atomicAdd(&s_acc[tc * V + k], s0[k]);
+                atomicAdd(&s_acc[C + tc * V + k], s1[k]);
+            }
         }
     }
     __syncthreads();
+    if (det) {              // gridDim.y == 1: this workgroup owns image n; row-groups added in order, plain stores
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+            float v = 0.f;
+            for (int r = 0; r < rpi; ++r) v += s_acc[r * 2 * C + i];
+            if (i < C) sum[n * C + i] = v; else sumsq[n * C + i - C] = v;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < C; i += blockDim.x) {
         atomicAdd(&sum[n * C + i], s_acc[i]);
         atomicAdd(&sumsq[n * C + i], s_acc[C + i]);
@@ -636,14 +695,16 @@ __global__ __launch_bounds__(256) void adain_fwd_kernel(const T* __restrict__ h,
 template <typename T>
 __global__ __launch_bounds__(256) void adain_bwd_reduce_kernel(const T* __restrict__ h, const T* __restrict__ dout,
                                         const float* __restrict__ mean, const float* __restrict__ rstd,
-                                        float* __restrict__ red, int HW, int C, int dcs, int dco) {
+                                        float* __restrict__ red, int HW, int C, int dcs, int dco, int det) {
     constexpr int V = Vec16<T>::N;
     const int cv = C / V, n = blockIdx.x;
     const int rpi = blockDim.x / cv;
     const int tc = threadIdx.x % cv, tr = threadIdx.x / cv;
-    extern __shared__ float s_acc[];   // [2*C]
-    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.f;
-    __syncthreads();
+    extern __shared__ float s_acc[];   // [2*C]; deterministic mode (one workgroup per image): [rpi][2*C]
+    if (!det) {
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) s_acc[i] = 0.f;
+        __syncthreads();
+    }
     float s0[V], s1[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) s0[k] = s1[k] = 0.f;
@@ -662,11 +723,24 @@ __global__ __launch_bounds__(256) void adain_bwd_reduce_kernel(const T* __restri
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            atomicAdd(&s_acc[tc * V + k], s0[k]);
-            atomicAdd(&s_acc[C + tc * V + k], s1[k]);
+            if (det) {
+                s_acc[tr * 2 * C + tc * V + k] = s0[k];
+                s_acc[tr * 2 * C + C + tc * V + k] = s1[k];
+            } else {
+                atomicAdd(&s_acc[tc * V + k], s0[k]);
+                atomicAdd(&s_acc[C + tc * V + k], s1[k]);
+            }
         }
     }
     __syncthreads();
+    if (det) {
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+            float v = 0.f;
+            for (int r = 0; r < rpi; ++r) v += s_acc[r * 2 * C + i];
+            if (i < C) red[(n * C + i) * 2 + 0] += v; else red[(n * C + i - C) * 2 + 1] += v;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < C; i += blockDim.x) {
         atomicAdd(&red[(n * C + i) * 2 + 0], s_acc[i]);
         atomicAdd(&red[(n * C + i) * 2 + 1], s_acc[C + i]);
@@ -736,9 +810,17 @@ extern "C" int sba_bn_stats(int dtype, const void* y, float* stats, int64_t rows
     const int cap_g = cap / groups > 64 ? cap / groups : 64;
     if (blocks > cap_g) blocks = cap_g;
     if (blocks < 1) blocks = 1;
-    SBA_DISPATCH(dtype, SBA_LAUNCH((bn_stats_kernel<T>), dim3(blocks, groups), dim3(256),
-                                           2 * (size_t)C * sizeof(float), (hipStream_t)stream, (const T*)y, stats,
-                                           rows, C));
+    float* part = nullptr;
+    size_t sh = 2 * (size_t)C * sizeof(float);
+    if (sba_det_on()) {
+        part = sba_det_alloc((int64_t)groups * blocks * 2 * C);
+        if (!part) return SBA_E_ARG;
+        sh *= rpi;
+    }
+    SBA_DISPATCH(dtype, SBA_LAUNCH((bn_stats_kernel<T>), dim3(blocks, groups), dim3(256), sh, (hipStream_t)stream,
+                                   (const T*)y, stats, rows, C, part));
+    // deterministic mode: the workgroups' partial sums are added in workgroup order into replica 0 (the others stay zero)
+    if (part) sba_det_fold(part, groups, blocks, 2 * C, stats, (int64_t)SBA_BN_STAT_SLOTS * 2 * C, 0, (hipStream_t)stream);
     return SBA_CHECK_LAUNCH();
 }
 
@@ -795,10 +877,17 @@ extern "C" int sba_bn_act_bwd_reduce(int dtype, const void* y, const void* dout,
     const int cap_g = cap / groups > 64 ? cap / groups : 64;
     if (blocks > cap_g) blocks = cap_g;
     if (blocks < 1) blocks = 1;
-    const size_t sh = 2 * (size_t)C * sizeof(float);
+    size_t sh = 2 * (size_t)C * sizeof(float);
+    float* part = nullptr;
+    if (sba_det_on()) {
+        part = sba_det_alloc((int64_t)groups * blocks * 2 * C);
+        if (!part) return SBA_E_ARG;
+        sh *= rpi;
+    }
     SBA_DISPATCH(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_reduce_kernel<T, ACT>), dim3(blocks, groups),
                                                            dim3(256), sh, (hipStream_t)stream, (const T*)y,
-                                                           (const T*)dout, aux, red, rows, C, dcs, dco)));
+                                                           (const T*)dout, aux, red, rows, C, dcs, dco, part)));
+    if (part) sba_det_fold(part, groups, blocks, 2 * C, red, (int64_t)SBA_BN_STAT_SLOTS * 2 * C, 0, (hipStream_t)stream);
     return SBA_CHECK_LAUNCH();
 }
 
@@ -812,6 +901,21 @@ extern "C" int sba_bn_act_bwd_apply(int dtype, const void* y, const void* dout, 
     if (dcs < Co + dco || dcs % V || dco % V) return SBA_E_ARG;
     const int blocks = grid_for(rows * (Co / V));
     const size_t sh = 6 * (size_t)C * sizeof(float);
+    if (sba_det_on() && groups > 1 && dgamma) {
+        // the groups add into the same dgamma / dbeta: one launch per group, in group order
+        const int64_t esz = dtype == SBA_BF16 ? 2 : 4;
+        for (int g = 0; g < groups; ++g) {
+            const char* yg = (const char*)y + (int64_t)g * rows * C * esz;
+            const char* dg = (const char*)dout + (int64_t)g * rows * dcs * esz;
+            char* dyg = (char*)dy + (int64_t)g * rows * C * esz;
+            const float* auxg = aux + (int64_t)g * 4 * C;
+            const float* redg = red + (int64_t)g * SBA_BN_STAT_SLOTS * 2 * C;
+            SBA_DISPATCH(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_apply_kernel<T, ACT>), dim3(blocks, 1), dim3(256), sh,
+                                                           (hipStream_t)stream, (const T*)yg, (const T*)dg, auxg, redg,
+                                                           (T*)dyg, dgamma, dbeta, rows, C, dcs, dco)));
+        }
+        return SBA_CHECK_LAUNCH();
+    }
     SBA_DISPATCH(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_apply_kernel<T, ACT>), dim3(blocks, groups),
                                                            dim3(256), sh, (hipStream_t)stream, (const T*)y,
                                                            (const T*)dout, aux, red, (T*)dy, dgamma, dbeta, rows, C,
@@ -844,6 +948,19 @@ extern "C" int sba_bn_act_bwd_fused(int dtype, const void* y, const void* dout, 
     const int Co = act == SBA_ACT_GLU ? C / 2 : C;
     const int V = dtype == SBA_BF16 ? 8 : 4;
     if (dcs < Co + dco || dcs % V || dco % V) return SBA_E_ARG;
+    if (sba_det_on() && groups > 1 && dgamma) {
+        const int64_t esz = dtype == SBA_BF16 ? 2 : 4;
+        for (int g = 0; g < groups; ++g) {
+            const char* yg = (const char*)y + (int64_t)g * rows * C * esz;
+            const char* dg = (const char*)dout + (int64_t)g * rows * dcs * esz;
+            char* dyg = (char*)dy + (int64_t)g * rows * C * esz;
+            const float* auxg = aux + (int64_t)g * 4 * C;
+            SBA_DISPATCH(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_fused_kernel<T, ACT>), dim3(Co / V, 1), dim3(256), 0,
+                                                           (hipStream_t)stream, (const T*)yg, (const T*)dg, auxg,
+                                                           (T*)dyg, dgamma, dbeta, rows, C, dcs, dco)));
+        }
+        return SBA_CHECK_LAUNCH();
+    }
     SBA_DISPATCH(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_fused_kernel<T, ACT>), dim3(Co / V, groups),
                                                            dim3(256), 0, (hipStream_t)stream, (const T*)y,
                                                            (const T*)dout, aux, (T*)dy, dgamma, dbeta, rows, C, dcs,
@@ -887,8 +1004,10 @@ extern "C" int sba_instnorm_stats(int dtype, const void* h, float* mean, float* 
     const int rpi = 256 / (C / V);
     int splits = cdiv(HW, rpi * 16);
     if (splits > 256) splits = 256;
+    const int det = sba_det_on() ? 1 : 0;
+    if (det) splits = 1;            // one workgroup per image, row-groups added in order
     SBA_DISPATCH(dtype, SBA_LAUNCH((instnorm_accum_kernel<T>), dim3(N, splits), dim3(256),
-                                           2 * C * sizeof(float), st, (const T*)h, mean, rstd, HW, C));
+                                           (det ? rpi : 1) * 2 * C * sizeof(float), st, (const T*)h, mean, rstd, HW, C, det));
     SBA_LAUNCH(instnorm_finalize_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, st, mean, rstd, N * C,
                        (float)HW, eps);
     return SBA_CHECK_LAUNCH();
@@ -914,9 +1033,11 @@ extern "C" int sba_adain_bwd_reduce(int dtype, const void* h, const void* dout, 
     const int rpi = 256 / (C / V);
     int splits = cdiv(HW, rpi * 16);
     if (splits > 256) splits = 256;
+    const int det = sba_det_on() ? 1 : 0;
+    if (det) splits = 1;
     SBA_DISPATCH(dtype, SBA_LAUNCH((adain_bwd_reduce_kernel<T>), dim3(N, splits), dim3(256),
-                                           2 * C * sizeof(float), (hipStream_t)stream, (const T*)h,
-                                           (const T*)dout, mean, rstd, red, HW, C, dcs, dco));
+                                           (det ? rpi : 1) * 2 * C * sizeof(float), (hipStream_t)stream, (const T*)h,
+                                           (const T*)dout, mean, rstd, red, HW, C, dcs, dco, det));
     return SBA_CHECK_LAUNCH();
 }
 

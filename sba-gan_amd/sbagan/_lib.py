@@ -108,6 +108,10 @@ SIGNATURES = {
     'sba_bert_attention': [I, P, P, I, I, I, I, P],
     'sba_bert_gelu': [I, P, L, P],
     'sba_bert_tanh_transpose': [I, P, P, I, I, I, P],
+    'sba_set_deterministic': [I, P, L],
+    'sba_det_reset': [],
+    'sba_get_deterministic': [],      # (returns the flag, not a status)
+    'sba_bn_stat_slots': [],          # (returns the compiled replica count)
     'sba_replay_create': [P, I, I, POINTER(c_void_p)],
     'sba_replay_launch': [P, P],
     'sba_replay_info': [P, POINTER(c_int)],
@@ -120,6 +124,8 @@ for _name, _args in SIGNATURES.items():
     _fn.restype = c_int
 lib.sba_version.restype = c_char_p
 lib.sba_version.argtypes = []
+lib.sba_det_high_water.restype = c_int64
+lib.sba_det_high_water.argtypes = []
 
 _ERR = {-1: 'SBA_E_ARG (unsupported shape/alignment/enum)', -2: 'SBA_E_LAUNCH (HIP launch failed)',
         -3: 'SBA_E_UNSUPPORTED (graph node kind the replayer cannot re-issue)'}

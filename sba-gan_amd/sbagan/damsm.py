@@ -15,6 +15,7 @@ import torch.nn as nn
 from miscc.config import cfg
 from miscc.losses import sent_loss, words_loss
 
+from . import ops
 from .trainer import FlatParams, FusedAdam
 
 
@@ -70,6 +71,7 @@ class DAMSMStep(object):
 
     def step(self, img, captions, cap_lens, class_ids):
         """Returns the four loss terms as device scalars."""
+        ops.det_reset()
         self.flat.zero_grad()
         w0, w1, s0, s1 = self.losses(img, captions, cap_lens, class_ids)
         loss = w0 + w1 + s0 + s1

@@ -252,6 +252,11 @@ class _FcBnGlu(nn.Sequential):
         return self[1]
 
     def forward(self, x):
+        if not self[1].training and torch.is_grad_enabled() and \
+                (x.requires_grad or self[0].weight.requires_grad or self[1].weight.requires_grad):
+            # (checked here: grad mode is always off inside autograd.Function.forward)
+            raise RuntimeError('INIT_STAGE_G.fc in eval mode is an inference path (running statistics, no backward): '
+                               'call the generator under torch.no_grad()')
         return ops.FcBnGluFn.apply(x, self[0].weight, self[1].weight, self[1].bias, self)
 
 

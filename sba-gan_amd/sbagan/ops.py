@@ -512,8 +512,42 @@ def wgrad_tail_stream():
     return comp
 
 
-BN_STAT_SLOTS = int(os.environ.get('SBA_BN_STAT_SLOTS', '8'))   # = SBA_BN_STAT_SLOTS the library was built with
-#                                                                  (include/sbagan_hip.h; the env var is for A/B builds)
+BN_STAT_SLOTS = _lib.lib.sba_bn_stat_slots()      # the replica count the library was COMPILED with (its kernels index
+#                                                   the statistics buffers with it; include/sbagan_hip.h)
+
+
+# ---- deterministic-reduction mode (include/sbagan_hip.h: sba_set_deterministic) ------------------------------
+_DET_SCRATCH = [None]
+DET_SCRATCH_BYTES = int(os.environ.get('SBA_DET_SCRATCH_MB', '2048')) << 20
+
+
+def set_deterministic(flag, device=None):
+    """Turn the library's deterministic-reduction mode on / off: with it on, two runs of the same launches on the
+    same inputs are bit-identical in every launch mode (eager, hipGraph, native replayer).  Allocates the scratch
+    ring the ordered reductions use (SBA_DET_SCRATCH_MB, default 2 GiB).  Call while the device is idle."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if flag:
+        dev = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+        if _DET_SCRATCH[0] is None or _DET_SCRATCH[0].device != dev:
+            _DET_SCRATCH[0] = torch.empty(DET_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+        call('sba_set_deterministic', 1, _DET_SCRATCH[0].data_ptr(), DET_SCRATCH_BYTES)
+    else:
+        call('sba_set_deterministic', 0, None, 0)
+
+
+def deterministic():
+    return bool(_lib.lib.sba_get_deterministic())
+
+
+def det_reset():
+    """Rewind the scratch ring of the deterministic mode (start of a step / before a capture)."""
+    if _lib.lib.sba_get_deterministic():
+        call('sba_det_reset')
+
+
+if os.environ.get('SBA_DETERMINISTIC', '0') == '1' and torch.cuda.is_available():
+    set_deterministic(True)
 
 
 class BNState(object):
@@ -740,9 +774,8 @@ class FcBnGluFn(torch.autograd.Function):
         out = torch.empty((B, F // 32, 4, 4), dtype=COMPUTE_DTYPE, device=x.device, memory_format=CL)
         if not bn.training:
             # inference (netG.eval(): trainer.py:368 sampling / :437 gen_example): running statistics, plain
-            # tensor ops -- this layer runs once per generated batch and is off the training path
-            if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
-                raise RuntimeError('INIT_STAGE_G.fc in eval mode is an inference path: call it under torch.no_grad()')
+            # tensor ops -- this layer runs once per generated batch and is off the training path (nets._FcBnGlu
+            # refuses the call when a gradient could be asked of it)
             yn = (y - bn.running_mean) * torch.rsqrt(bn.running_var + BN_EPS) * bn.weight + bn.bias
             glu = yn[:, :F // 2] * torch.sigmoid(yn[:, F // 2:])
             return glu.view(B, F // 32, 4, 4).to(COMPUTE_DTYPE).contiguous(memory_format=CL)

@@ -177,6 +177,7 @@ class GANStep(object):
     # loss, backward, Adam + EMA.  step() composes them with the eager stream forks.
     def phase_a(self, sent_emb, words_embs, mask, noise, eps=None):
         ops.SIDE_WGRAD = self.overlap_wgrad
+        ops.det_reset()                       # deterministic mode: the step's partial sums start at the ring's base
         ops.ARENA.begin(self.device)          # one memset for all per-layer accumulators of the step
         self.netG.ca_net.eps = eps
         fake_imgs, _, mu, logvar = self.netG(noise, sent_emb, words_embs, mask)
@@ -190,7 +191,6 @@ class GANStep(object):
         behind them (the reference evaluates them inside generator_loss, after the updates: ~4.5 ms of the
         critical path at B=20)."""
         fake_imgs = self._ctx[0]
-        ops.SIDE_WGRAD = False
         self._damsm = damsm_image_terms(self.image_encoder, fake_imgs[-1], words_embs, sent_emb, self.match_labels,
                                         cap_lens, class_ids)
 
@@ -226,6 +226,7 @@ class GANStep(object):
     def phase_b_bwd(self, sent_emb, words_embs, cap_lens, class_ids):
         fake_imgs, mu, logvar = self._ctx
         mark = self._mark
+        ops.SIDE_WGRAD = self.overlap_wgrad
         for p in self._d_params:
             p.requires_grad_(False)
         self.flatG.zero_grad()

@@ -14,11 +14,17 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'statistical: compares two runs of the DEFAULT (atomic-order dependent) mode with '
+                                       'fixed noise bounds; ordered after every oracle / golden / boundary test')
 
 
 def pytest_collection_modifyitems(config, items):
-    """GPU tests are skipped (not failed) when no device is visible, so a bare
-    `pytest tests/` stays green in the CPU-only build container."""
+    """Order: every test that compares with the oracle, the reference's golden vectors or the boundary contract
+    first; the few `statistical` tests (run-to-run comparisons of the default, atomic-order dependent mode) last, so
+    that `pytest -x` reaches every parity test before any noise-bounded one.
+    GPU tests are skipped (not failed) when no device is visible, so a bare `pytest tests/` stays green in the
+    CPU-only build container."""
+    items.sort(key=lambda it: 1 if 'statistical' in it.keywords else 0)     # (stable: file order otherwise kept)
     import torch
     if torch.cuda.is_available():
         return

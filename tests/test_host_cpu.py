@@ -19,7 +19,7 @@ def _header_decls():
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     decls = {}
     for m in re.finditer(r'\bint\s+(sba_\w+)\s*\(([^;]*?)\)\s*;', txt, flags=re.S):
-        args = [a for a in m.group(2).split(',') if a.strip()]
+        args = [a for a in m.group(2).split(',') if a.strip() and a.strip() != 'void']
         decls[m.group(1)] = len(args)
     return decls
 
