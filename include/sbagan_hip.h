@@ -27,6 +27,12 @@ extern "C" {
 
 #define SBA_F32 0
 #define SBA_BF16 1
+/* bf16 activations / packed weights as SBA_BF16, but the RAW conv output y -- the pre-BatchNorm tensor, which is
+ * only ever read by the BatchNorm kernels, never an MFMA operand -- is stored as IEEE binary16 (values saturate
+ * at +-65504): three more mantissa bits at the same bytes, which removes one of the two bf16 roundings per
+ * conv + BatchNorm + activation layer.  Accepted by sba_conv_igemm (no addend / bias / ReLU / mask epilogue) and by
+ * the sba_bn_* entry points (where it describes y; out, dout, residual and dy stay bf16). */
+#define SBA_BF16_YH 2
 
 #define SBA_OK 0
 #define SBA_E_ARG (-1)      /* shape / alignment / enum argument the kernels do not support */

@@ -19,6 +19,14 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return __builtin_bit_cast(bf16_t, b);
 }
 
+// IEEE binary16 storage of the pre-BatchNorm conv outputs (SBA_BF16_YH): same bytes as bf16, 3 more mantissa bits
+typedef _Float16 f16_t;
+__device__ __forceinline__ bf16_t f2h_bits(float f) {      // saturating, RNE; returned as the 16 raw bits
+    f = fminf(fmaxf(f, -65504.f), 65504.f);
+    const f16_t h = (f16_t)f;
+    return __builtin_bit_cast(bf16_t, h);
+}
+
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
@@ -39,6 +47,12 @@ template <> struct Vec16<bf16_t> {
     uint4 v;
     __device__ __forceinline__ float get(int i) const { return bf2f(((const bf16_t*)&v)[i]); }
     __device__ __forceinline__ void set(int i, float f) { ((bf16_t*)&v)[i] = f2bf(f); }
+};
+template <> struct Vec16<f16_t> {
+    static constexpr int N = 8;
+    uint4 v;
+    __device__ __forceinline__ float get(int i) const { return (float)((const f16_t*)&v)[i]; }
+    __device__ __forceinline__ void set(int i, float f) { ((f16_t*)&v)[i] = (f16_t)f; }
 };
 template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
     Vec16<T> r;
@@ -92,6 +106,14 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
     do {                                                \
         if ((dtype) == SBA_F32) { using T = float; CALL; }        \
         else if ((dtype) == SBA_BF16) { using T = bf16_t; CALL; } \
+        else return SBA_E_ARG;                          \
+    } while (0)
+// T = activation storage type, YT = storage type of the raw conv output y (SBA_BF16_YH: binary16)
+#define SBA_DISPATCH_Y(dtype, CALL)                     \
+    do {                                                \
+        if ((dtype) == SBA_F32) { using T = float; using YT = float; CALL; }            \
+        else if ((dtype) == SBA_BF16) { using T = bf16_t; using YT = bf16_t; CALL; }    \
+        else if ((dtype) == SBA_BF16_YH) { using T = bf16_t; using YT = f16_t; CALL; }  \
         else return SBA_E_ARG;                          \
     } while (0)
 

@@ -35,7 +35,8 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
 // ---------------------------------------------------------------------------
 // optional epilogue operands: per-channel bias, and a ReLU mask source (same layout as y): outputs are
 // zeroed where mask <= 0 -- the backward of the ReLU that produced the tensor whose gradient this is
-struct EpiX { const float* bias; const void* mask; };
+// yh: store the (bf16-typed) output as IEEE binary16 bits (SBA_BF16_YH: the pre-BatchNorm tensor)
+struct EpiX { const float* bias; const void* mask; int yh; };
 
 // keep the bf16 halves of v whose counterpart in m is > 0
 __device__ __forceinline__ uint32_t relu_mask_bf16x2(uint32_t v, uint32_t m) {
@@ -138,7 +139,8 @@ __device__ __forceinline__ void tile_epilogue(f32x16_t (&acc)[TM][TN], const boo
                 if (g.relu) v = fmaxf(v, 0.f);
                 if (kStageOut) {
                     // (the main loop's last barrier has passed: the staging buffers are free)
-                    *reinterpret_cast<T*>(lds_all + row * OROW + (wn0 + j * 32 + col_l) * 2) = from_f<T>(v);
+                    *reinterpret_cast<bf16_t*>(lds_all + row * OROW + (wn0 + j * 32 + col_l) * 2) =
+                        ex.yh ? f2h_bits(v) : f2bf(v);
                 } else {
                     const int pix = rowoff[row];
                     if (pix >= 0 && co < g.Cout) {
@@ -2304,7 +2306,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ 
             if (g.relu) v[k] = fmaxf(v[k], 0.f);
             if (addend) v[k] += to_f<T>(av[k]);
             if (ex.mask && !(to_f<T>(mv[k]) > 0.f)) v[k] = 0.f;
-            ov[k] = from_f<T>(v[k]);
+            if (sizeof(T) == 2 && ex.yh) *reinterpret_cast<bf16_t*>(&ov[k]) = f2h_bits(v[k]);
+            else ov[k] = from_f<T>(v[k]);
         }
         *reinterpret_cast<V4*>(y + o) = *reinterpret_cast<const V4*>(ov);
     }
@@ -2466,7 +2469,7 @@ static void launch_halo(const sba_conv_geom& g, const bf16_t* x, const bf16_t* w
 template <typename T>
 int launch_igemm(const void* x, const void* w, void* y, const void* addend, float* stats,
                  const sba_conv_geom& g, void* workspace, int64_t ws_bytes, hipStream_t st,
-                 const EpiX ex = EpiX{nullptr, nullptr}) {
+                 const EpiX ex = EpiX{nullptr, nullptr, 0}) {
     const int M = g.N * g.OHs * g.OWs;
     const T* xp = (const T*)x; const T* wp = (const T*)w; T* yp = (T*)y; const T* ap = (const T*)addend;
     if (sizeof(T) == 2 && halo_ok(g)) {
@@ -2613,6 +2616,19 @@ bool dense_output(const sba_conv_geom& g) {
 extern "C" int sba_conv_igemm(int dtype, const void* x, const void* w, void* y, const void* addend,
                               float* stats, const sba_conv_geom* g, void* workspace, int64_t workspace_bytes,
                               void* stream) {
+    if (dtype == SBA_BF16_YH) {
+        // bf16 operands, y stored as binary16 (the pre-BatchNorm tensor: include/sbagan_hip.h)
+        if (!x || !w || !y || !geom_ok(g, SBA_BF16) || addend || g->relu || g->Cout % 8) return SBA_E_ARG;
+        if (((uintptr_t)workspace & 15) != 0) return SBA_E_ARG;
+        const EpiX ex{nullptr, nullptr, 1};
+        if (sba_det_on() && stats) {
+            if (!dense_output(*g)) return SBA_E_ARG;
+            const int rc = launch_igemm<bf16_t>(x, w, y, nullptr, nullptr, *g, workspace, workspace_bytes, (hipStream_t)stream, ex);
+            if (rc != SBA_OK) return rc;
+            return sba_bn_stats(dtype, y, stats, (int64_t)g->N * g->OH * g->OW, 1, g->Cout, stream);
+        }
+        return launch_igemm<bf16_t>(x, w, y, nullptr, stats, *g, workspace, workspace_bytes, (hipStream_t)stream, ex);
+    }
     if (!x || !w || !y || !geom_ok(g, dtype)) return SBA_E_ARG;
     if (((uintptr_t)workspace & 15) != 0) return SBA_E_ARG;
     if (sba_det_on() && stats) {
@@ -2637,7 +2653,7 @@ extern "C" int sba_conv_igemm_bias(int dtype, const void* x, const void* w, void
     if (((uintptr_t)workspace & 15) != 0) return SBA_E_ARG;
     if (sba_det_on() && stats) return SBA_E_ARG;        // (no caller asks for statistics behind a bias / ReLU epilogue)
     SBA_DISPATCH(dtype, return launch_igemm<T>(x, w, y, addend, stats, *g, workspace, workspace_bytes,
-                                               (hipStream_t)stream, EpiX{bias, relu_mask}));
+                                               (hipStream_t)stream, EpiX{bias, relu_mask, 0}));
     return SBA_E_ARG;
 }
 

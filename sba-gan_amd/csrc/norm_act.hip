@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y_a
 // LDS (C rsqrt: noise next to the streaming pass); workgroup (0, g) also stores aux[g] = scale,
 // shift, mean, rstd for the backward, and workgroup (0, 0) applies the running-statistics updates
 // of all groups in order (momentum, unbiased variance), as consecutive module calls would.
-template <typename T, int ACT>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y_all, const float* __restrict__ stats_all,
+template <typename T, typename YT, int ACT>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const YT* __restrict__ y_all, const float* __restrict__ stats_all,
                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                   float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ nbt,
                                   float* __restrict__ aux_all, const T* __restrict__ residual_all,
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
     __syncthreads();
     const float* scale = s_co;
     const float* shift = s_co + C;
-    const T* y = y_all + (int64_t)g * rows * C;
+    const YT* y = y_all + (int64_t)g * rows * C;
     const T* residual = residual_all ? residual_all + (int64_t)g * rows * Co : nullptr;
     T* out = out_all + (int64_t)g * rows * out_cstride;
     const int cv = Co / V;
@@ -141,9 +141,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / cv;
         const int c = (int)(i - row * cv) * V;
-        Vec16<T> a = ld16(y + row * C + c), o;
+        Vec16<YT> a = ld16(y + row * C + c);
+        Vec16<T> o;
         if (ACT == SBA_ACT_GLU) {
-            Vec16<T> gt = ld16(y + row * C + Co + c);
+            Vec16<YT> gt = ld16(y + row * C + Co + c);
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 const float n = a.get(k) * scale[c + k] + shift[c + k];
@@ -167,13 +168,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 
 // ---- backward pass 1: per-channel sum(dz), sum(dz*xhat); blockIdx.y = group ----
 // thread mapping: each thread keeps a fixed set of channel vectors and strides over rows
-template <typename T, int ACT>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ y_all, const T* __restrict__ dout_all,
+template <typename T, typename YT, int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const YT* __restrict__ y_all, const T* __restrict__ dout_all,
                                      const float* __restrict__ aux_all, float* __restrict__ red_all,
                                      int64_t rows, int C, int dcs, int dco, float* __restrict__ det_part) {
     constexpr int V = Vec16<T>::N;
     const int g = blockIdx.y;
-    const T* y = y_all + (int64_t)g * rows * C;
+    const YT* y = y_all + (int64_t)g * rows * C;
     const T* dout = dout_all + (int64_t)g * rows * dcs;
     const float* scale = aux_all + (int64_t)g * 4 * C;
     const float* shift = scale + C;
@@ -206,10 +207,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         }
 #pragma unroll 2
         for (int64_t row = (int64_t)blockIdx.x * rpi + tr; row < rows; row += (int64_t)gridDim.x * rpi) {
-            Vec16<T> a = ld16(y + row * C + c);
+            Vec16<YT> a = ld16(y + row * C + c);
             Vec16<T> d = ld16(dout + row * dcs + dco + c);
             if (ACT == SBA_ACT_GLU) {
-                Vec16<T> gt = ld16(y + row * C + Co + c);
+                Vec16<YT> gt = ld16(y + row * C + Co + c);
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
                     const float n = a.get(k) * sc[k] + sh[k];
@@ -272,8 +273,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 
 // ---- backward pass 2: dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat)); blockIdx.y = group ----
 // per-channel coefficients live in LDS: A = scale, B = shift, M = mean, R = rstd, P = red0/rows, Q = red1/rows
-template <typename T, int ACT>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ y_all, const T* __restrict__ dout_all,
+template <typename T, typename YT, int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const YT* __restrict__ y_all, const T* __restrict__ dout_all,
                                     const float* __restrict__ aux_all, const float* __restrict__ red_all,
                                     T* __restrict__ dy_all, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                     int64_t rows, int C, int dcs, int dco) {
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const float* rstd = s_k + 3 * C;
     const float* P = s_k + 4 * C;
     const float* Q = s_k + 5 * C;
-    const T* y = y_all + (int64_t)g * rows * C;
+    const YT* y = y_all + (int64_t)g * rows * C;
     const T* dout = dout_all + (int64_t)g * rows * dcs;
     T* dy = dy_all + (int64_t)g * rows * C;
     const int Co = ACT == SBA_ACT_GLU ? C / 2 : C;
@@ -315,11 +316,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / cv;
         const int c = (int)(i - row * cv) * V;
-        Vec16<T> a = ld16(y + row * C + c);
+        Vec16<YT> a = ld16(y + row * C + c);
         Vec16<T> d = ld16(dout + row * dcs + dco + c);
         Vec16<T> o;
         if (ACT == SBA_ACT_GLU) {
-            Vec16<T> gt = ld16(y + row * C + Co + c), og;
+            Vec16<YT> gt = ld16(y + row * C + Co + c);
+            Vec16<T> og;
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 const int ca = c + k, cg = Co + c + k;
@@ -354,8 +356,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // a conv epilogue (grouped real|fake passes): statistics, finalize, running-stat update and normalise in
 // ONE launch.  A workgroup owns V channels (+ their V gate channels for GLU) over all rows and walks
 // the groups in order, so the running statistics see the same sequence as consecutive module calls.
-template <typename T, int ACT>
-__global__ __launch_bounds__(256) void bn_fwd_fused_kernel(const T* __restrict__ y_all, const float* __restrict__ gamma,
+template <typename T, typename YT, int ACT>
+__global__ __launch_bounds__(256) void bn_fwd_fused_kernel(const YT* __restrict__ y_all, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ rmean,
                                                            float* __restrict__ rvar, int64_t* __restrict__ nbt,
                                                            float* __restrict__ aux_all, T* __restrict__ out_all,
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256) void bn_fwd_fused_kernel(const T* __restrict__
     const float count = (float)rows;
     if (blockIdx.x == 0 && tid == 0 && nbt) *nbt += groups;
     for (int g = 0; g < groups; ++g) {
-        const T* y = y_all + (int64_t)g * rows * C;
+        const YT* y = y_all + (int64_t)g * rows * C;
         T* out = out_all + (int64_t)g * rows * out_cstride;
         float* aux = aux_all + (int64_t)g * 4 * C;
         float s0[NV][V], s1[NV][V];
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256) void bn_fwd_fused_kernel(const T* __restrict__
         for (int64_t row = tid; row < rows; row += 256) {
 #pragma unroll
             for (int h = 0; h < NV; ++h) {
-                Vec16<T> a = ld16(y + row * C + c + h * Co);
+                Vec16<YT> a = ld16(y + row * C + c + h * Co);
 #pragma unroll
                 for (int k = 0; k < V; ++k) { const float v = a.get(k); s0[h][k] += v; s1[h][k] += v * v; }
             }
@@ -414,9 +416,10 @@ __global__ __launch_bounds__(256) void bn_fwd_fused_kernel(const T* __restrict__
         }
         __syncthreads();
         for (int64_t row = tid; row < rows; row += 256) {
-            Vec16<T> a = ld16(y + row * C + c), o;
+            Vec16<YT> a = ld16(y + row * C + c);
+            Vec16<T> o;
             if (ACT == SBA_ACT_GLU) {
-                Vec16<T> gt = ld16(y + row * C + Co + c);
+                Vec16<YT> gt = ld16(y + row * C + Co + c);
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
                     const float n = a.get(k) * s_co[k * 2] + s_co[k * 2 + 1];
@@ -441,8 +444,8 @@ __global__ __launch_bounds__(256) void bn_fwd_fused_kernel(const T* __restrict__
 // the discriminator tails and the generator's first stage): a workgroup owns V channels (and, for GLU,
 // their V gate channels) over ALL rows of one group, so both the reduction and the apply pass are
 // workgroup-local -- no global accumulator, no second launch.  blockIdx.x = channel vector, .y = group.
-template <typename T, int ACT>
-__global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const T* __restrict__ y_all, const T* __restrict__ dout_all,
+template <typename T, typename YT, int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const YT* __restrict__ y_all, const T* __restrict__ dout_all,
                                                            const float* __restrict__ aux_all, T* __restrict__ dy_all,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            int64_t rows, int C, int dcs, int dco) {
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const T* __restrict__
     const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int Co = ACT == SBA_ACT_GLU ? C / 2 : C;
     const int c = blockIdx.x * V;                           // first owned (value) channel
-    const T* y = y_all + (int64_t)g * rows * C;
+    const YT* y = y_all + (int64_t)g * rows * C;
     const T* dout = dout_all + (int64_t)g * rows * dcs;
     T* dy = dy_all + (int64_t)g * rows * C;
     const float* aux = aux_all + (int64_t)g * 4 * C;
@@ -472,10 +475,10 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const T* __restrict__
         for (int k = 0; k < V; ++k) { s0[h][k] = 0.f; s1[h][k] = 0.f; }
     // dz of one row for the owned channels
     auto dz_row = [&](int64_t row, float (&dz)[NV][V], float (&xh)[NV][V]) {
-        Vec16<T> a = ld16(y + row * C + c);
+        Vec16<YT> a = ld16(y + row * C + c);
         Vec16<T> d = ld16(dout + row * dcs + dco + c);
         if (ACT == SBA_ACT_GLU) {
-            Vec16<T> gt = ld16(y + row * C + Co + c);
+            Vec16<YT> gt = ld16(y + row * C + Co + c);
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 const float n = a.get(k) * sc[0][k] + sh[0][k];
@@ -797,7 +800,7 @@ inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 extern "C" int sba_bn_stats(int dtype, const void* y, float* stats, int64_t rows, int groups, int C,
                             void* stream) {
-    const int V = dtype == SBA_BF16 ? 8 : 4;
+    const int V = dtype != SBA_F32 ? 8 : 4;
     if (!y || !stats || rows <= 0 || groups <= 0 || groups > 65535 || C <= 0 || C % V || !pow2(C / V) || C > 4096)
         return SBA_E_ARG;
     const int cv = C / V;
@@ -817,8 +820,8 @@ extern "C" int sba_bn_stats(int dtype, const void* y, float* stats, int64_t rows
         if (!part) return SBA_E_ARG;
         sh *= rpi;
     }
-    SBA_DISPATCH(dtype, SBA_LAUNCH((bn_stats_kernel<T>), dim3(blocks, groups), dim3(256), sh, (hipStream_t)stream,
-                                   (const T*)y, stats, rows, C, part));
+    SBA_DISPATCH_Y(dtype, SBA_LAUNCH((bn_stats_kernel<YT>), dim3(blocks, groups), dim3(256), sh, (hipStream_t)stream,
+                                     (const YT*)y, stats, rows, C, part));
     // deterministic mode: the workgroups' partial sums are added in workgroup order into replica 0 (the others stay zero)
     if (part) sba_det_fold(part, groups, blocks, 2 * C, stats, (int64_t)SBA_BN_STAT_SLOTS * 2 * C, 0, (hipStream_t)stream);
     return SBA_CHECK_LAUNCH();
@@ -833,7 +836,7 @@ extern "C" int sba_bn_stats(int dtype, const void* y, float* stats, int64_t rows
     }
 
 static bool bn_shape_ok(int dtype, int64_t rows, int groups, int C, int act) {
-    const int V = dtype == SBA_BF16 ? 8 : 4;
+    const int V = dtype != SBA_F32 ? 8 : 4;
     const int Co = act == SBA_ACT_GLU ? C / 2 : C;
     return rows > 0 && groups > 0 && groups <= 65535 && C > 0 && pow2(C) && Co % V == 0 && C <= 4096;
 }
@@ -848,12 +851,12 @@ extern "C" int sba_bn_act_fwd(int dtype, const void* y, const float* stats, cons
     if ((running_mean == nullptr) != (running_var == nullptr)) return SBA_E_ARG;
     if (act == SBA_ACT_GLU && residual) return SBA_E_ARG;
     const int Co = act == SBA_ACT_GLU ? C / 2 : C;
-    const int V = dtype == SBA_BF16 ? 8 : 4;
+    const int V = dtype != SBA_F32 ? 8 : 4;
     if (out_cstride < Co + out_coff || out_cstride % V || out_coff % V) return SBA_E_ARG;
     const int blocks = grid_for(rows * (Co / V));
     const size_t sh = 2 * (size_t)C * sizeof(float);
-    SBA_DISPATCH(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_act_fwd_kernel<T, ACT>), dim3(blocks, groups),
-                                                           dim3(256), sh, (hipStream_t)stream, (const T*)y, stats,
+    SBA_DISPATCH_Y(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_act_fwd_kernel<T, YT, ACT>), dim3(blocks, groups),
+                                                           dim3(256), sh, (hipStream_t)stream, (const YT*)y, stats,
                                                            gamma, beta, running_mean, running_var,
                                                            num_batches_tracked, aux, (const T*)residual, (T*)out,
                                                            rows, C, out_cstride, out_coff, eps, momentum,
@@ -865,7 +868,7 @@ extern "C" int sba_bn_act_bwd_reduce(int dtype, const void* y, const void* dout,
                                      int64_t rows, int groups, int C, int act, int dcs, int dco, void* stream) {
     if (!y || !dout || !aux || !red || !bn_shape_ok(dtype, rows, groups, C, act)) return SBA_E_ARG;
     const int Co = act == SBA_ACT_GLU ? C / 2 : C;
-    const int V = dtype == SBA_BF16 ? 8 : 4;
+    const int V = dtype != SBA_F32 ? 8 : 4;
     if (dcs < Co + dco || dcs % V || dco % V) return SBA_E_ARG;
     const int cv = Co / V;
     const int rpi = cv < 256 ? 256 / cv : 1;
@@ -884,8 +887,8 @@ extern "C" int sba_bn_act_bwd_reduce(int dtype, const void* y, const void* dout,
         if (!part) return SBA_E_ARG;
         sh *= rpi;
     }
-    SBA_DISPATCH(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_reduce_kernel<T, ACT>), dim3(blocks, groups),
-                                                           dim3(256), sh, (hipStream_t)stream, (const T*)y,
+    SBA_DISPATCH_Y(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_reduce_kernel<T, YT, ACT>), dim3(blocks, groups),
+                                                           dim3(256), sh, (hipStream_t)stream, (const YT*)y,
                                                            (const T*)dout, aux, red, rows, C, dcs, dco, part)));
     if (part) sba_det_fold(part, groups, blocks, 2 * C, red, (int64_t)SBA_BN_STAT_SLOTS * 2 * C, 0, (hipStream_t)stream);
     return SBA_CHECK_LAUNCH();
@@ -897,27 +900,27 @@ extern "C" int sba_bn_act_bwd_apply(int dtype, const void* y, const void* dout, 
     if (!y || !dout || !aux || !red || !dy || !bn_shape_ok(dtype, rows, groups, C, act)) return SBA_E_ARG;
     if ((dgamma == nullptr) != (dbeta == nullptr)) return SBA_E_ARG;
     const int Co = act == SBA_ACT_GLU ? C / 2 : C;
-    const int V = dtype == SBA_BF16 ? 8 : 4;
+    const int V = dtype != SBA_F32 ? 8 : 4;
     if (dcs < Co + dco || dcs % V || dco % V) return SBA_E_ARG;
     const int blocks = grid_for(rows * (Co / V));
     const size_t sh = 6 * (size_t)C * sizeof(float);
     if (sba_det_on() && groups > 1 && dgamma) {
         // the groups add into the same dgamma / dbeta: one launch per group, in group order
-        const int64_t esz = dtype == SBA_BF16 ? 2 : 4;
+        const int64_t esz = dtype != SBA_F32 ? 2 : 4;
         for (int g = 0; g < groups; ++g) {
             const char* yg = (const char*)y + (int64_t)g * rows * C * esz;
             const char* dg = (const char*)dout + (int64_t)g * rows * dcs * esz;
             char* dyg = (char*)dy + (int64_t)g * rows * C * esz;
             const float* auxg = aux + (int64_t)g * 4 * C;
             const float* redg = red + (int64_t)g * SBA_BN_STAT_SLOTS * 2 * C;
-            SBA_DISPATCH(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_apply_kernel<T, ACT>), dim3(blocks, 1), dim3(256), sh,
-                                                           (hipStream_t)stream, (const T*)yg, (const T*)dg, auxg, redg,
+            SBA_DISPATCH_Y(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_apply_kernel<T, YT, ACT>), dim3(blocks, 1), dim3(256), sh,
+                                                           (hipStream_t)stream, (const YT*)yg, (const T*)dg, auxg, redg,
                                                            (T*)dyg, dgamma, dbeta, rows, C, dcs, dco)));
         }
         return SBA_CHECK_LAUNCH();
     }
-    SBA_DISPATCH(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_apply_kernel<T, ACT>), dim3(blocks, groups),
-                                                           dim3(256), sh, (hipStream_t)stream, (const T*)y,
+    SBA_DISPATCH_Y(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_apply_kernel<T, YT, ACT>), dim3(blocks, groups),
+                                                           dim3(256), sh, (hipStream_t)stream, (const YT*)y,
                                                            (const T*)dout, aux, red, (T*)dy, dgamma, dbeta, rows, C,
                                                            dcs, dco)));
     return SBA_CHECK_LAUNCH();
@@ -930,10 +933,10 @@ extern "C" int sba_bn_act_fwd_fused(int dtype, const void* y, const float* gamma
     if (!y || !gamma || !beta || !aux || !out || !bn_shape_ok(dtype, rows, groups, C, act)) return SBA_E_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return SBA_E_ARG;
     const int Co = act == SBA_ACT_GLU ? C / 2 : C;
-    const int V = dtype == SBA_BF16 ? 8 : 4;
+    const int V = dtype != SBA_F32 ? 8 : 4;
     if (out_cstride < Co + out_coff || out_cstride % V || out_coff % V) return SBA_E_ARG;
-    SBA_DISPATCH(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_fwd_fused_kernel<T, ACT>), dim3(Co / V), dim3(256), 0,
-                                                           (hipStream_t)stream, (const T*)y, gamma, beta,
+    SBA_DISPATCH_Y(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_fwd_fused_kernel<T, YT, ACT>), dim3(Co / V), dim3(256), 0,
+                                                           (hipStream_t)stream, (const YT*)y, gamma, beta,
                                                            running_mean, running_var, num_batches_tracked, aux,
                                                            (T*)out, rows, groups, C, out_cstride, out_coff, eps,
                                                            momentum)));
@@ -946,23 +949,23 @@ extern "C" int sba_bn_act_bwd_fused(int dtype, const void* y, const void* dout, 
     if (!y || !dout || !aux || !dy || !bn_shape_ok(dtype, rows, groups, C, act)) return SBA_E_ARG;
     if ((dgamma == nullptr) != (dbeta == nullptr)) return SBA_E_ARG;
     const int Co = act == SBA_ACT_GLU ? C / 2 : C;
-    const int V = dtype == SBA_BF16 ? 8 : 4;
+    const int V = dtype != SBA_F32 ? 8 : 4;
     if (dcs < Co + dco || dcs % V || dco % V) return SBA_E_ARG;
     if (sba_det_on() && groups > 1 && dgamma) {
-        const int64_t esz = dtype == SBA_BF16 ? 2 : 4;
+        const int64_t esz = dtype != SBA_F32 ? 2 : 4;
         for (int g = 0; g < groups; ++g) {
             const char* yg = (const char*)y + (int64_t)g * rows * C * esz;
             const char* dg = (const char*)dout + (int64_t)g * rows * dcs * esz;
             char* dyg = (char*)dy + (int64_t)g * rows * C * esz;
             const float* auxg = aux + (int64_t)g * 4 * C;
-            SBA_DISPATCH(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_fused_kernel<T, ACT>), dim3(Co / V, 1), dim3(256), 0,
-                                                           (hipStream_t)stream, (const T*)yg, (const T*)dg, auxg,
+            SBA_DISPATCH_Y(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_fused_kernel<T, YT, ACT>), dim3(Co / V, 1), dim3(256), 0,
+                                                           (hipStream_t)stream, (const YT*)yg, (const T*)dg, auxg,
                                                            (T*)dyg, dgamma, dbeta, rows, C, dcs, dco)));
         }
         return SBA_CHECK_LAUNCH();
     }
-    SBA_DISPATCH(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_fused_kernel<T, ACT>), dim3(Co / V, groups),
-                                                           dim3(256), 0, (hipStream_t)stream, (const T*)y,
+    SBA_DISPATCH_Y(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_bwd_fused_kernel<T, YT, ACT>), dim3(Co / V, groups),
+                                                           dim3(256), 0, (hipStream_t)stream, (const YT*)y,
                                                            (const T*)dout, aux, (T*)dy, dgamma, dbeta, rows, C, dcs,
                                                            dco)));
     return SBA_CHECK_LAUNCH();
@@ -991,7 +994,7 @@ extern "C" int sba_bn1d_glu_bwd(int dtype, const float* y, const void* dout, con
 }
 
 static bool in_shape_ok(int dtype, int N, int HW, int C) {
-    const int V = dtype == SBA_BF16 ? 8 : 4;
+    const int V = dtype != SBA_F32 ? 8 : 4;
     return N > 0 && HW > 0 && C > 0 && C % V == 0 && C / V <= 256 && pow2(C / V);
 }
 
@@ -1000,7 +1003,7 @@ extern "C" int sba_instnorm_stats(int dtype, const void* h, float* mean, float* 
     if (!h || !mean || !rstd || !in_shape_ok(dtype, N, HW, C)) return SBA_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     sba_zero_f32(mean, rstd, (int64_t)N * C, st);
-    const int V = dtype == SBA_BF16 ? 8 : 4;
+    const int V = dtype != SBA_F32 ? 8 : 4;
     const int rpi = 256 / (C / V);
     int splits = cdiv(HW, rpi * 16);
     if (splits > 256) splits = 256;
@@ -1016,7 +1019,7 @@ extern "C" int sba_instnorm_stats(int dtype, const void* h, float* mean, float* 
 extern "C" int sba_adain_fwd(int dtype, const void* h, const float* mean, const float* rstd, const float* style,
                              void* out, int N, int HW, int C, int ocs, int oco, void* stream) {
     if (!h || !mean || !rstd || !style || !out || !in_shape_ok(dtype, N, HW, C)) return SBA_E_ARG;
-    const int V = dtype == SBA_BF16 ? 8 : 4;
+    const int V = dtype != SBA_F32 ? 8 : 4;
     if (ocs < C + oco || ocs % V || oco % V) return SBA_E_ARG;
     const int blocks = grid_for((int64_t)N * HW * (C / V));
     SBA_DISPATCH(dtype, SBA_LAUNCH((adain_fwd_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
@@ -1028,7 +1031,7 @@ extern "C" int sba_adain_bwd_reduce(int dtype, const void* h, const void* dout, 
                                     const float* rstd, float* red, int N, int HW, int C, int dcs, int dco,
                                     void* stream) {
     if (!h || !dout || !mean || !rstd || !red || !in_shape_ok(dtype, N, HW, C)) return SBA_E_ARG;
-    const int V = dtype == SBA_BF16 ? 8 : 4;
+    const int V = dtype != SBA_F32 ? 8 : 4;
     if (dcs < C + dco || dcs % V || dco % V) return SBA_E_ARG;
     const int rpi = 256 / (C / V);
     int splits = cdiv(HW, rpi * 16);
@@ -1046,7 +1049,7 @@ extern "C" int sba_adain_bwd_apply(int dtype, const void* h, const void* dout, c
                                    float* dstyle, int N, int HW, int C, int dcs, int dco, int accumulate,
                                    void* stream) {
     if (!h || !dout || !mean || !rstd || !style || !red || !dh || !in_shape_ok(dtype, N, HW, C)) return SBA_E_ARG;
-    const int V = dtype == SBA_BF16 ? 8 : 4;
+    const int V = dtype != SBA_F32 ? 8 : 4;
     if (dcs < C + dco || dcs % V || dco % V) return SBA_E_ARG;
     const int blocks = grid_for((int64_t)N * HW * (C / V));
     SBA_DISPATCH(dtype, SBA_LAUNCH((adain_bwd_apply_kernel<T>), dim3(blocks), dim3(256), 0,

@@ -16,7 +16,7 @@ from ctypes import (POINTER, Structure, byref, c_char_p, c_float, c_int, c_int8,
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SBA_LIB_PATH') or os.path.join(os.path.dirname(_HERE), 'csrc', 'libsbagan_hip.so')
 
-SBA_F32, SBA_BF16 = 0, 1
+SBA_F32, SBA_BF16, SBA_BF16_YH = 0, 1, 2
 ACT_NONE, ACT_GLU, ACT_LRELU = 0, 1, 2
 MAX_TAPS = 32
 

@@ -57,7 +57,24 @@ def _dt(t):
         return _lib.SBA_F32
     if t.dtype == torch.bfloat16:
         return _lib.SBA_BF16
+    if t.dtype == torch.float16:        # a raw conv output y in the bf16 path (Y_F16 below)
+        return _lib.SBA_BF16_YH
     raise TypeError('unsupported activation dtype %s' % t.dtype)
+
+
+# bf16 path, optional (SBA_Y_F16=1): the RAW conv outputs (the pre-BatchNorm tensors y, read only by the BatchNorm
+# kernels, never an MFMA operand) stored as IEEE binary16 instead of bf16 -- the same bytes, three more mantissa bits:
+# one of the two roundings per conv + BatchNorm + activation layer shrinks by 8x (include/sbagan_hip.h: SBA_BF16_YH;
+# the epilogue saturates at +-65504).  Measured on the reference's B = 20 golden step in deterministic mode
+# (profiles/r03_bf16_rounding_points.txt): it moves the bf16 step's deviation from the reference by +-3e-4 in BOTH
+# directions (errD0 7.7e-4 -> 7.1e-4, errD2 9.3e-4 -> 1.2e-3): that deviation is a sum of ~30 roundings of ~1e-4 with
+# random signs (tools/bf16_bisect.py), no single tensor dominates it -- so the default stays plain bf16.
+Y_F16 = os.environ.get('SBA_Y_F16', '0') == '1'
+
+
+def _act_dtype(y):
+    """storage dtype of the activations around a raw conv output y"""
+    return torch.bfloat16 if y.dtype == torch.float16 else y.dtype
 
 
 def _p(t):
@@ -376,24 +393,29 @@ def tune_geom(g, dt):
 
 def _igemm(dt, x, w, y, addend, stats, g, device):
     ws = workspace(device)
-    tune_geom(g, dt)
+    tune_geom(g, _lib.SBA_BF16 if dt == _lib.SBA_BF16_YH else dt)
     call('sba_conv_igemm', dt, x, w, y, addend, stats, ctypes.byref(g), ws.data_ptr(), WORKSPACE_BYTES, _stream())
 
 
 # ----------------------------------------------------------------------------
 # raw (non-autograd) building blocks
 # ----------------------------------------------------------------------------
-def conv_forward(x, pw, kind, want_stats=True, addend=None):
+def conv_forward(x, pw, kind, want_stats=True, addend=None, pre_bn=False):
     """y = conv(x) in NHWC; returns (y, stats) with stats = BN_STAT_SLOTS replicas of the per-channel
-    (sum, sumsq) pair (add them up; see SBA_BN_STAT_SLOTS in sbagan_hip.h)."""
+    (sum, sumsq) pair (add them up; see SBA_BN_STAT_SLOTS in sbagan_hip.h).
+    pre_bn: y goes to a BatchNorm and nowhere else -- in the bf16 path it is then a float16 tensor (Y_F16)."""
     _need_gpu(x)
     N, Cin, H, W = x.shape
     O = pw.param.shape[0]
     OH, OW = _conv_out_hw(kind, H, W)
-    y = empty_act(N, O, OH, OW, x)
+    yh = pre_bn and Y_F16 and x.dtype == torch.bfloat16 and addend is None and O % 8 == 0
+    if yh:
+        y = torch.empty((N, O, OH, OW), dtype=torch.float16, device=x.device, memory_format=CL)
+    else:
+        y = empty_act(N, O, OH, OW, x)
     stats = zeros_f32((BN_STAT_SLOTS, 2 * O), x.device) if want_stats else None
     g = _geom((kind, N, H, W, Cin, O, None))
-    _igemm(_dt(x), _p(x), _p(pw.fwd(x.dtype)), _p(y), _p(addend), _p(stats), g, x.device)
+    _igemm(_lib.SBA_BF16_YH if yh else _dt(x), _p(x), _p(pw.fwd(x.dtype)), _p(y), _p(addend), _p(stats), g, x.device)
     return y, stats
 
 
@@ -563,7 +585,7 @@ def bn_act_forward(y, stats, bn, act, residual=None, groups=1):
     st = BNState()
     st.C, st.rows, st.groups = C, (N // groups) * H * W, groups
     st.aux = torch.empty((groups, 4, C), dtype=torch.float32, device=y.device)
-    out = empty_act(N, Co, H, W, y)
+    out = torch.empty((N, Co, H, W), dtype=_act_dtype(y), device=y.device, memory_format=CL)
     call('sba_bn_act_fwd', _dt(y), _p(y), _p(stats), _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
          _p(bn.running_var), _p(bn.num_batches_tracked), _p(st.aux), _p(residual), _p(out), st.rows, groups, C,
          act, Co, 0, BN_EPS, BN_MOMENTUM, 1 if bn.training else 0, _stream())
@@ -576,7 +598,7 @@ BN_FUSED_BWD_ROWS = int(os.environ.get('SBA_BN_FUSED_ROWS', '2560'))       # row
 def bn_act_backward(y, dout, st, bn, act, need_param_grad=True):
     N, C, H, W = y.shape
     Co = C // 2 if act == ACT_GLU else C
-    dy = torch.empty_like(y)
+    dy = torch.empty(y.shape, dtype=_act_dtype(y), device=y.device, memory_format=CL)
     dg = db = None
     if need_param_grad:
         dg, db = param_grad(bn.weight), param_grad(bn.bias)
@@ -599,7 +621,7 @@ def bn_act_forward_fused(y, bn, act, groups):
     st = BNState()
     st.C, st.rows, st.groups = C, (N // groups) * H * W, groups
     st.aux = torch.empty((groups, 4, C), dtype=torch.float32, device=y.device)
-    out = empty_act(N, Co, H, W, y)
+    out = torch.empty((N, Co, H, W), dtype=_act_dtype(y), device=y.device, memory_format=CL)
     call('sba_bn_act_fwd_fused', _dt(y), _p(y), _p(bn.weight), _p(bn.bias), _p(bn.running_mean), _p(bn.running_var),
          _p(bn.num_batches_tracked), _p(st.aux), _p(out), st.rows, groups, C, act, Co, 0, BN_EPS, BN_MOMENTUM, _stream())
     return out, st
@@ -636,10 +658,10 @@ class ConvBNActFn(torch.autograd.Function):
     def forward(ctx, x, weight, gamma, beta, layer, kind, act, residual, groups=1):
         x = as_act(x)
         if groups == 1:
-            y, stats = conv_forward(x, layer.pw, kind, want_stats=layer.bn.training)
+            y, stats = conv_forward(x, layer.pw, kind, want_stats=layer.bn.training, pre_bn=True)
         else:
             assert residual is None and x.shape[0] % groups == 0
-            y, _ = conv_forward(x, layer.pw, kind, want_stats=False)
+            y, _ = conv_forward(x, layer.pw, kind, want_stats=False, pre_bn=True)
             rows_g = (y.shape[0] // groups) * y.shape[2] * y.shape[3]
             if layer.bn.training and rows_g <= BN_FUSED_BWD_ROWS:
                 out, sts = bn_act_forward_fused(y, layer.bn, act, groups)
@@ -676,9 +698,9 @@ class ResBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, blk):
         x = as_act(x)
-        y1, s1 = conv_forward(x, blk.l1.pw, '3x3', want_stats=blk.l1.bn.training)
+        y1, s1 = conv_forward(x, blk.l1.pw, '3x3', want_stats=blk.l1.bn.training, pre_bn=True)
         a1, st1 = bn_act_forward(y1, s1, blk.l1.bn, ACT_GLU)
-        y2, s2 = conv_forward(a1, blk.l2.pw, '3x3', want_stats=blk.l2.bn.training)
+        y2, s2 = conv_forward(a1, blk.l2.pw, '3x3', want_stats=blk.l2.bn.training, pre_bn=True)
         out, st2 = bn_act_forward(y2, s2, blk.l2.bn, ACT_NONE, residual=x)
         ctx.blk, ctx.st1, ctx.st2 = blk, st1, st2
         ctx.save_for_backward(x, y1, a1, y2)
@@ -1147,7 +1169,7 @@ class DHeadsFn(torch.autograd.Function):
                 E = cond.shape[1]
                 xin = empty_act(rows, C + E, 4, 4, feats)
                 call('sba_cond_cat_fwd', dt, _p(h), _p(cond[c0:c0 + rows]), _p(xin), rows, C, E, _stream())
-                y, stats = conv_forward(xin, layer.pw, '3x3', want_stats=layer.bn.training)
+                y, stats = conv_forward(xin, layer.pw, '3x3', want_stats=layer.bn.training, pre_bn=True)
                 hc, st = bn_act_forward(y, stats, layer.bn, ACT_LRELU)
                 o = cnet.outlogits[0]
                 call('sba_logits_fwd', dt, _p(hc), _p(o.weight), _p(o.bias), _p(pslice), rows, K, _stream())
