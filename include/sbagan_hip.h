@@ -124,6 +124,17 @@ int sba_conv_igemm(int dtype, const void* x, const void* w, void* y, const void*
 int sba_conv_igemm_bias(int dtype, const void* x, const void* w, void* y, const void* addend,
                         float* stats, const float* bias, const void* relu_mask, const sba_conv_geom* g,
                         void* workspace, int64_t workspace_bytes, void* stream);
+/* GROUPED launch: n <= SBA_GROUP_MAX independent convolutions -- no output of one is an input of another, their outputs
+ * do not overlap -- as ONE grid (bf16 only, no split-K, no statistics; bias / ReLU (g->relu) / addend /
+ * relu_mask per item as in sba_conv_igemm_bias).  For the branches of an Inception block at one depth level (model.py:226-262:
+ * the reference runs them one after the other): each alone is 120..273 workgroups of a 64 x 64 tile on 256 CUs.
+ * tile: 1 = 64x64, 3 = 96x64, 5 = 128x64 (0 = 1).  The item array is HOST memory, read during the call. */
+#define SBA_GROUP_MAX 8
+typedef struct sba_conv_group_item {
+    const void* x; const void* w; void* y; const void* addend; const float* bias; const void* relu_mask;
+    const sba_conv_geom* g;
+} sba_conv_group_item;
+int sba_conv_igemm_group(int dtype, int n, const sba_conv_group_item* items, int tile, void* stream);
 /* dw[co][t][ci] += sum_pixel dy[pixel][co] * x[gather(pixel,t)][ci]   (f32 accumulate/output).
  * ksplit > 1 splits the pixel range over that many workgroups (atomic accumulation). */
 int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* dw, const sba_conv_geom* g,

@@ -111,9 +111,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
 // T = activation storage type, YT = storage type of the raw conv output y (SBA_BF16_YH: binary16)
 #define SBA_DISPATCH_Y(dtype, CALL)                     \
     do {                                                \
-        if ((dtype) == SBA_F32) { using T = float; using YT = float; CALL; }            \
-        else if ((dtype) == SBA_BF16) { using T = bf16_t; using YT = bf16_t; CALL; }    \
-        else if ((dtype) == SBA_BF16_YH) { using T = bf16_t; using YT = f16_t; CALL; }  \
+        if ((dtype) == SBA_F32) { using T [[maybe_unused]] = float; using YT = float; CALL; }            \
+        else if ((dtype) == SBA_BF16) { using T [[maybe_unused]] = bf16_t; using YT = bf16_t; CALL; }    \
+        else if ((dtype) == SBA_BF16_YH) { using T [[maybe_unused]] = bf16_t; using YT = f16_t; CALL; }  \
         else return SBA_E_ARG;                          \
     } while (0)
 

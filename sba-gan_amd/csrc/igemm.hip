@@ -605,20 +605,22 @@ static unsigned long long* g_dma_trace = nullptr;
 extern "C" void sba_set_dma_trace(unsigned long long* p) { g_dma_trace = p; }
 #define DMA_TRACE_PARAM , unsigned long long* __restrict__ trace
 #define DMA_TRACE_ARG , g_dma_trace
+#define DMA_TRACE_ARG_FWD , trace
 #define DMA_STAMP(slot) do { if (trace && L < 32 && tid == 0 && s < 30) { asm volatile("" ::: "memory"); \
     trace[(L * 32 + s) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } } while (0)
 #else
 #define DMA_TRACE_PARAM
 #define DMA_TRACE_ARG
+#define DMA_TRACE_ARG_FWD
 #define DMA_STAMP(slot) do { } while (0)
 #endif
 
 template <int BM, int BN, int WM, int WN, int KS, int D>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(
+__device__ __forceinline__ void igemm_dma_body(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
-    const bf16_t* __restrict__ addend, float* __restrict__ stats, const sba_conv_geom g, const int M,
+    const bf16_t* __restrict__ addend, float* __restrict__ stats, const sba_conv_geom& g, const int M,
     float* __restrict__ ws, int* __restrict__ tickets, const int slabs_per_split, const EpiX ex, const int gx,
-    const int gy DMA_TRACE_PARAM) {
+    const int gy, const int L, const int bz DMA_TRACE_PARAM) {
     typedef bf16_t T;
     constexpr int TM = WM / 32, TN = WN / 32, WAVES_N = BN / WN;
     constexpr int NW = (BM / WM) * (BN / WN), NT = NW * 64;
@@ -639,7 +641,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(
     float* s_stat = reinterpret_cast<float*>(lds_all + EPI_OFF + BM * 4);
 
     // workgroup -> tile: ids L and L + 8 share an XCD; the N tiles of an M tile take consecutive slots of one XCD
-    const int L = blockIdx.x, xcd = L & 7, q = L >> 3;
+    const int xcd = L & 7, q = L >> 3;
     const int mt = xcd + 8 * (q / gy), nt = q - (q / gy) * gy;
     if (mt >= gx) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -679,7 +681,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(
     }
     const int xcs = g.x_cstride ? g.x_cstride : g.Cin;
     const int ycs = g.y_cstride ? g.y_cstride : g.Cout;
-    const int s_begin = blockIdx.z * slabs_per_split;
+    const int s_begin = bz * slabs_per_split;
     const int s_end = min(s_begin + slabs_per_split, nsteps);
 
     int g_tap = s_begin / cpt, g_c = s_begin - g_tap * cpt, g_step = s_begin;
@@ -811,7 +813,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(
     wg_barrier();
 
     if (ws) {
-        if (!splitk_arrive<TM, TN>(ws, tickets, acc, m_base + wm0, n_base + wn0, lane, M, g.Cout, (int)blockIdx.x,
+        if (!splitk_arrive<TM, TN>(ws, tickets, acc, m_base + wm0, n_base + wn0, lane, M, g.Cout, L,
                                    reinterpret_cast<int*>(lds_all)))
             return;
     }
@@ -828,7 +830,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(
     for (int c = threadIdx.x; c < 2 * BN; c += NT) s_stat[c] = 0.f;
     __syncthreads();
     tile_epilogue<T, BM, BN, TM, TN, NT, LDS_BYTES>(acc, true, lds_all, rowoff, s_stat, wm0, wn0, lane, n_base, ycs, g, y,
-                                                    addend, stats, ex, mt + (int)blockIdx.z);
+                                                    addend, stats, ex, mt + bz);
+}
+
+template <int BM, int BN, int WM, int WN, int KS, int D>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+    const bf16_t* __restrict__ addend, float* __restrict__ stats, const sba_conv_geom g, const int M,
+    float* __restrict__ ws, int* __restrict__ tickets, const int slabs_per_split, const EpiX ex, const int gx,
+    const int gy DMA_TRACE_PARAM) {
+    igemm_dma_body<BM, BN, WM, WN, KS, D>(x, w, y, addend, stats, g, M, ws, tickets, slabs_per_split, ex, gx, gy,
+                                          (int)blockIdx.x, (int)blockIdx.z DMA_TRACE_ARG_FWD);
 }
 
 // ---------------------------------------------------------------------------
@@ -848,12 +860,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(
 // Everything else (zero-filled out-of-range taps / rows / dead stages, XCD-aware tile numbering, split-K into
 // the f32 workspace, shared epilogue) is as in the kernel above.
 // ---------------------------------------------------------------------------
+// (the body is shared by the one-conv kernel and the grouped kernel below: L = the workgroup's index among this
+// conv's tiles, bz = its K split)
 template <int BM, int BN, int WM, int WN, int D>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma2_kernel(
+__device__ __forceinline__ void igemm_dma2_body(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
-    const bf16_t* __restrict__ addend, float* __restrict__ stats, const sba_conv_geom g, const int M,
+    const bf16_t* __restrict__ addend, float* __restrict__ stats, const sba_conv_geom& g, const int M,
     float* __restrict__ ws, int* __restrict__ tickets, const int slabs_per_split, const EpiX ex, const int gx,
-    const int gy DMA_TRACE_PARAM) {
+    const int gy, const int L, const int bz DMA_TRACE_PARAM) {
     typedef bf16_t T;
     constexpr int TM = WM / 32, TN = WN / 32, WAVES_N = BN / WN;
     constexpr int NW = (BM / WM) * (BN / WN), NT = NW * 64;
@@ -872,7 +886,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma2_kernel(
     int* rowoff = reinterpret_cast<int*>(lds_all + EPI_OFF);
     float* s_stat = reinterpret_cast<float*>(lds_all + EPI_OFF + BM * 4);
 
-    const int L = blockIdx.x, xcd = L & 7, q = L >> 3;
+    const int xcd = L & 7, q = L >> 3;
     const int mt = xcd + 8 * (q / gy), nt = q - (q / gy) * gy;
     if (mt >= gx) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -913,7 +927,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma2_kernel(
     }
     const int xcs = g.x_cstride ? g.x_cstride : g.Cin;
     const int ycs = g.y_cstride ? g.y_cstride : g.Cout;
-    const int s_begin = blockIdx.z * slabs_per_split;
+    const int s_begin = bz * slabs_per_split;
     const int s_end = min(s_begin + slabs_per_split, nsteps);
     int g_tap = s_begin / cpt, g_c = s_begin - g_tap * cpt, g_step = s_begin;
     int cur_tap = -1;
@@ -1073,7 +1087,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma2_kernel(
     wg_barrier();
 
     if (ws) {
-        if (!splitk_arrive<TM, TN>(ws, tickets, acc, m_base + wm0, n_base + wn0, lane, M, g.Cout, (int)blockIdx.x,
+        if (!splitk_arrive<TM, TN>(ws, tickets, acc, m_base + wm0, n_base + wn0, lane, M, g.Cout, L,
                                    reinterpret_cast<int*>(lds_all)))
             return;
     }
@@ -1090,7 +1104,60 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma2_kernel(
     for (int c = threadIdx.x; c < 2 * BN; c += NT) s_stat[c] = 0.f;
     __syncthreads();
     tile_epilogue<T, BM, BN, TM, TN, NT, LDS_BYTES>(acc, true, lds_all, rowoff, s_stat, wm0, wn0, lane, n_base, ycs, g, y,
-                                                    addend, stats, ex, mt + (int)blockIdx.z);
+                                                    addend, stats, ex, mt + bz);
+}
+
+template <int BM, int BN, int WM, int WN, int D>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma2_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+    const bf16_t* __restrict__ addend, float* __restrict__ stats, const sba_conv_geom g, const int M,
+    float* __restrict__ ws, int* __restrict__ tickets, const int slabs_per_split, const EpiX ex, const int gx,
+    const int gy DMA_TRACE_PARAM) {
+    igemm_dma2_body<BM, BN, WM, WN, D>(x, w, y, addend, stats, g, M, ws, tickets, slabs_per_split, ex, gx, gy,
+                                       (int)blockIdx.x, (int)blockIdx.z DMA_TRACE_ARG_FWD);
+}
+
+// ---------------------------------------------------------------------------
+// GROUPED launch: up to SBA_GROUP_MAX independent convolutions (the branches of one Inception block at one depth
+// level: model.py:226-262 runs them one after the other) as ONE grid.  Each of them alone is 120..273 workgroups of
+// a 64 x 64 tile on 256 CUs -- one wave per SIMD, nothing to overlap the LDS / DMA-issue latency of a stage with, a
+// nearly empty second round, ~4.4 us of launch floor -- and hipGraph replay runs the branches' streams back to back.
+// Grouped, their tiles share the chip: two workgroups per CU co-resident, one launch floor, one tail.  The item
+// descriptors travel BY VALUE in the kernarg segment (pointers change every eager step; no device-side table to
+// refresh, nothing for a captured graph to copy).
+// ---------------------------------------------------------------------------
+struct GroupItem {
+    const bf16_t* x; const bf16_t* w; bf16_t* y; const bf16_t* addend; const float* bias; const void* mask;
+    sba_conv_geom g;
+    int M, gx, gy, tile_begin;
+};
+struct GroupArgs { int n; int pad; GroupItem it[SBA_GROUP_MAX]; };
+
+template <int BM, int BN, int WM, int WN, int D>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma2_group_kernel(const GroupArgs A DMA_TRACE_PARAM) {
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < SBA_GROUP_MAX; ++k)
+        if (k < A.n && (int)blockIdx.x >= A.it[k].tile_begin) i = k;
+    const GroupItem& it = A.it[i];
+    const sba_conv_geom g = it.g;
+    igemm_dma2_body<BM, BN, WM, WN, D>(it.x, it.w, it.y, it.addend, nullptr, g, it.M, nullptr, nullptr,
+                                       g.ntaps * (g.Cin / 64), EpiX{it.bias, it.mask, 0}, it.gx, it.gy,
+                                       (int)blockIdx.x - it.tile_begin, 0 DMA_TRACE_ARG_FWD);
+}
+
+// the same for members whose Cin is a multiple of 32 only (32-channel slabs, first-generation body)
+template <int BM, int BN, int WM, int WN, int KS, int D>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_group_kernel(const GroupArgs A DMA_TRACE_PARAM) {
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < SBA_GROUP_MAX; ++k)
+        if (k < A.n && (int)blockIdx.x >= A.it[k].tile_begin) i = k;
+    const GroupItem& it = A.it[i];
+    const sba_conv_geom g = it.g;
+    igemm_dma_body<BM, BN, WM, WN, KS, D>(it.x, it.w, it.y, it.addend, nullptr, g, it.M, nullptr, nullptr,
+                                          g.ntaps * (g.Cin / 32), EpiX{it.bias, it.mask, 0}, it.gx, it.gy,
+                                          (int)blockIdx.x - it.tile_begin, 0 DMA_TRACE_ARG_FWD);
 }
 
 // ---------------------------------------------------------------------------
@@ -2655,6 +2722,56 @@ extern "C" int sba_conv_igemm_bias(int dtype, const void* x, const void* w, void
     SBA_DISPATCH(dtype, return launch_igemm<T>(x, w, y, addend, stats, *g, workspace, workspace_bytes,
                                                (hipStream_t)stream, EpiX{bias, relu_mask, 0}));
     return SBA_E_ARG;
+}
+
+template <int BM, int BN, int WM, int WN, int D, int KS = 0>
+static int launch_group(const sba_conv_group_item* items, int n, hipStream_t st) {
+    GroupArgs A;
+    A.n = n;
+    A.pad = 0;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const sba_conv_geom& g = *items[i].g;
+        GroupItem& it = A.it[i];
+        it.x = (const bf16_t*)items[i].x; it.w = (const bf16_t*)items[i].w; it.y = (bf16_t*)items[i].y;
+        it.addend = (const bf16_t*)items[i].addend; it.bias = items[i].bias; it.mask = items[i].relu_mask;
+        it.g = g;
+        it.M = g.N * g.OHs * g.OWs;
+        it.gx = cdiv(it.M, BM);
+        it.gy = cdiv(g.Cout, BN);
+        it.tile_begin = tiles;
+        tiles += 8 * cdiv(it.gx, 8) * it.gy;
+    }
+    for (int i = n; i < SBA_GROUP_MAX; ++i) A.it[i] = A.it[0];
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;
+    if (KS == 0) SBA_LAUNCH((igemm_dma2_group_kernel<BM, BN, WM, WN, D>), dim3(tiles), dim3(NT), 0, st, A DMA_TRACE_ARG);
+    else SBA_LAUNCH((igemm_dma_group_kernel<BM, BN, WM, WN, (KS ? KS : 1), D>), dim3(tiles), dim3(NT), 0, st, A DMA_TRACE_ARG);
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_conv_igemm_group(int dtype, int n, const sba_conv_group_item* items, int tile, void* stream) {
+    if (dtype != SBA_BF16 || !items || n < 1 || n > SBA_GROUP_MAX) return SBA_E_ARG;
+    bool all64 = true;
+    for (int i = 0; i < n; ++i) {
+        const sba_conv_group_item& it = items[i];
+        if (!it.x || !it.w || !it.y || !geom_ok(it.g, dtype)) return SBA_E_ARG;     // (geom_ok: Cin % 32 == 0)
+        all64 = all64 && it.g->Cin % 64 == 0;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (all64) {        // 64-channel slabs, second-generation body
+        switch (tile) {
+            case 0: case 1: return launch_group<64, 64, 32, 32, 4>(items, n, st);
+            case 3: return launch_group<96, 64, 32, 64, 3>(items, n, st);
+            case 5: return launch_group<128, 64, 32, 64, 3>(items, n, st);
+            default: return SBA_E_ARG;
+        }
+    }
+    switch (tile) {     // some member has Cin % 64 == 32: 32-channel slabs for the whole group
+        case 0: case 1: return launch_group<64, 64, 32, 32, 4, 2>(items, n, st);
+        case 3: return launch_group<96, 64, 32, 64, 3, 2>(items, n, st);
+        case 5: return launch_group<128, 64, 32, 64, 4, 1>(items, n, st);
+        default: return SBA_E_ARG;
+    }
 }
 
 extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* dw, const sba_conv_geom* g,

@@ -33,6 +33,13 @@ class ConvGeom(Structure):
                 ('relu', c_int32), ('tile', c_int32), ('ksplit', c_int32), ('first_write', c_int32)]
 
 
+class ConvGroupItem(Structure):
+    _fields_ = [('x', c_void_p), ('w', c_void_p), ('y', c_void_p), ('addend', c_void_p), ('bias', c_void_p),
+                ('relu_mask', c_void_p), ('g', POINTER(ConvGeom))]
+
+
+GROUP_MAX = 8
+
 if not os.path.exists(LIB_PATH):
     raise ImportError('libsbagan_hip.so not built: run `python __graft_entry__.py` or '
                       '`make -C sba-gan_amd/csrc` (expected %s)' % LIB_PATH)
@@ -45,6 +52,7 @@ G = POINTER(ConvGeom)
 SIGNATURES = {
     'sba_conv_igemm': [I, P, P, P, P, P, G, P, L, P],
     'sba_conv_igemm_bias': [I, P, P, P, P, P, P, P, G, P, L, P],
+    'sba_conv_igemm_group': [I, I, POINTER(ConvGroupItem), I, P],
     'sba_conv_wgrad': [I, P, P, P, G, I, P],
     'sba_pack_weight': [I, P, P, I, I, I, I, I, P],
     'sba_pack_weights_multi': [I, P, I, I, P],

@@ -17,10 +17,12 @@ import os
 import torch
 
 from . import _lib, ops
-from ._lib import ConvGeom, call
+from ._lib import ConvGeom, ConvGroupItem, call
 
 BN_EPS = 1e-3
 SAVE_ARGMAX = os.environ.get('SBA_ENC_SAVE_ARGMAX', '1') != '0'    # max-pool forward keeps the window argmax for the backward
+GROUP_MIN_TILES = int(os.environ.get('SBA_ENC_GROUP_MIN_TILES', '512'))
+GROUP_TILE = int(os.environ.get('SBA_ENC_GROUP_TILE', '0'))             # tuning aid: force the grouped launches' tile id
 
 
 def _pad32(c):
@@ -123,6 +125,13 @@ class InceptionHIP(object):
         self._geoms = {}
         self._side, self._branch_ops, self._block = None, None, None
         self.parallel = os.environ.get('SBA_ENC_PARALLEL', '1') == '1'      # Inception branches on side streams
+        # GROUPED launches (bf16): the branches of a block are issued level by level on ONE stream, and the implicit-GEMM
+        # convs of one level -- independent of each other -- go out as one sba_conv_igemm_group grid instead of one
+        # 120..273-workgroup launch each (hipGraph replay runs the side streams back to back anyway, ROCm 7.2)
+        self.group = os.environ.get('SBA_ENC_GROUP', '1') == '1' and self.dtype == torch.bfloat16
+        self._thunks = None          # forward: launch closures of the branch being recorded
+        self._keep = []
+        self._pending = None         # implicit-GEMM launches collected for the current level
         dev = next(enc.parameters()).device
         self.device = dev
         for name, m in enc.named_modules():
@@ -151,11 +160,53 @@ class InceptionHIP(object):
         return torch.empty((N, H, W, C), dtype=self.dtype, device=self.device)
 
     def _igemm(self, x_ptr, w, y_ptr, addend_ptr, bias, g, mask_ptr=None):
+        if self._pending is not None:
+            self._pending.append((x_ptr, w, y_ptr, addend_ptr, bias, g, mask_ptr))
+            return
         ws = ops.workspace(self.device)
         ops.tune_geom(g, self._dt())
         call('sba_conv_igemm_bias', self._dt(), x_ptr, w.data_ptr(), y_ptr, addend_ptr,
              None, None if bias is None else bias.data_ptr(), mask_ptr, ctypes.byref(g), ws.data_ptr(),
              ops.WORKSPACE_BYTES, ops._stream())
+
+    def _launch(self, fn):
+        """run a launch closure now, or keep it for the level-by-level issue of the block being recorded"""
+        if self._thunks is not None:
+            self._thunks.append(fn)
+        else:
+            fn()
+
+    def _flush(self):
+        """issue the implicit-GEMM launches collected for one level as one grid (several when there are more than
+        SBA_GROUP_MAX)"""
+        items, self._pending = self._pending, None
+        grp = items if len(items) >= 2 else []
+        taken = set(id(it) for it in grp)
+        for it in items:
+            if id(it) not in taken:
+                self._igemm(*it)
+        for i0 in range(0, len(grp), _lib.GROUP_MAX):
+            part = grp[i0:i0 + _lib.GROUP_MAX]
+            if len(part) == 1:
+                self._igemm(*part[0])
+                continue
+            arr = (ConvGroupItem * len(part))()
+            m128 = m96 = 0
+            for a, (x_ptr, w, y_ptr, addend_ptr, bias, g, mask_ptr) in zip(arr, part):
+                a.x, a.w, a.y, a.addend = x_ptr, w.data_ptr(), y_ptr, addend_ptr
+                a.bias = None if bias is None else bias.data_ptr()
+                a.relu_mask = mask_ptr
+                a.g = ctypes.pointer(g)
+                M = g.N * g.OHs * g.OWs
+                ny = (g.Cout + 63) // 64
+                m128 += ((M + 127) // 128) * ny
+                m96 += ((M + 95) // 96) * ny
+            # bigger tiles move fewer bytes L2 -> LDS per FLOP; use them when they still fill two workgroups per CU
+            tile = 5 if m128 >= GROUP_MIN_TILES else (3 if m96 >= GROUP_MIN_TILES else 1)
+            if GROUP_TILE:
+                tile = GROUP_TILE
+            call('sba_conv_igemm_group', _lib.SBA_BF16, len(part), arr, tile, ops._stream())
+        self._keep = []             # temporaries the collected launches read (ReLU-masked gradients)
 
     def conv(self, name, x, out=None):
         """y = relu(conv(x) + bias) written to `out` (an _Act slice) or a new tensor."""
@@ -179,7 +230,8 @@ class InceptionHIP(object):
         taps = [(t // L.KW - L.ph, t % L.KW - L.pw) for t in range(L.KH * L.KW)]
         g = _geom(N, H, W, L.Ip, OH, OW, L.Op, taps, sy=L.stride, xcs=Ct, xco=x.coff, ycs=out.shape[3],
                   yco=out.coff, relu=1 if L.relu else 0)
-        self._igemm(x.t.data_ptr(), L.w_fwd, out.t.data_ptr(), None, L.bias, g)
+        xp, yp = x.t.data_ptr(), out.t.data_ptr()
+        self._launch(lambda: self._igemm(xp, L.w_fwd, yp, None, L.bias, g))
         self._record(('conv', L, x, out))
         self._consume(x)
         if L.relu:
@@ -237,6 +289,8 @@ class InceptionHIP(object):
         dt = self._dt()
         if L.relu and not self._is_masked(out):
             dpre = self._new(N, OH, OW, L.Op)
+            if self._pending is not None:
+                self._keep.append(dpre)     # read by a launch that is issued later (at the end of the level)
             call('sba_relu_bwd', dt, out.t.data_ptr(), gy[0].data_ptr(), dpre.data_ptr(), N * OH * OW, L.Op, Ct_o,
                  out.coff, Ct_o, out.coff, ops._stream())
             dsrc, dcs, dco = dpre, L.Op, 0
@@ -274,13 +328,14 @@ class InceptionHIP(object):
         if out is None:
             out = _Act(self._new(N, OH, OW, x.C))
         arg = None
+        xp, yp, dt, C, ocs, oco, xco = x.t.data_ptr(), out.t.data_ptr(), self._dt(), x.C, out.shape[3], out.coff, x.coff
         if SAVE_ARGMAX and getattr(self, '_want_grad', False):
             arg = torch.empty((N, OH, OW, x.C), dtype=torch.uint8, device=self.device)
-            call('sba_maxpool3x3s2_fwd_arg', self._dt(), x.t.data_ptr(), out.t.data_ptr(), arg.data_ptr(), N, H, W, x.C,
-                 Ct, x.coff, out.shape[3], out.coff, ops._stream())
+            ap = arg.data_ptr()
+            self._launch(lambda: call('sba_maxpool3x3s2_fwd_arg', dt, xp, yp, ap, N, H, W, C, Ct, xco, ocs, oco,
+                                      ops._stream()))
         else:
-            call('sba_maxpool3x3s2_fwd', self._dt(), x.t.data_ptr(), out.t.data_ptr(), N, H, W, x.C, Ct, x.coff,
-                 out.shape[3], out.coff, ops._stream())
+            self._launch(lambda: call('sba_maxpool3x3s2_fwd', dt, xp, yp, N, H, W, C, Ct, xco, ocs, oco, ops._stream()))
         self._record(('maxpool', arg, x, out))
         self._consume(x)
         return out
@@ -300,8 +355,8 @@ class InceptionHIP(object):
     def avgpool(self, x):
         N, H, W, Ct = x.shape
         out = _Act(self._new(N, H, W, x.C))
-        call('sba_avgpool3x3', self._dt(), x.t.data_ptr(), out.t.data_ptr(), N, H, W, x.C, Ct, x.coff, x.C, 0, 0,
-             ops._stream())
+        xp, yp, dt, C, xco = x.t.data_ptr(), out.t.data_ptr(), self._dt(), x.C, x.coff
+        self._launch(lambda: call('sba_avgpool3x3', dt, xp, yp, N, H, W, C, Ct, xco, C, 0, 0, ops._stream()))
         self._record(('avgpool', None, x, out))
         self._consume(x)
         return out
@@ -330,7 +385,9 @@ class InceptionHIP(object):
         def __enter__(self):
             r = self.r
             r._branch_ops = []
-            if r.parallel:
+            if r.group:
+                r._thunks = []              # the branch's launches are issued level by level in _end_block
+            elif r.parallel:
                 st = r._streams()[self.k]
                 st.wait_stream(r._main)
                 self.ctx = torch.cuda.stream(st)
@@ -339,7 +396,10 @@ class InceptionHIP(object):
 
         def __exit__(self, *a):
             r = self.r
-            if r.parallel:
+            if r.group:
+                r._block_thunks.append(r._thunks)
+                r._thunks = None
+            elif r.parallel:
                 self.ctx.__exit__(*a)
             r._block.append((self.k, r._branch_ops))
             r._branch_ops = None
@@ -349,6 +409,7 @@ class InceptionHIP(object):
         self._block = []
         self._block_x = x
         self._block_pre = []
+        self._block_thunks = []
 
     def _heads(self, names, x, ext):
         """the fused 1x1 head convs of a block: outputs occupy channels [0, sum Op) of `ext`; returns the
@@ -366,7 +427,16 @@ class InceptionHIP(object):
         return views
 
     def _end_block(self, cat_view):
-        if self.parallel:
+        if self.group:
+            # level l = the l-th launch of every branch: independent of each other, the convs among them as one grid
+            for lvl in range(max(len(t) for t in self._block_thunks)):
+                self._pending = []
+                for t in self._block_thunks:
+                    if lvl < len(t):
+                        t[lvl]()
+                self._flush()
+            self._block_thunks = []
+        elif self.parallel:
             for k, _ in self._block:
                 self._main.wait_stream(self._streams()[k])
         self._relu_slices.add(self._key(cat_view))          # every slice of the concat is a ReLU (or max-pool of ReLU) output
@@ -582,6 +652,23 @@ class InceptionHIP(object):
             _, branches, bx, pre = entry
             held = []
             used = []
+            if self.group:
+                chains = []
+                for k, ops_k in branches:
+                    rest = list(ops_k)
+                    if rest and rest[0][2].t is bx.t:
+                        held.append(rest.pop(0))
+                    if rest:
+                        chains.append(list(reversed(rest)))
+                for lvl in range(max([len(c) for c in chains] or [0])):
+                    self._pending = []
+                    for c in chains:
+                        if lvl < len(c):
+                            run(c[lvl])
+                    self._flush()
+                for op in sorted(held, key=lambda o: 0 if o[0] != 'conv' else 1) + list(reversed(pre)):
+                    run(op)
+                continue
             for k, ops_k in branches:
                 rest = list(ops_k)
                 if rest and rest[0][2].t is bx.t:

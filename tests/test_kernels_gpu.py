@@ -358,6 +358,21 @@ def test_conv_bn_act_blocks(dev, dt, which):
     _check_module(mod, Q, dt, 'm.', gscale=3)
 
 
+@pytest.mark.parametrize('which', ['up', 'leak', 'down', 'res'])
+def test_conv_bn_act_blocks_binary16_conv_output(dev, which):
+    """SBA_Y_F16=1 / SBA_BF16_YH: the raw conv output between the conv epilogue and the BatchNorm kernels stored as IEEE
+    binary16 instead of bf16 (forward, both backward passes, grouped and fused variants go through the same blocks)."""
+    from sbagan import ops
+    was = ops.Y_F16
+    ops.Y_F16 = True
+    try:
+        test_conv_bn_act_blocks(dev, torch.bfloat16, which)
+        if which == 'leak':
+            test_grouped_real_fake_pass_equals_two_calls(dev, torch.bfloat16)
+    finally:
+        ops.Y_F16 = was
+
+
 @pytest.mark.parametrize('dt', DTYPES)
 @pytest.mark.parametrize('mask_mode', [0, 1])
 def test_word_attention(dev, dt, mask_mode):
