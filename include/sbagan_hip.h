@@ -276,6 +276,13 @@ int sba_adain_bwd_apply(int dtype, const void* h, const void* dout, const float*
 int sba_word_attn_fwd(int dtype, const void* h, const float* src, const uint8_t* mask, void* ctx,
                       float* att, int B, int Q, int idf, int L, int mask_mode, int out_cstride,
                       int out_coff, void* stream);
+/* BASELINE config 5 ("fp8 MFMA for the attention / context GEMM"): the same forward (bf16 activations) with BOTH
+ * contractions of GlobalAttention.py:103,117 on v_mfma_f32_32x32x16_fp8_fp8 -- OCP e4m3 operands, f32 accumulate, h scaled
+ * per 32-query tile and the keys per image by powers of two (exact un-scaling), probabilities x 256.  Forward only: the
+ * backward (sba_word_attn_bwd) keeps the bf16 / f32 operands (straight-through w.r.t. the quantisation).  Stated tolerance:
+ * context rel L2 <= 8e-2, attention map abs <= 0.12 on N(0,1)-scaled inputs (tests/test_kernels_gpu.py). */
+int sba_word_attn_fwd_fp8(const void* h, const float* src, const uint8_t* mask, void* ctx, float* att, int B, int Q,
+                          int idf, int L, int mask_mode, int out_cstride, int out_coff, void* stream);
 /* dh = d/dh, dsrc[B][idf][L] += d/dsrc (f32, caller zeroes).  accumulate != 0: dh += . */
 int sba_word_attn_bwd(int dtype, const void* h, const float* src, const uint8_t* mask,
                       const void* dctx, void* dh, float* dsrc, int B, int Q, int idf, int L,

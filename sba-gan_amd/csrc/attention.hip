@@ -10,6 +10,8 @@
 // Mask quirk (GlobalAttention.py:105-108): the reference masks row r = b*Q + q of
 // the (B*Q) x L score matrix with mask.repeat(Q, 1)[r] = mask[r % B], not mask[b].
 // mask_mode 0 reproduces that bit-for-bit; mask_mode 1 is the per-sample mask.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -94,6 +96,194 @@ __global__ __launch_bounds__(256) void word_attn_fwd_kernel(
             o.set(k, acc);
         }
         st16(op + cv * V, o);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The forward on the matrix cores (bf16 activations): both contractions of GlobalAttention.py:103,117 as
+// v_mfma_f32_32x32x16 tiles with the QUERY axis as the MFMA's N (lane) axis, so that no operand ever passes
+// through LDS and the softmax is in-lane:
+//   S^T[l][q]  = sum_c src[c][l] h[q][c]      A = src^T (32 words x 16 channels per k-step, constant per image:
+//                                              kept in registers), B = h^T: lane (q, k-group g) needs channels
+//                                              16 s + 8 g .. +8 of its query = ONE 16-byte load straight from HBM
+//   the accumulator of lane (q, g) then holds words l = (r&3) + 8 (r>>2) + 4 g, r < 16, of query q: softmax over
+//   the words = 16 registers + ONE exchange with lane q of the other half-wave (__shfl_xor 32)
+//   ctx^T[c][q] = sum_l src[c][l] a[q][l]     A = src (32 channels x 16 words per k-step, registers), B = a^T: the
+//                                              contraction index is walked in the order the accumulator already holds
+//                                              the words (k-step s, group g, j -> word (j&3) + 8 (2s + (j>>2)) + 4 g),
+//                                              applied to A and B alike: no cross-lane movement at all
+// MODE 0: bf16 operands, the f32 src and the probabilities split into hi + lo bf16 parts (5 MFMAs instead of 2 per
+//         k-step pair: the matrix cores idle anyway, the kernel is HBM-bound at 128 B per query) -- results within
+//         f32 rounding of the VALU kernel above;
+// MODE 1: BASELINE config 5 -- FP8 (OCP e4m3) operands on v_mfma_f32_32x32x16_fp8_fp8 for BOTH contractions:
+//         h scaled per 32-query tile, src per image, by powers of two (exact un-scaling), probabilities x 256.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8_t pack8_bf16(const float (&v)[8]) {
+    bf16x8_t r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(v[j]);
+    return r;
+}
+__device__ __forceinline__ long pack8_e4m3(const float (&v)[8], const float s) {
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * s, v[1] * s, 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * s, v[3] * s, lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * s, v[5] * s, 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * s, v[7] * s, hi, true);
+    return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo);
+}
+__device__ __forceinline__ float pow2_scale(const float amax, const float top) {
+    return amax > 0.f ? exp2f(floorf(log2f(top / amax))) : 1.f;
+}
+
+template <int IDF, int MODE>
+__global__ __launch_bounds__(256) void word_attn_fwd_mfma_kernel(
+    const bf16_t* __restrict__ h, const float* __restrict__ src, const uint8_t* __restrict__ mask,
+    bf16_t* __restrict__ ctx, float* __restrict__ att, int B, int Q, int L, int mask_mode, int ocs, int oco,
+    int tiles_per_wave) {
+    constexpr int KS = IDF / 16;            // k-steps of the score contraction (channels)
+    constexpr int MT = IDF / 32;            // 32-channel tiles of the context
+    constexpr int NDEAD = 1024;
+    __shared__ uint32_t s_dead[NDEAD];      // mask_mode 0: dead-word bits of mask row (r % B), r = b*Q + q
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ql = lane & 31, kg = lane >> 5;
+    const int nrows = mask_mode == 0 ? B : 1;
+    for (int i = tid; i < nrows && i < NDEAD; i += 256) s_dead[i] = dead_words(mask, mask_mode == 0 ? i : b, L);
+    // ---- the image's keys as MFMA A operands (registers)
+    const float* sb = src + (int64_t)b * IDF * L;
+    float smax = 0.f;
+    if (MODE == 1) {
+        for (int i = lane; i < IDF * L; i += 64) smax = fmaxf(smax, fabsf(sb[i]));
+        smax = wave_max(smax);
+    }
+    const float ss = MODE == 1 ? pow2_scale(smax, 448.f) : 1.f;
+    bf16x8_t st_hi[KS], st_lo[KS];          // score contraction: row = word ql, k = channel 16 s + 8 kg + j
+    long st_f8[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        float v[8], lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = ql < L ? sb[(16 * s + 8 * kg + j) * L + ql] : 0.f;
+            lo[j] = v[j] - bf2f(f2bf(v[j]));
+        }
+        st_hi[s] = pack8_bf16(v);
+        st_lo[s] = pack8_bf16(lo);
+        st_f8[s] = MODE == 1 ? pack8_e4m3(v, ss) : 0;
+    }
+    bf16x8_t sc_hi[MT][2], sc_lo[MT][2];    // context contraction: row = channel 32 mt + ql, k = word wmap(s, kg, j)
+    long sc_f8[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float v[8], lo[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int l = (j & 3) + 8 * (2 * s + (j >> 2)) + 4 * kg;
+                v[j] = l < L ? sb[(32 * mt + ql) * L + l] : 0.f;
+                lo[j] = v[j] - bf2f(f2bf(v[j]));
+            }
+            sc_hi[mt][s] = pack8_bf16(v);
+            sc_lo[mt][s] = pack8_bf16(lo);
+            sc_f8[mt][s] = MODE == 1 ? pack8_e4m3(v, ss) : 0;
+        }
+    __syncthreads();
+
+    const int tile0 = (blockIdx.x * 4 + wid) * tiles_per_wave;
+    for (int t = 0; t < tiles_per_wave; ++t) {
+        const int q0 = (tile0 + t) * 32;
+        if (q0 >= Q) break;                                   // (wave-uniform)
+        const int q = q0 + ql;
+        const bool live = q < Q;
+        const int64_t r = (int64_t)b * Q + (live ? q : 0);
+        // ---- scores
+        bf16x8_t hb[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) hb[s] = *reinterpret_cast<const bf16x8_t*>(h + r * IDF + 16 * s + 8 * kg);
+        f32x16_t acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        float sh = 1.f;
+        if (MODE == 1) {
+            float hm = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hm = fmaxf(hm, fabsf(bf2f((bf16_t)hb[s][j])));
+            sh = pow2_scale(wave_max(hm), 448.f);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = bf2f((bf16_t)hb[s][j]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(st_f8[s], pack8_e4m3(v, sh), acc, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st_hi[s], hb[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st_lo[s], hb[s], acc, 0, 0, 0);
+            }
+        }
+        const float unscale = MODE == 1 ? 1.f / (ss * sh) : 1.f;
+        // ---- softmax over the words: 16 in this lane, 16 in lane ^ 32
+        const int mrow = mask_mode == 0 ? (int)(r % B) : 0;
+        const uint32_t deadbits = (mask_mode == 0 && mrow >= NDEAD) ? dead_words(mask, mrow, L) : s_dead[mrow];
+        float a[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int l = (i & 3) + 8 * (i >> 2) + 4 * kg;
+            a[i] = ((deadbits >> l) & 1u) ? -INFINITY : acc[i] * unscale;
+            mx = fmaxf(mx, a[i]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a[i] = __expf(a[i] - mx); sum += a[i]; }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] *= inv;
+        if (att && live) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int l = (i & 3) + 8 * (i >> 2) + 4 * kg;
+                if (l < L) att[((int64_t)b * L + l) * Q + q] = a[i];
+            }
+        }
+        // ---- context
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x16_t c;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) c[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float v[8], lo[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[j] = a[8 * s + j]; lo[j] = v[j] - bf2f(f2bf(v[j])); }
+                if (MODE == 1) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(sc_f8[mt][s], pack8_e4m3(v, 256.f), c, 0, 0, 0);
+                } else {
+                    const bf16x8_t ah = pack8_bf16(v), al = pack8_bf16(lo);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sc_hi[mt][s], ah, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sc_hi[mt][s], al, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sc_lo[mt][s], ah, c, 0, 0, 0);
+                }
+            }
+            const float cs = MODE == 1 ? 1.f / (ss * 256.f) : 1.f;
+            if (live) {
+                bf16_t* op = ctx + r * ocs + oco + 32 * mt + 4 * kg;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {        // channels 32 mt + 8 g4 + 4 kg .. + 4
+                    uint2 o;
+                    o.x = (uint32_t)f2bf(c[4 * g4] * cs) | ((uint32_t)f2bf(c[4 * g4 + 1] * cs) << 16);
+                    o.y = (uint32_t)f2bf(c[4 * g4 + 2] * cs) | ((uint32_t)f2bf(c[4 * g4 + 3] * cs) << 16);
+                    *reinterpret_cast<uint2*>(op + 8 * g4) = o;
+                }
+            }
+        }
     }
 }
 
@@ -286,9 +476,29 @@ __global__ __launch_bounds__(AttnMma<T>::NW * 64) void word_attn_bwd_kernel(
     }
 }
 
+// SBA_ATTN_MFMA=0: the VALU kernel for bf16 as well (A/B aid)
+static int attn_mfma_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SBA_ATTN_MFMA"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
+
+template <int IDF, int MODE>
+int launch_fwd_mfma(const void* h, const float* src, const uint8_t* mask, void* ctx, float* att, int B, int Q, int L,
+                    int mode, int ocs, int oco, hipStream_t st) {
+    const int tiles = cdiv(Q, 32);
+    int tpw = tiles * B >= 16384 ? 4 : (tiles * B >= 4096 ? 2 : 1);        // >= ~1000 workgroups where the map allows
+    dim3 grid(cdiv(tiles, 4 * tpw), B);
+    SBA_LAUNCH((word_attn_fwd_mfma_kernel<IDF, MODE>), grid, dim3(256), 0, st, (const bf16_t*)h, src, mask,
+               (bf16_t*)ctx, att, B, Q, L, mode, ocs, oco, tpw);
+    return SBA_CHECK_LAUNCH();
+}
+
 template <typename T, int IDF>
 int launch_fwd(const void* h, const float* src, const uint8_t* mask, void* ctx, float* att, int B, int Q, int L,
                int mode, int ocs, int oco, hipStream_t st) {
+    if (sizeof(T) == 2 && IDF <= 64 && ocs % 4 == 0 && oco % 4 == 0 && attn_mfma_enabled())
+        return launch_fwd_mfma<(IDF <= 64 ? IDF : 32), 0>(h, src, mask, ctx, att, B, Q, L, mode, ocs, oco, st);
     dim3 grid(cdiv(Q, 256), B);
     SBA_LAUNCH((word_attn_fwd_kernel<T, IDF>), grid, dim3(256), 0, st, (const T*)h, src, mask, (T*)ctx, att,
                        B, Q, L, mode, ocs, oco);
@@ -331,6 +541,18 @@ extern "C" int sba_word_attn_fwd(int dtype, const void* h, const float* src, con
     if (out_cstride < idf + out_coff || out_cstride % V || out_coff % V) return SBA_E_ARG;
     SBA_DISPATCH(dtype, IDF_SWITCH(idf, return (launch_fwd<T, IDF>(h, src, mask, ctx, att, B, Q, L, mask_mode,
                                                                      out_cstride, out_coff, (hipStream_t)stream))));
+    return SBA_E_ARG;
+}
+
+extern "C" int sba_word_attn_fwd_fp8(const void* h, const float* src, const uint8_t* mask, void* ctx, float* att, int B,
+                                     int Q, int idf, int L, int mask_mode, int out_cstride, int out_coff, void* stream) {
+    if (!h || !src || !ctx || B <= 0 || Q <= 0 || L <= 0 || L > LMAX || B > 65535) return SBA_E_ARG;
+    if (mask_mode != 0 && mask_mode != 1) return SBA_E_ARG;
+    if (out_cstride < idf + out_coff || out_cstride % 8 || out_coff % 8) return SBA_E_ARG;
+    if (idf == 32) return launch_fwd_mfma<32, 1>(h, src, mask, ctx, att, B, Q, L, mask_mode, out_cstride, out_coff,
+                                                 (hipStream_t)stream);
+    if (idf == 64) return launch_fwd_mfma<64, 1>(h, src, mask, ctx, att, B, Q, L, mask_mode, out_cstride, out_coff,
+                                                 (hipStream_t)stream);
     return SBA_E_ARG;
 }
 

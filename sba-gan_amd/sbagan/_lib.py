@@ -77,6 +77,7 @@ SIGNATURES = {
     'sba_adain_bwd_reduce': [I, P, P, P, P, P, I, I, I, I, I, P],
     'sba_adain_bwd_apply': [I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P],
     'sba_word_attn_fwd': [I, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    'sba_word_attn_fwd_fp8': [P, P, P, P, P, I, I, I, I, I, I, I, P],
     'sba_word_attn_bwd': [I, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P],
     'sba_img_head_fwd': [I, P, P, P, I, I, I, I, P],
     'sba_img_head_bwd': [I, P, P, P, P, P, P, I, I, I, I, I, P],

@@ -823,8 +823,9 @@ class FcBnGluFn(torch.autograd.Function):
         return dx, None, None, None, None
 
 
-# BASELINE config 5: the attention key projection (GlobalAttention.py:97 conv_context) with FP8 operands on
-# v_mfma_f32_32x32x16_fp8_fp8 (forward only; backward keeps f32 operands).  Off by default.
+# BASELINE config 5 ("fp8 MFMA for the attention / context GEMM"): the attention key projection (GlobalAttention.py:97
+# conv_context) AND the two attention contractions (GlobalAttention.py:103 scores, :117 context) with FP8 (OCP e4m3)
+# operands on v_mfma_f32_32x32x16_fp8_fp8 (forward only; the backward keeps bf16 / f32 operands).  Off by default.
 ATTN_FP8 = os.environ.get('SBA_ATTN_FP8', '0') == '1'
 
 
@@ -838,6 +839,15 @@ def _ctx_proj_fwd(words, wc, src, N, C, cdf, L):
         call('sba_ctx_proj_fwd_fp8', _p(words), _p(wc), _p(src), N, C, cdf, L, _stream())
     else:
         call('sba_ctx_proj_fwd', _p(words), _p(wc), _p(src), N, C, cdf, L, _stream())
+
+
+def _word_attn_fwd(h, src, m8, out, att, N, HW, C, L, mask_mode, ocs, oco):
+    if ATTN_FP8 and h.dtype == torch.bfloat16 and C in (32, 64):
+        call('sba_word_attn_fwd_fp8', _p(h), _p(src), _p(m8), _p(out), _p(att), N, HW, C, L, mask_mode, ocs, oco,
+             _stream())
+    else:
+        call('sba_word_attn_fwd', _dt(h), _p(h), _p(src), _p(m8), _p(out), _p(att), N, HW, C, L, mask_mode, ocs, oco,
+             _stream())
 
 
 def _mask_u8(mask):
@@ -866,8 +876,7 @@ class AttnAdainCatFn(torch.autograd.Function):
         _ctx_proj_fwd(words, wc, src, N, C, cdf, L)
         out = empty_act(N, 2 * C, H, W, h)
         att = torch.empty((N, L, H, W), dtype=torch.float32, device=dev) if want_att else None
-        call('sba_word_attn_fwd', _dt(h), _p(h), _p(src), _p(m8), _p(out), _p(att), N, HW, C, L, mask_mode,
-             2 * C, C, _stream())
+        _word_attn_fwd(h, src, m8, out, att, N, HW, C, L, mask_mode, 2 * C, C)
         mr = torch.empty((2, N, C), dtype=torch.float32, device=dev)
         call('sba_instnorm_stats', _dt(h), _p(h), _p(mr[0]), _p(mr[1]), N, HW, C, IN_EPS, _stream())
         call('sba_adain_fwd', _dt(h), _p(h), _p(mr[0]), _p(mr[1]), _p(style), _p(out), N, HW, C, 2 * C, 0,
@@ -920,8 +929,7 @@ class WordAttnFn(torch.autograd.Function):
         _ctx_proj_fwd(words, wc, src, N, C, cdf, L)
         out = empty_act(N, C, H, W, h)
         att = torch.empty((N, L, H, W), dtype=torch.float32, device=h.device)
-        call('sba_word_attn_fwd', _dt(h), _p(h), _p(src), _p(m8), _p(out), _p(att), N, H * W, C, L, mask_mode, C, 0,
-             _stream())
+        _word_attn_fwd(h, src, m8, out, att, N, H * W, C, L, mask_mode, C, 0)
         ctx.save_for_backward(h, words, src)
         ctx.m8, ctx.w_ctx, ctx.mask_mode = m8, w_ctx, mask_mode
         ctx.mark_non_differentiable(att)

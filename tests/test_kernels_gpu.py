@@ -798,6 +798,79 @@ def test_attention_key_projection_fp8(dev):
     assert 0 < rel_l2(o8, o32) <= 1e-1, rel_l2(o8, o32)      # measured 5.9e-2 (the softmax sharpens the key error)
 
 
+@pytest.mark.parametrize('shape', [(3, 32, 7, 12 * 12, 0), (20, 32, 18, 64 * 64, 0), (5, 64, 20, 1000, 1), (2, 32, 32, 33, 1)])
+def test_word_attention_matrix_core_forward(dev, shape):
+    """The bf16 forward runs both contractions (GlobalAttention.py:103,117) on v_mfma_f32_32x32x16_bf16 with the keys
+    and the probabilities split into hi + lo bf16 parts: it must agree with an f32 evaluation of the same bf16 inputs to
+    f32 rounding (NOT to bf16 rounding: only the stored context is rounded), for ragged query counts, L up to 32, both
+    mask modes, an output written into a channel slice, and the optional attention map; a fully masked row gives NaN
+    exactly where the reference's softmax does."""
+    from sbagan._lib import call
+    B, idf, L, Q, mode = shape
+    g = torch.Generator().manual_seed(5)
+    h = torch.randn((B, Q, idf), generator=g).to(dev).bfloat16()
+    src = (torch.randn((B, idf, L), generator=g) * 0.5).to(dev)
+    mask = (torch.rand((B, L), generator=g) < 0.3).to(dev)
+    mask[:, 0] = False
+    m8 = mask.to(torch.uint8).contiguous()
+    ocs, oco = 2 * idf, idf
+    out = torch.zeros((B, Q, ocs), device=dev, dtype=torch.bfloat16)
+    att = torch.empty((B, L, Q), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    call('sba_word_attn_fwd', 1, h.data_ptr(), src.data_ptr(), m8.data_ptr(), out.data_ptr(), att.data_ptr(), B, Q, idf,
+         L, mode, ocs, oco, st)
+    torch.cuda.synchronize()
+    s = torch.bmm(h.float(), src)                                         # B x Q x L
+    rows = torch.arange(B * Q, device=dev).view(B, Q)
+    mrow = (rows % B) if mode == 0 else torch.arange(B, device=dev).view(B, 1).expand(B, Q)
+    s = s.masked_fill(mask[mrow], float('-inf'))
+    a = torch.softmax(s, 2)
+    ctx = torch.bmm(a, src.transpose(1, 2))                               # B x Q x idf
+    assert float((att.transpose(1, 2) - a).abs().max()) <= 3e-5       # keys carried as hi + lo bf16: ~2^-17 relative
+    assert torch.equal(out[..., :oco], torch.zeros_like(out[..., :oco]))  # the other half of the slice is untouched
+    got = out[..., oco:].float()
+    assert float((got - ctx.bfloat16().float()).abs().max()) <= 1e-2 * float(ctx.abs().max())     # <= 1 bf16 ulp
+    assert rel_l2(got, ctx) <= 3e-3
+
+
+def test_word_attention_fp8(dev):
+    """BASELINE config 5: both attention contractions on v_mfma_f32_32x32x16_fp8_fp8 (sba_word_attn_fwd_fp8).
+    (1) layout / scaling: with inputs e4m3 represents exactly and ONE live word per query (probability exactly 1) the
+    context equals the selected key column bit for bit; (2) stated tolerance on N(0,1)-scaled inputs (e4m3: 2^-4 relative
+    per operand, 32-term scores of standard deviation ~1.7): attention map within 0.12 absolute (measured 0.081), context
+    within 8e-2 relative L2 (measured 5.6e-2) of the f32 evaluation."""
+    from sbagan._lib import call
+    st = torch.cuda.current_stream().cuda_stream
+    B, idf, L, Q = 4, 32, 9, 1000
+    g = torch.Generator().manual_seed(7)
+    h = torch.randint(-2, 3, (B, Q, idf), generator=g).float().to(dev).bfloat16()
+    src = torch.randint(-4, 5, (B, idf, L), generator=g).float().to(dev) * 0.25
+    mask = torch.ones((B, L), dtype=torch.bool, device=dev)
+    for b in range(B):
+        mask[b, (3 * b) % L] = False
+    m8 = mask.to(torch.uint8).contiguous()
+    out = torch.empty((B, Q, idf), device=dev, dtype=torch.bfloat16)
+    call('sba_word_attn_fwd_fp8', h.data_ptr(), src.data_ptr(), m8.data_ptr(), out.data_ptr(), None, B, Q, idf, L, 1, idf, 0,
+         st)
+    torch.cuda.synchronize()
+    want = torch.stack([src[b, :, (3 * b) % L] for b in range(B)])[:, None, :].expand(B, Q, idf)
+    assert torch.equal(out.float(), want), float((out.float() - want).abs().max())
+    h = torch.randn((B, Q, idf), generator=g).to(dev).bfloat16()
+    src = (torch.randn((B, idf, L), generator=g) * 0.3).to(dev)
+    mask = (torch.rand((B, L), generator=g) < 0.3).to(dev)
+    mask[:, 0] = False
+    m8 = mask.to(torch.uint8).contiguous()
+    att = torch.empty((B, L, Q), device=dev)
+    call('sba_word_attn_fwd_fp8', h.data_ptr(), src.data_ptr(), m8.data_ptr(), out.data_ptr(), att.data_ptr(), B, Q, idf,
+         L, 1, idf, 0, st)
+    torch.cuda.synchronize()
+    s = torch.bmm(h.float(), src).masked_fill(mask[:, None, :], float('-inf'))
+    a = torch.softmax(s, 2)
+    ctx = torch.bmm(a, src.transpose(1, 2))
+    da, dc = float((att.transpose(1, 2) - a).abs().max()), rel_l2(out.float(), ctx)
+    assert 1e-4 < da <= 0.12 and 1e-3 < dc <= 8e-2, (da, dc)
+
+
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
 def test_bert_encoder_hip_vs_module(dev, dt):
     """BertEncoder.forward (model_bert.py:177-189) on the HIP kernels against the same module evaluated by
