@@ -42,6 +42,8 @@ extern "C" {
 #define SBA_ACT_NONE 0
 #define SBA_ACT_GLU 1       /* model.py:15-23 */
 #define SBA_ACT_LRELU 2     /* LeakyReLU(0.2), model.py:544 */
+#define SBA_ACT_RELU 3      /* sba_bn_act_fwd only: BasicConv2d of the Inception trunk in TRAINING mode (frozen weights,
+                             * batch statistics: pretrain_DAMSM.py:51 cnn_model.train(), model.py:170-199); no backward */
 
 #define SBA_MAX_TAPS 32
 

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void enc_stem_fwd_kernel(const float* __restri
         const int ox = (int)(p % O), oy = (int)((p / O) % O), n = (int)(p / ((int64_t)O * O));
         float acc[V];
 #pragma unroll
-        for (int k = 0; k < V; ++k) acc[k] = bias[c + k];
+        for (int k = 0; k < V; ++k) acc[k] = bias ? bias[c + k] : 0.f;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void enc_stem_fwd_kernel(const float* __restri
                 }
         Vec16<T> o;
 #pragma unroll
-        for (int k = 0; k < V; ++k) o.set(k, fmaxf(acc[k], 0.f));
+        for (int k = 0; k < V; ++k) o.set(k, bias ? fmaxf(acc[k], 0.f) : acc[k]);     // bias == NULL: the raw conv output
         st16(out + p * C + c, o);
     }
 }
@@ -423,7 +423,7 @@ extern "C" int sba_resize_bilinear(const float* in, float* out, int NC, int S, i
 
 extern "C" int sba_enc_stem_fwd(int dtype, const float* img, const float* w, const float* bias, void* out, int N,
                                 int S, int C, void* stream) {
-    if (!img || !w || !bias || !out || N <= 0 || S < 3 || C <= 0 || C % 8 || C > 256) return SBA_E_ARG;
+    if (!img || !w || !out || N <= 0 || S < 3 || C <= 0 || C % 8 || C > 256) return SBA_E_ARG;
     const int O = (S - 3) / 2 + 1, V = dtype == SBA_BF16 ? 8 : 4;
     SBA_DISPATCH(dtype, SBA_LAUNCH((enc_stem_fwd_kernel<T>), dim3(grid_for((int64_t)N * O * O * (C / V), 4096)),
                                            dim3(256), sizeof(float) * 27 * C, (hipStream_t)stream, img, w, bias,

@@ -44,9 +44,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y_a
         __syncthreads();
     }
     const int tpr = cv < (int)blockDim.x ? cv : (int)blockDim.x;
-    const int rpi = blockDim.x / tpr;
+    const int rpi = blockDim.x / tpr;           // (cv not a power of two: the last blockDim.x % tpr threads idle)
     const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr;
-    for (int cvi = tc; cvi < cv; cvi += tpr) {
+    for (int cvi = tc; cvi < cv && tr < rpi; cvi += tpr) {
         const int c = cvi * V;
         float s0[V], s1[V];
 #pragma unroll
@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const YT* __restrict__ 
             for (int k = 0; k < V; ++k) {
                 float n = a.get(k) * scale[c + k] + shift[c + k];
                 if (ACT == SBA_ACT_LRELU) n = n > 0.f ? n : LRELU_SLOPE * n;
+                if (ACT == SBA_ACT_RELU) n = fmaxf(n, 0.f);
                 if (residual) n += r.get(k);
                 o.set(k, n);
             }
@@ -801,7 +802,7 @@ inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 extern "C" int sba_bn_stats(int dtype, const void* y, float* stats, int64_t rows, int groups, int C,
                             void* stream) {
     const int V = dtype != SBA_F32 ? 8 : 4;
-    if (!y || !stats || rows <= 0 || groups <= 0 || groups > 65535 || C <= 0 || C % V || !pow2(C / V) || C > 4096)
+    if (!y || !stats || rows <= 0 || groups <= 0 || groups > 65535 || C <= 0 || C % V || C > 4096)
         return SBA_E_ARG;
     const int cv = C / V;
     const int rpi = cv < 256 ? 256 / cv : 1;
@@ -846,7 +847,12 @@ extern "C" int sba_bn_act_fwd(int dtype, const void* y, const float* stats, cons
                               int64_t* num_batches_tracked, float* aux, const void* residual, void* out,
                               int64_t rows, int groups, int C, int act, int out_cstride, int out_coff, float eps,
                               float momentum, int training, void* stream) {
-    if (!y || !gamma || !beta || !aux || !out || !bn_shape_ok(dtype, rows, groups, C, act)) return SBA_E_ARG;
+    // (the forward kernel indexes channels generically: any C that is a multiple of the vector width -- the Inception
+    // trunk's 80 / 96 / 160 / 192 / 320 / 448 ... channel BatchNorms in the DAMSM pre-training loop)
+    const int Vw = dtype != SBA_F32 ? 8 : 4;
+    const bool shape_ok = rows > 0 && groups > 0 && groups <= 65535 && C > 0 && C <= 4096 &&
+                          (act == SBA_ACT_GLU ? (C / 2) % Vw == 0 && C % 2 == 0 : C % Vw == 0);
+    if (!y || !gamma || !beta || !aux || !out || !shape_ok) return SBA_E_ARG;
     if (training ? !stats : (!running_mean || !running_var)) return SBA_E_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return SBA_E_ARG;
     if (act == SBA_ACT_GLU && residual) return SBA_E_ARG;
@@ -855,6 +861,13 @@ extern "C" int sba_bn_act_fwd(int dtype, const void* y, const float* stats, cons
     if (out_cstride < Co + out_coff || out_cstride % V || out_coff % V) return SBA_E_ARG;
     const int blocks = grid_for(rows * (Co / V));
     const size_t sh = 2 * (size_t)C * sizeof(float);
+    if (act == SBA_ACT_RELU) {
+        SBA_DISPATCH_Y(dtype, SBA_LAUNCH((bn_act_fwd_kernel<T, YT, SBA_ACT_RELU>), dim3(blocks, groups), dim3(256), sh,
+                                         (hipStream_t)stream, (const YT*)y, stats, gamma, beta, running_mean, running_var,
+                                         num_batches_tracked, aux, (const T*)residual, (T*)out, rows, C, out_cstride,
+                                         out_coff, eps, momentum, training));
+        return SBA_CHECK_LAUNCH();
+    }
     SBA_DISPATCH_Y(dtype, ACT_SWITCH(act, SBA_LAUNCH((bn_act_fwd_kernel<T, YT, ACT>), dim3(blocks, groups),
                                                            dim3(256), sh, (hipStream_t)stream, (const YT*)y, stats,
                                                            gamma, beta, running_mean, running_var,

@@ -51,7 +51,8 @@ class DAMSMStep(object):
 
     def image_forward(self, img):
         """CNN_ENCODER.forward (model.py:207-267) with gradients only into emb_features / emb_cnn_code."""
-        f768, pooled = self.trunk.trunk_features(img)                       # [B,17,17,768], [B,2048]
+        # (training mode = the reference's cnn_model.train(): BatchNorm with batch statistics, running statistics moved)
+        f768, pooled = self.trunk.trunk_features(img, train=self.image_encoder.training)    # [B,17,17,768], [B,2048]
         B = f768.shape[0]
         w = self.image_encoder.emb_features.weight.view(-1, 768)           # [nef, 768]
         feat = torch.matmul(f768.view(B, 289, 768), w.t())                  # [B, 289, nef]

@@ -58,6 +58,7 @@ class _Conv(object):
             b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(O, device=dev)
         self.O, self.I, self.KH, self.KW = O, I, KH, KW
         self.Op, self.Ip = _pad32(O), _pad32(I)
+        self.bn, self.conv_mod, self._w_raw = bn, conv, None
         self.stride = conv.stride[0]
         self.ph, self.pw = conv.padding
         self.relu = relu
@@ -79,6 +80,18 @@ class _Conv(object):
                     idx = torch.tensor([kh * KW + kw for kh, kw in sel], device=dev)
                     self.w_dgrad.append(wt[:, idx, :].to(dtype).contiguous())
                     self.dtaps.append([((py - kh) // 2, (px - kw) // 2) for kh, kw in sel])
+
+
+def _raw_weights(L, dtype):
+    """UNFOLDED packed weights [O][taps][Ip] of a BasicConv2d (training-mode BatchNorm: the conv output is normalised
+    with batch statistics, so the running statistics cannot be folded in)"""
+    if L._w_raw is None or L._w_raw.dtype != dtype:
+        w = L.conv_mod.weight.detach().float()
+        O, I, KH, KW = w.shape
+        wp = torch.zeros((O, KH * KW, L.Ip), dtype=torch.float32, device=w.device)
+        wp[:, :, :I] = w.permute(0, 2, 3, 1).reshape(O, KH * KW, I)
+        L._w_raw = wp.to(dtype).contiguous()
+    return L._w_raw
 
 
 class _FusedHeads(object):
@@ -130,6 +143,7 @@ class InceptionHIP(object):
         # 120..273-workgroup launch each (hipGraph replay runs the side streams back to back anyway, ROCm 7.2)
         self.group = os.environ.get('SBA_ENC_GROUP', '1') == '1' and self.dtype == torch.bfloat16
         self._thunks = None          # forward: launch closures of the branch being recorded
+        self._train = False          # trunk_features(train=True): BatchNorm with batch statistics (DAMSM pre-training)
         self._keep = []
         self._pending = None         # implicit-GEMM launches collected for the current level
         dev = next(enc.parameters()).device
@@ -152,12 +166,51 @@ class InceptionHIP(object):
             memory_format=torch.channels_last)
         self.stem_b = (stem.bn.bias.detach().float() - stem.bn.running_mean.detach().float() * s).contiguous()
 
+    def refold(self):
+        """rebuild the folded (eval-mode) operands from the module's current BatchNorm buffers"""
+        for name, m in self.enc.named_modules():
+            if m.__class__.__name__ == 'BasicConv2d':
+                self._convs[name] = _Conv(m.conv, m.bn, self.dtype)
+        self._fused = {}
+        stem = self.enc.Conv2d_1a_3x3
+        s = stem.bn.weight.detach().float() / torch.sqrt(stem.bn.running_var.detach().float() + stem.bn.eps)
+        self.stem_w = (stem.conv.weight.detach().float() * s.view(-1, 1, 1, 1)).contiguous(
+            memory_format=torch.channels_last)
+        self.stem_b = (stem.bn.bias.detach().float() - stem.bn.running_mean.detach().float() * s).contiguous()
+
     # ------------------------------------------------------------------ primitive ops
     def _dt(self):
         return _lib.SBA_BF16 if self.dtype == torch.bfloat16 else _lib.SBA_F32
 
     def _new(self, N, H, W, C):
+        if self._train:     # padding channels are not written by the BatchNorm pass: they must read as zeros
+            return torch.zeros((N, H, W, C), dtype=self.dtype, device=self.device)
         return torch.empty((N, H, W, C), dtype=self.dtype, device=self.device)
+
+    def _bn_relu_train(self, y, bn, rows, O, out_t, ocs, oco, stats=None):
+        """BatchNorm2d(train: batch statistics, eps 1e-3, momentum 0.1, running statistics updated in place) + ReLU of
+        a dense [rows][O] tensor y into channels [oco, oco + O) of out_t"""
+        dt = self._dt()
+        if stats is None:
+            stats = torch.zeros((ops.BN_STAT_SLOTS, 2 * O), dtype=torch.float32, device=self.device)
+            call('sba_bn_stats', dt, y.data_ptr(), stats.data_ptr(), rows, 1, O, ops._stream())
+        aux = torch.empty((4, O), dtype=torch.float32, device=self.device)
+        call('sba_bn_act_fwd', dt, y.data_ptr(), stats.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
+             bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(), aux.data_ptr(),
+             None, out_t.data_ptr(), rows, 1, O, _lib.ACT_RELU, ocs, oco, BN_EPS, 0.1, 1, ops._stream())
+
+    def _conv_train(self, L, x, out, OH, OW):
+        """BasicConv2d in TRAINING mode (pretrain_DAMSM.py:51 cnn_model.train(); weights frozen, model.py:174-175):
+        conv with the unfolded weights (statistics of the f32 accumulators in its epilogue) -> BatchNorm + ReLU"""
+        N, H, W, Ct = x.shape
+        y = torch.empty((N, OH, OW, L.O), dtype=self.dtype, device=self.device)
+        stats = torch.zeros((ops.BN_STAT_SLOTS, 2 * L.O), dtype=torch.float32, device=self.device)
+        taps = [(t // L.KW - L.ph, t % L.KW - L.pw) for t in range(L.KH * L.KW)]
+        g = _geom(N, H, W, L.Ip, OH, OW, L.O, taps, sy=L.stride, xcs=Ct, xco=x.coff)
+        ws = ops.workspace(self.device)
+        call('sba_conv_igemm', self._dt(), x.t.data_ptr(), _raw_weights(L, self.dtype).data_ptr(), y.data_ptr(), None,
+             stats.data_ptr(), ctypes.byref(g), ws.data_ptr(), ops.WORKSPACE_BYTES, ops._stream())
+        self._bn_relu_train(y, L.bn, N * OH * OW, L.O, out.t, out.shape[3], out.coff, stats)
 
     def _igemm(self, x_ptr, w, y_ptr, addend_ptr, bias, g, mask_ptr=None):
         if self._pending is not None:
@@ -227,6 +280,9 @@ class InceptionHIP(object):
         if out is None:
             out = _Act(self._new(N, OH, OW, L.Op))
         assert out.C == L.Op and out.shape[1] == OH and out.shape[2] == OW, (name, out.C, L.Op)
+        if self._train and getattr(L, 'bn', None) is not None:
+            self._conv_train(L, x, out, OH, OW)
+            return out
         taps = [(t // L.KW - L.ph, t % L.KW - L.pw) for t in range(L.KH * L.KW)]
         g = _geom(N, H, W, L.Ip, OH, OW, L.Op, taps, sy=L.stride, xcs=Ct, xco=x.coff, ycs=out.shape[3],
                   yco=out.coff, relu=1 if L.relu else 0)
@@ -416,7 +472,13 @@ class InceptionHIP(object):
         per-branch views in the order of `names`"""
         f = self.fused(names)
         self._branch_ops = self._block_pre                 # recorded as a main-stream op of the block
-        self.conv_L(f, x, _Act(ext, 0, f.Op))
+        if self._train:     # training-mode BatchNorm: no folded (hence no fused) operands -- one conv per head
+            off = 0
+            for c in f.parts:
+                self.conv_L(c, x, _Act(ext, off, c.Op))
+                off += c.Op
+        else:
+            self.conv_L(f, x, _Act(ext, 0, f.Op))
         self._branch_ops = None
         views, off = [], 0
         for c in f.parts:
@@ -547,6 +609,9 @@ class InceptionHIP(object):
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, img):
+        if not self._train and getattr(self, '_stale', False):
+            self.refold()
+            self._stale = False
         img = img.float().contiguous()
         N, _, S, _ = img.shape
         dt = self._dt()
@@ -557,8 +622,15 @@ class InceptionHIP(object):
         x299 = torch.empty((N, 3, 299, 299), dtype=torch.float32, device=self.device)
         call('sba_resize_bilinear', img.data_ptr(), x299.data_ptr(), N * 3, S, 299, 0, st)
         a0 = _Act(self._new(N, 149, 149, 32))
-        call('sba_enc_stem_fwd', dt, x299.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(),
-             a0.t.data_ptr(), N, 299, 32, st)
+        if self._train:
+            stem = self.enc.Conv2d_1a_3x3
+            wraw = stem.conv.weight.detach().float().contiguous(memory_format=torch.channels_last)
+            y0 = torch.empty((N, 149, 149, 32), dtype=self.dtype, device=self.device)
+            call('sba_enc_stem_fwd', dt, x299.data_ptr(), wraw.data_ptr(), None, y0.data_ptr(), N, 299, 32, st)
+            self._bn_relu_train(y0, stem.bn, N * 149 * 149, 32, a0.t, 32, 0)
+        else:
+            call('sba_enc_stem_fwd', dt, x299.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(),
+                 a0.t.data_ptr(), N, 299, 32, st)
         nm = self.named
         nm['Conv2d_1a_3x3'] = a0
         a = nm['Conv2d_2a_3x3'] = self.conv('Conv2d_2a_3x3', a0)
@@ -588,12 +660,26 @@ class InceptionHIP(object):
         self._saved = (img.shape, x299, a0, f, a, pooled_t, code)
         return features[:, :nef], code.t.view(N, -1)[:, :nef].float()
 
-    def trunk_features(self, img):
+    def trunk_features(self, img, train=False):
         """The FROZEN part only, without a tape: (Mixed_6e output B x 768 x 17 x 17 as an NHWC f32 tensor
         [B, 17, 17, 768], pooled Mixed_7c output [B, 2048] f32) -- the inputs of the two trainable embedding layers
-        (emb_features, emb_cnn_code) that the DAMSM pre-training loop updates (pretrain_DAMSM.py:62-75)."""
+        (emb_features, emb_cnn_code) that the DAMSM pre-training loop updates (pretrain_DAMSM.py:62-75).
+
+        train=True: the reference's pre-training loop runs the whole encoder in TRAINING mode (pretrain_DAMSM.py:51
+        cnn_model.train()): the Inception weights are frozen (model.py:174-175) but every BatchNorm normalises with
+        BATCH statistics and moves its running statistics (momentum 0.1) -- those updated buffers are what
+        image_encoder*.pth carries into the GAN.  Each BasicConv2d then runs as conv (unfolded weights, statistics in
+        the epilogue) + one BatchNorm/ReLU pass; train=False (evaluate(), pretrain_DAMSM.py:134) is the folded trunk."""
         with torch.no_grad():
-            self.forward(img)
+            saved = (self._train, self.group, self.parallel)
+            if train:
+                self._train, self.group, self.parallel = True, False, False
+            try:
+                self.forward(img)
+            finally:
+                self._train, self.group, self.parallel = saved
+            if train:       # the folded operands of the next eval-mode call must see the moved running statistics
+                self._stale = True
             (_, _, _, _, last, pooled_t, _) = self._saved
             feat_in = self.named['Mixed_6e']
             f768 = feat_in.t[..., feat_in.coff:feat_in.coff + 768].float().contiguous()
