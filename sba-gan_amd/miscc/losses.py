@@ -98,10 +98,27 @@ def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size)
     return l0, l1, []
 
 
-def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake_labels):
+def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake_labels, real_features=None):
     """losses.py:136-161: two separate trunk passes (real, fake.detach()), five heads,
-    errD = (real + cond_real)/2 + (fake + cond_fake + cond_wrong)/3."""
-    if BATCH_REAL_FAKE and real_imgs.shape == fake_imgs.shape:
+    errD = (real + cond_real)/2 + (fake + cond_fake + cond_wrong)/3.
+
+    real_features (optional, beyond the reference's signature): netD(real_imgs) evaluated AHEAD of this call (the
+    data-parallel step runs it beside the generator's gradient exchange: it does not depend on the generator); the
+    fake half then runs as its own pass, in the reference's order (real first), with the same per-pass BatchNorm
+    batches and running-statistic updates."""
+    feats = None
+    if real_features is not None:
+        n = real_features.size(0)
+        fake_features = netD(fake_imgs.detach())
+        if FUSED_HEADS and fake_features.shape == real_features.shape:
+            feats = torch.cat((real_features, fake_features), 0)
+            if netD.UNCOND_DNET is not None:
+                heads = ((0, n, 0, 1., .5, 1), (n, n, 0, 0., 1. / 3, 3), (0, n - 1, 1, 0., 1. / 3, 4),
+                         (0, n, None, 1., .5, 0), (n, n, None, 0., 1. / 3, 2))
+            else:
+                heads = ((0, n, 0, 1., 1., 0), (n, n, 0, 0., .5, 1), (0, n - 1, 1, 0., .5, 2))
+            return ops.d_heads(netD, feats, conditions, heads)
+    elif BATCH_REAL_FAKE and real_imgs.shape == fake_imgs.shape:
         # one trunk pass over [real | fake] with per-half BatchNorm batches: same results and module
         # state as the reference's two calls, half the launches and weight reads
         n = real_imgs.size(0)
@@ -111,7 +128,7 @@ def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake
         real_features = netD(real_imgs)
         fake_features = netD(fake_imgs.detach())
     batch_size = real_features.size(0)
-    if FUSED_HEADS and BATCH_REAL_FAKE and real_imgs.shape == fake_imgs.shape:
+    if FUSED_HEADS and feats is not None:
         # the five heads + the BCE sum as one autograd node over the [real | fake] feature map (ops.DHeadsFn):
         # evaluated in the reference's call order, summed in the order of the terms of errD
         n = batch_size

@@ -50,6 +50,7 @@ class FlatParams(object):
             p.data = view
             p.grad = self.grad[o:o + k].as_strided(p.shape, p.stride())
         self.offsets = offs
+        self.offset_of = {id(p): o for p, o in zip(params, offs)}
         self.avg = self.data.clone() if with_ema else None
         self.epoch = [0]
         ops.register_epoch(params, self.epoch)
@@ -165,9 +166,64 @@ class GANStep(object):
         self.exchange = GradExchange(dev, enabled=distributed)
         self.distributed, self.world = self.exchange.enabled, self.exchange.world
         self._d_params = [p for d in netsD for p in d.parameters()]
+        # data-parallel: where each discriminator's second gradient bucket starts in its flat buffer (None: one bucket)
+        self._bucket_off = []
+        for d, f in zip(netsD, self.flatD):
+            name = getattr(d, 'bucket_from', None)
+            first = next(getattr(d, name).parameters()) if name else None
+            self._bucket_off.append(None if first is None else f.offset_of[id(first)])
+        self._real_feats = [None] * len(netsD)
+        self._g_pending = None
+        self._d_buckets = {}
 
     def _allreduce_start(self, flat):
         return self.exchange.start(flat.grad)
+
+    # ---- data-parallel overlap (new functionality) --------------------------------------------------
+    # (1) generator: its all-reduce is issued right behind its backward pass and NOT waited for; the Adam + EMA update
+    #     is applied at the start of the next step (or by finish()), after everything of that step that does not
+    #     depend on the generator has been issued: the frozen text encoder (the caller's prologue, trainer.py:248-252)
+    #     and the three discriminators' forward passes on the REAL images (losses.py:139) -- which is why the
+    #     data-parallel discriminator loss runs the real and the fake half as two passes (the reference's own shape)
+    #     instead of one grouped pass.
+    # (2) discriminators: D_NET128 / D_NET256 exchange their gradients in two buckets.  The backward pass reaches the
+    #     tail of the network first (D_NET256: img_code_s64 .. heads = 242 of 287 MB): its all-reduce starts there and
+    #     runs under the rest of the backward pass (the large-map layers, most of the time) instead of behind it.
+    bucket_d = True
+    overlap_g = True
+    force_overlap_layout = False    # tests: a SINGLE-process step with the data-parallel launch decomposition (real-image
+    #                                 forwards ahead as their own passes, split backward passes) -- what a rank of the
+    #                                 data-parallel step must reproduce bit for bit in the deterministic mode
+
+    def _two_pass(self):
+        return (self.distributed and self.overlap_g) or self.force_overlap_layout
+
+    def phase_pre(self, imgs, streams=None):
+        """netD_i(real_i) for every discriminator, ahead of the generator's (pending) update; a no-op outside the
+        overlapped data-parallel mode.  streams[i]: the stream discriminator i's update will run on -- autograd
+        replays a node's backward on the stream of its forward, and the two passes of one network add into the same
+        weight gradients, so both must live on ONE stream."""
+        self._real_feats = [None] * len(self.netsD)
+        if not self._two_pass():
+            return
+        ops.SIDE_WGRAD = False
+        main = torch.cuda.current_stream()
+        for i, d in enumerate(self.netsD):
+            st = streams[i] if streams is not None else main
+            if st is not main:
+                st.wait_stream(main)
+            with torch.cuda.stream(st):
+                d.clear_cuts()
+                self._real_feats[i] = d(imgs[i])
+
+    def finish(self):
+        """Apply a pending generator update (overlapped data-parallel mode: the last step's all-reduce may still be in
+        flight and its Adam + EMA step not applied).  Call before reading the generator: checkpoints, sampling,
+        snapshot(); the next step() does it by itself."""
+        if self._g_pending is not None:
+            h, self._g_pending = self._g_pending, None
+            self._allreduce_wait(h[0])
+            self.optG.step(1.0 / self.world)
 
     def _allreduce_wait(self, h):
         self.exchange.wait(h)
@@ -194,32 +250,79 @@ class GANStep(object):
         self._damsm = damsm_image_terms(self.image_encoder, fake_imgs[-1], words_embs, sent_emb, self.match_labels,
                                         cap_lens, class_ids)
 
-    def phase_d_bwd(self, i, imgs, sent_emb, forked):
-        """loss + backward of discriminator i on the CURRENT stream; returns the stream on which the update
-        must continue (the weight-gradient companion when `forked`, see ops.wgrad_tail_stream)."""
+    def phase_d_bwd_tail(self, i, imgs, sent_emb):
+        """loss of discriminator i and the backward pass down to its bucket boundary (the whole backward pass when the
+        network exchanges one bucket); returns True when phase_d_bwd_rest has work left"""
         fake_imgs = self._ctx[0]
+        netD = self.netsD[i]
         ops.SIDE_WGRAD = self.overlap_wgrad and self.overlap_wgrad_d
         self.flatD[i].zero_grad()
-        errD = discriminator_loss(self.netsD[i], imgs[i], fake_imgs[i], sent_emb, self.real_labels,
-                                  self.fake_labels)
-        errD.backward()
+        rf = self._real_feats[i]
+        self._real_feats[i] = None
+        split = ((self.distributed and self.bucket_d) or self.force_overlap_layout) and \
+            self._bucket_off[i] is not None and not ops.SIDE_WGRAD
+        if rf is None:
+            netD.clear_cuts(record=split)
+        errD = discriminator_loss(netD, imgs[i], fake_imgs[i], sent_emb, self.real_labels, self.fake_labels,
+                                  real_features=rf)
+        cuts = list(netD._cuts)
+        netD.clear_cuts(record=False)
         self._out['errD%d' % i] = errD.detach()
+        if split and cuts:
+            gcuts = torch.autograd.grad(errD, cuts)         # heads + tail: their parameter gradients are complete now
+            self._d_buckets[i] = (cuts, gcuts)
+            return True
+        errD.backward()
+        return False
+
+    def phase_d_bwd_rest(self, i):
+        cuts, gcuts = self._d_buckets.pop(i)
+        torch.autograd.backward(cuts, gcuts)
+
+    def _d_exchange(self, i, split_done):
+        """all-reduce handles of discriminator i's gradient: the whole flat buffer, or (bucketed) its head part --
+        the tail part was started by the caller between the two halves of the backward pass"""
+        off = self._bucket_off[i]
+        g = self.flatD[i].grad
+        return self.exchange.start(g[:off] if split_done else g)
+
+    def phase_d_bwd(self, i, imgs, sent_emb, forked):
+        """loss + backward of discriminator i on the CURRENT stream (data-parallel: with the gradient exchange started
+        bucket by bucket); returns (the stream on which the update must continue -- the weight-gradient companion
+        when `forked`, see ops.wgrad_tail_stream --, the exchange handles to wait for)"""
+        handles = []
+        if self.phase_d_bwd_tail(i, imgs, sent_emb):
+            if self.distributed:
+                handles.append(self.exchange.start(self.flatD[i].grad[self._bucket_off[i]:]))
+            self.phase_d_bwd_rest(i)
+            split = True
+        else:
+            split = False
         if forked:
             tail = ops.wgrad_tail_stream()
         else:
             ops.join_wgrads()
             tail = torch.cuda.current_stream()
         ops.SIDE_WGRAD = self.overlap_wgrad
-        return tail
+        if self.distributed:
+            with torch.cuda.stream(tail):
+                handles.append(self._d_exchange(i, split))
+        return tail, handles
+
+    def phase_d_bwd_join(self):
+        """end of a discriminator's backward pass on the current stream (per-phase graph capture)"""
+        ops.join_wgrads()
+        ops.SIDE_WGRAD = self.overlap_wgrad
 
     def phase_d_opt(self, i):
         """Adam step of discriminator i (its averaged gradient must be in place)."""
         self.optD[i].step(1.0 / self.world)
 
     def phase_d(self, i, imgs, sent_emb, forked):
-        tail = self.phase_d_bwd(i, imgs, sent_emb, forked)
+        tail, handles = self.phase_d_bwd(i, imgs, sent_emb, forked)
         with torch.cuda.stream(tail):
-            self._allreduce_wait(self._allreduce_start(self.flatD[i]))
+            for h in handles:
+                self._allreduce_wait(h)
             self.phase_d_opt(i)
         return tail
 
@@ -262,6 +365,14 @@ class GANStep(object):
 
     def phase_b(self, sent_emb, words_embs, cap_lens, class_ids):
         self.phase_b_bwd(sent_emb, words_embs, cap_lens, class_ids)
+        if self.distributed and self.overlap_g:
+            # the exchange runs behind this step; the update is applied by the next step (after its text encoder and
+            # real-image forwards have been issued) or by finish()
+            self._g_pending = (self._allreduce_start(self.flatG),)
+            self._mark('g_adam')
+            ops.ARENA.end()
+            ops.SIDE_WGRAD = False
+            return self._out
         self._allreduce_wait(self._allreduce_start(self.flatG))
         return self.phase_b_opt()
 
@@ -269,14 +380,16 @@ class GANStep(object):
         """Returns a dict of DEVICE scalars (errD0.., errG_total, kl_loss, g_loss*, w_loss, s_loss)."""
         mark = self._mark
         mark('start')
+        main = torch.cuda.current_stream()
+        nD = len(self.netsD)
+        streams = self._d_streams()[:nD] if self.concurrent_d else [main] * nD
+        self.phase_pre(imgs, streams)         # (data-parallel: beside the generator's pending gradient exchange)
+        self.finish()
         self.phase_a(sent_emb, words_embs, mask, noise, eps)
         mark('g_forward')
         # The three discriminator updates are independent of each other (different networks, the
         # same detached fakes): each runs on its own HIP stream so that the small launches of the
         # 4x4 / 8x8 layers of one network fill CUs the others leave idle.
-        main = torch.cuda.current_stream()
-        nD = len(self.netsD)
-        streams = self._d_streams()[:nD] if self.concurrent_d else [main] * nD
         tails = []
         for i in range(nD):
             st = streams[i]
@@ -329,6 +442,7 @@ class GANStep(object):
     def snapshot(self):
         """Device copies of everything a step mutates: parameters, Adam moments and step counters, the EMA
         shadow, BatchNorm running statistics / batch counters."""
+        self.finish()
         snap = []
         for net, flat, opt in self._trained():
             snap.append({'data': flat.data.clone(), 'm': flat.m.clone(), 'v': flat.v.clone(),
@@ -405,8 +519,15 @@ class GraphedStep(object):
             torch.cuda.current_stream().wait_stream(stream)
         eager_on(self.cap)                       # warm the capture stream (its split-K workspace)
         torch.cuda.synchronize()
+        gan.finish()                             # (data-parallel: the warm-up step's generator update may be pending)
         self.gA, self.gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         self.gD = [torch.cuda.CUDAGraph() for _ in range(nD)]
+        self.gPre, self._pending = None, None
+        if gan.distributed and gan.overlap_g:
+            # the discriminators' forward passes on the real images: replayed BEFORE the generator's pending update
+            self.gPre = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.gPre, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
+                gan.phase_pre(imgs)
         if single and not gan.distributed:       # the whole step as ONE graph, discriminator updates as forked branches
             with torch.cuda.graph(self.gA, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
                 if prologue is not None:
@@ -427,11 +548,21 @@ class GraphedStep(object):
         if gan.distributed:
             # the gradient exchange (RCCL) stays OUTSIDE the graphs: per network one graph for loss +
             # backward and one for the Adam step, the all-reduce issued eagerly between them
+            # (a bucketed discriminator: one graph down to the bucket boundary, one for the rest of its backward pass,
+            # the tail bucket's all-reduce issued between them)
             self.gDo = [torch.cuda.CUDAGraph() for _ in range(nD)]
+            self.gD2 = [None] * nD
             self.gBo = torch.cuda.CUDAGraph()
             for i in range(nD):
                 with torch.cuda.graph(self.gD[i], stream=self.cap, capture_error_mode=_CAPTURE_MODE):
-                    gan.phase_d_bwd(i, imgs, sent_emb, forked=False)
+                    split = gan.phase_d_bwd_tail(i, imgs, sent_emb)
+                    if not split:
+                        gan.phase_d_bwd_join()
+                if split:
+                    self.gD2[i] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.gD2[i], stream=self.cap, capture_error_mode=_CAPTURE_MODE):
+                        gan.phase_d_bwd_rest(i)
+                        gan.phase_d_bwd_join()
                 with torch.cuda.graph(self.gDo[i], stream=self.cap, capture_error_mode=_CAPTURE_MODE):
                     gan.phase_d_opt(i)
             with torch.cuda.graph(self.gB, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
@@ -457,11 +588,21 @@ class GraphedStep(object):
                 flat.packs.refresh(dt)
         ops.weights_changed()
 
+    def finish(self):
+        """data-parallel, overlapped generator exchange: apply the pending generator update (see GANStep.finish)"""
+        if self._pending is not None:
+            h, self._pending = self._pending, None
+            self.gan._allreduce_wait(h[0])
+            self.gBo.replay()
+
     def replay(self):
         main = torch.cuda.current_stream()
         # the graphs repack the bf16 weight copies at the points where the capture did, without consulting the
         # host-side change counters; invalidate those so that an EAGER call after a replay repacks as well
         ops.weights_changed()
+        if self.gPre is not None:
+            self.gPre.replay()      # netD_i(real_i): beside the generator's all-reduce of the previous replay
+            self.finish()
         self.gA.replay()
         if self.single:
             return self.out
@@ -480,13 +621,22 @@ class GraphedStep(object):
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
                     self.gD[i].replay()
-                    gan._allreduce_wait(gan._allreduce_start(gan.flatD[i]))
+                    handles = []
+                    if self.gD2[i] is not None:
+                        handles.append(gan.exchange.start(gan.flatD[i].grad[gan._bucket_off[i]:]))
+                        self.gD2[i].replay()
+                    handles.append(gan._d_exchange(i, self.gD2[i] is not None))
+                    for h in handles:
+                        gan._allreduce_wait(h)
                     self.gDo[i].replay()
             for st in self.dstreams:
                 main.wait_stream(st)
             if self.gE is not None:
                 main.wait_stream(self.estream)
             self.gB.replay()
+            if self.gPre is not None:
+                self._pending = (gan._allreduce_start(gan.flatG),)  # applied by the next replay / finish()
+                return self.out
             gan._allreduce_wait(gan._allreduce_start(gan.flatG))
             self.gBo.replay()
             return self.out

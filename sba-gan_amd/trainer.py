@@ -181,6 +181,7 @@ class condGANTrainer(object):
                           ' '.join('g_loss%d: %.2f' % (i, v['g_loss%d' % i]) for i in range(nD)) +
                           ' w_loss: %.2f s_loss: %.2f kl_loss: %.2f' % (v['w_loss'], v['s_loss'], v['kl_loss']))
                 if gen_iterations % 1000 == 0:
+                    gan.finish()        # (data-parallel: a pending generator update is applied before it is read)
                     backup_para = copy_G_params(netG)
                     load_params(netG, gan.flatG.ema_params())
                     self.save_img_results(netG, fixed_noise, sent_emb, words_embs, mask, image_encoder, captions,
@@ -195,9 +196,11 @@ class condGANTrainer(object):
                       % (epoch, self.max_epoch, self.num_batches, errD_total, float(out['errG_total']),
                          end_t - start_t))
             if epoch % cfg.TRAIN.SNAPSHOT_INTERVAL == 0:
+                gan.finish()
                 self.save_model(netG, gan.flatG.ema_params(), netsD, epoch)
             if max_steps is not None and gen_iterations >= max_steps:
                 break
+        gan.finish()
         self.save_model(netG, gan.flatG.ema_params(), netsD, self.max_epoch)
 
     # ------------------------------------------------------------------ inference (trainer.py:348-518)

@@ -35,7 +35,8 @@ def build(dev, B, distributed):
     for d in netsD:
         d.to(dev).train()
     netG.set_return_attention(False)
-    enc = fill.StandInImageEncoder(256, device=dev)
+    from test_determinism_gpu import _OrderedStandIn      # (torch's adaptive_avg_pool2d backward adds with atomics)
+    enc = _OrderedStandIn(256, device=dev)
     return GANStep(netG, netsD, enc, B, lr_g=2e-4, lr_d=2e-4, distributed=distributed)
 
 
@@ -71,20 +72,45 @@ def main():
     imgs = [i.to(dev) for i in x['imgs']]
     sent, words, mask, lens = x['sent'].to(dev), x['words'].to(dev), x['mask'].to(dev), x['cap_lens'].to(dev)
     noise, eps = fill.unit((B, 100), 550 + rank).to(dev), fill.unit((B, 100), 560 + rank).to(dev)
+    noise_in = noise
     args = (imgs, sent, words, mask, lens, x['class_ids'], noise, eps)
 
     dp = build(dev, B, True)
     assert dp.distributed and dp.world == world
     solo = build(dev, B, False)
+    # the single-process yardstick runs the data-parallel step's launch decomposition (real-image forwards ahead as
+    # their own passes, bucketed backward passes), so that "equal" can mean bit-equal: on this fixture the discriminators'
+    # logits are saturated (BCELoss's log clamp), and a 1e-7 difference in summation order between a grouped and a
+    # two-pass BatchNorm statistics sum moves D_NET256's gradient by tens of percent
+    solo.force_overlap_layout = True
     p0 = [f.data.clone() for f in [dp.flatG] + dp.flatD]
     local = {}
     orig_start = dp.exchange.start
 
-    def start(flat_grad):                 # keep this rank's gradient as it was BEFORE the exchange
+    def start(flat_grad):                 # keep this rank's gradient as it was BEFORE the exchange (bucket by bucket)
         local[flat_grad.data_ptr()] = flat_grad.clone()
         return orig_start(flat_grad)
     dp.exchange.start = start
+    assert dp.bucket_d and dp.overlap_g
     out_dp = dp.step(*args)
+    # the generator's update is deferred to the next step (its exchange overlaps that step's real-image forwards)
+    pG = dp.flatG.data.clone()
+    expect_pending = dp._g_pending is not None
+    dp.finish()
+    assert expect_pending and not torch.equal(pG, dp.flatG.data), 'generator update was not deferred / not applied'
+
+    def local_grad(flat):
+        """this rank's pre-exchange gradient of a network, reassembled from its buckets"""
+        base, esz = flat.grad.data_ptr(), flat.grad.element_size()
+        out = torch.empty_like(flat.grad)
+        covered = 0
+        for ptr, t in local.items():
+            o = (ptr - base) // esz
+            if 0 <= o < flat.grad.numel() and (ptr - base) % esz == 0 and o + t.numel() <= flat.grad.numel():
+                out[o:o + t.numel()] = t
+                covered += t.numel()
+        assert covered == flat.grad.numel(), (covered, flat.grad.numel())
+        return out
     snap = solo.snapshot()
     out_solo = solo.step(*args)
     torch.cuda.synchronize()
@@ -108,11 +134,14 @@ def main():
         expect(abs(a - b) <= 1e-5 * abs(b), 'errD%d: data-parallel %r vs single-process %r' % (i, a, b))
     for k, (fd, fs) in enumerate(zip(flats_dp, flats_solo)):
         name = 'G' if k == 0 else 'D%d' % (k - 1)
-        mine = local[fd.grad.data_ptr()]
+        mine = local_grad(fd)
         if k > 0:       # discriminators: the local gradient IS the single-process gradient on this batch
             r = rel_l2(mine, solo_grads[k])
             expect(torch.equal(mine, solo_grads[k]), '%s: local gradient differs from the single-process run (rel L2 '
                    '%.2e, single-process run-to-run difference %.2e)' % (name, r, noise[k]))
+            if k > 1:   # D_NET128 / D_NET256 went out in two buckets
+                expect(sum(1 for p in local if fd.grad.data_ptr() <= p < fd.grad.data_ptr() + fd.grad.numel() * 4) == 2,
+                       '%s: expected two gradient buckets' % name)
         gathered = [torch.empty_like(mine).cpu() for _ in range(world)]
         dist.all_gather(gathered, mine.cpu())
         total = gathered[0].clone()
@@ -131,6 +160,53 @@ def main():
         both = [torch.empty_like(fd.data).cpu() for _ in range(world)]
         dist.all_gather(both, fd.data.cpu())
         expect(all(torch.equal(both[0], t) for t in both[1:]), '%s: replicas diverged after one step' % name)
+    # ---- the same data-parallel step replayed from per-phase hipGraphs (the launch mode bench.py uses for N > 1): the
+    # real-image forwards as their own graph ahead of the deferred generator update, every bucketed discriminator as
+    # two backward graphs with the tail bucket's all-reduce between them -- two replays + finish() must leave every
+    # parameter, Adam moment and BatchNorm buffer bit-identical to two eager data-parallel steps from the same state
+    from sbagan.trainer import GraphedStep
+    orig_a = dp.phase_a
+    dp.phase_a = lambda se, we, m, nz, e=None: orig_a(se, we, m, nz, eps)        # fixed eps, eager and captured
+    dp.exchange.start = orig_start
+    gargs = (imgs, sent, words, mask, lens, x['class_ids'], noise_in)
+    snap_dp = dp.snapshot()
+    dp.early_damsm = False          # the per-phase graphs keep the ranking terms inside the generator-loss phase
+
+    def state_names():
+        names = []
+        for k, f in enumerate(flats_dp):
+            nm = 'G' if k == 0 else 'D%d' % (k - 1)
+            names += ['%s.%s' % (nm, t) for t in ('data', 'm', 'v', 'grad')]
+        for k, net in enumerate([dp.netG] + dp.netsD):
+            names += ['%s.%s' % ('G' if k == 0 else 'D%d' % (k - 1), n) for n, _ in net.named_buffers()]
+        return names
+
+    def state():
+        return [t for f in flats_dp for t in (f.data, f.m, f.v, f.grad)] + \
+               [b for net in [dp.netG] + dp.netsD for _, b in net.named_buffers()]
+    eager_out = None
+    for _ in range(2):
+        eager_out = dp.step(*gargs)
+    dp.finish()
+    dp.early_damsm = True
+    torch.cuda.synchronize()
+    want = [t.clone() for t in state()]
+    want_out = {k: float(v) for k, v in eager_out.items()}
+    graph = GraphedStep(dp, *gargs)
+    expect(graph.gPre is not None and any(g2 is not None for g2 in graph.gD2), 'overlap graphs were not captured')
+    dp.restore(snap_dp)
+    graph.resync()
+    for _ in range(2):
+        graph.replay()
+    graph.finish()
+    torch.cuda.synchronize()
+    got = state()
+    names = state_names()
+    bad = [(names[i], rel_l2(a.float(), b.float())) for i, (a, b) in enumerate(zip(got, want)) if not torch.equal(a, b)]
+    got_out = {k: float(v) for k, v in graph.out.items()}
+    bad_out = [(k, got_out[k], want_out[k]) for k in want_out if got_out[k] != want_out[k]]
+    expect(not bad and not bad_out, 'hipGraph replay of the data-parallel step differs from the eager data-parallel step '
+           'in %d tensors: %r; losses %r' % (len(bad), bad[:12], bad_out[:6]))
     # generator: its local gradient is taken against the UPDATED (replica-identical) discriminators, so it
     # differs from the single-process run, whose discriminators moved by the local gradient only
     expect(bool(torch.isfinite(out_dp['errG_total'])), 'errG_total not finite')
