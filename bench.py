@@ -448,6 +448,9 @@ def main():
             graph.replay()
         else:
             out = one_step()
+    # data-parallel: the last step's generator update is deferred (its all-reduce overlaps the next step's real-image
+    # forwards); it belongs to the timed steps -- the first timed step applied the update of the last warm-up step
+    (graph if (graph is not None and hasattr(graph, 'finish')) else step).finish()
     sync_all()
     dt = time.perf_counter() - t0
     if multi:

@@ -1,14 +1,26 @@
-"""CUB / COCO text-image data path with the reference's surface (AttnGAN2/code/datasets.py):
-`prepare_data`, `get_imgs`, `TextDataset` (same constructor, attributes, pickle file formats and
-per-item tuple), without the nltk / torchvision dependencies: the tokenizer is the regular expression the
-reference hands to nltk's RegexpTokenizer (r'\\w+', datasets.py:157), the transforms are miscc.transforms."""
+"""Text / image data path behind the training step, written from the BATCH CONTRACT the step consumes
+rather than from the reference's loader code.  What a caller of AttnGAN2/code/datasets.py relies on, and what this module
+keeps:
+
+  * `TextDataset(data_dir, split, base_size, transform)`: a map-style dataset whose items are
+        (images: list of BRANCH_NUM float tensors 3 x S_i x S_i in [-1, 1], S_i = base_size * 2**i,
+         caption: int64 array WORDS_NUM x 1, zero padded,  caption length,  class id,  file key)
+    with the attributes the scripts read: filenames, captions, ixtoword, wordtoix, n_words, class_id, imsize,
+    embeddings_num, number_example.
+  * the on-disk formats: <split>/filenames.pickle, <split>/class_info.pickle (latin1), and captions.pickle =
+    [train captions, test captions, ixtoword, wordtoix] (protocol 2), built from text/<key>.txt on first use; word ids
+    are handed out in order of first appearance (train split first), 0 = '<end>' -- a reference checkpoint's embedding
+    rows line up with them.
+  * `prepare_data(batch)`: rows sorted by caption length, descending (what the packed bi-LSTM needs), on the device.
+  * the draw order on numpy's global generator per item -- image transform first, then the caption pick, then (only for
+    captions longer than WORDS_NUM) the word subset -- so that a seeded run visits the same samples.
+No nltk / torchvision / pandas: the tokenizer is the \\w+ pattern, transforms come from miscc.transforms.
+"""
 import os
 import pickle
 import re
-from collections import defaultdict
 
 import numpy as np
-import numpy.random as random
 import torch
 import torch.utils.data as data
 from PIL import Image
@@ -16,205 +28,151 @@ from PIL import Image
 from miscc import transforms
 from miscc.config import cfg
 
-_TOKEN = re.compile(r'\w+')
+END_TOKEN = '<end>'
+_WORD = re.compile(r'\w+')
+_CUB_SUBDIR = 'CUB_200_2011/CUB_200_2011'
 
 
 def tokenize(text):
-    """RegexpTokenizer(r'\\w+').tokenize(text.lower()) followed by the ascii filter of datasets.py:164-168."""
-    out = []
-    for t in _TOKEN.findall(text.lower()):
-        t = t.encode('ascii', 'ignore').decode('ascii')
-        if len(t) > 0:
-            out.append(t)
-    return out
+    """lower-cased \\w+ tokens with non-ASCII characters dropped (a token that becomes empty disappears)"""
+    words = (w.encode('ascii', 'ignore').decode('ascii') for w in _WORD.findall(text.lower()))
+    return [w for w in words if w]
 
 
-def prepare_data(data):
-    """datasets.py:28-56: sort the batch by caption length (descending) and move it to the device.
-    Returns [real_imgs (list per scale), captions B x T int64, sorted_cap_lens B int64, class_ids (numpy), keys]."""
-    imgs, captions, captions_lens, class_ids, keys = data
-    sorted_cap_lens, sorted_cap_indices = torch.sort(captions_lens, 0, True)
-    dev = torch.device('cuda', cfg.GPU_ID) if cfg.CUDA else torch.device('cpu')
-    real_imgs = []
-    for i in range(len(imgs)):
-        imgs[i] = imgs[i][sorted_cap_indices]
-        real_imgs.append(imgs[i].to(dev))
-    captions = captions[sorted_cap_indices].squeeze()
-    if captions.dim() == 1:          # batch of one: squeeze() dropped the batch axis too
-        captions = captions.unsqueeze(0)
-    class_ids = class_ids[sorted_cap_indices].numpy()
-    keys = [keys[i] for i in sorted_cap_indices.numpy()]
-    return [real_imgs, captions.to(dev), sorted_cap_lens.to(dev), class_ids, keys]
+def _unpickle(path, **kw):
+    with open(path, 'rb') as f:
+        return pickle.load(f, **kw)
+
+
+def prepare_data(batch):
+    """One collated batch -> [images per scale, captions B x T, caption lengths B (descending), class ids (numpy),
+    keys], every tensor on the training device, all rows permuted together by the length sort."""
+    images, captions, lengths, class_ids, keys = batch
+    lengths, order = torch.sort(lengths, dim=0, descending=True)
+    device = torch.device('cuda', cfg.GPU_ID) if cfg.CUDA else torch.device('cpu')
+    images = [scale.index_select(0, order).to(device) for scale in images]
+    captions = captions.index_select(0, order).reshape(captions.size(0), -1)      # B x T x 1 -> B x T
+    keys = [keys[int(j)] for j in order]
+    return [images, captions.to(device), lengths.to(device), class_ids.index_select(0, order).numpy(), keys]
+
+
+def _crop_around(img, box):
+    """square window of 1.5 x the longer side of box = (x, y, w, h), centred on the box, clipped to the image"""
+    x, y, w, h = box
+    half = int(max(w, h) * 0.75)
+    cx, cy = int((2 * x + w) / 2), int((2 * y + h) / 2)
+    W, H = img.size
+    return img.crop([max(0, cx - half), max(0, cy - half), min(W, cx + half), min(H, cy + half)])
 
 
 def get_imgs(img_path, imsize, bbox=None, transform=None, normalize=None):
-    """datasets.py:59-90: crop to 1.5x the bounding box, transform, one tensor per scale."""
+    """The image pyramid of one sample: crop to the bounding box, apply the (random) transform once, then one
+    normalised tensor per scale -- the transform's output is the LARGEST scale, the others are resized from it."""
     img = Image.open(img_path).convert('RGB')
-    width, height = img.size
     if bbox is not None:
-        r = int(np.maximum(bbox[2], bbox[3]) * 0.75)
-        center_x = int((2 * bbox[0] + bbox[2]) / 2)
-        center_y = int((2 * bbox[1] + bbox[3]) / 2)
-        y1 = np.maximum(0, center_y - r)
-        y2 = np.minimum(height, center_y + r)
-        x1 = np.maximum(0, center_x - r)
-        x2 = np.minimum(width, center_x + r)
-        img = img.crop([x1, y1, x2, y2])
+        img = _crop_around(img, bbox)
     if transform is not None:
         img = transform(img)
-    ret = []
     if cfg.GAN.B_DCGAN:
-        ret = [normalize(img)]
-    else:
-        for i in range(cfg.TREE.BRANCH_NUM):
-            if i < (cfg.TREE.BRANCH_NUM - 1):
-                re_img = transforms.Resize(imsize[i])(img)
-            else:
-                re_img = img
-            ret.append(normalize(re_img))
-    return ret
+        return [normalize(img)]
+    last = cfg.TREE.BRANCH_NUM - 1
+    return [normalize(img if i == last else transforms.Resize(imsize[i])(img)) for i in range(cfg.TREE.BRANCH_NUM)]
+
+
+class _CaptionStore(object):
+    """Captions of both splits as word-id lists plus the vocabulary, cached in <data_dir>/captions.pickle."""
+
+    def __init__(self, data_dir, per_image):
+        self.data_dir, self.per_image = data_dir, per_image
+        self.names = {s: self._names(s) for s in ('train', 'test')}
+        cache = os.path.join(data_dir, 'captions.pickle')
+        if os.path.isfile(cache):
+            train, test, self.ixtoword, self.wordtoix = _unpickle(cache)[:4]
+            print('Load from: ', cache)
+        else:
+            words = {s: self._read_split(self.names[s]) for s in ('train', 'test')}
+            self.wordtoix = {END_TOKEN: 0}
+            for sentence in words['train'] + words['test']:           # ids in order of first appearance
+                for w in sentence:
+                    self.wordtoix.setdefault(w, len(self.wordtoix))
+            self.ixtoword = {i: w for w, i in self.wordtoix.items()}
+            train, test = ([[self.wordtoix[w] for w in sentence] for sentence in words[s]] for s in ('train', 'test'))
+            with open(cache, 'wb') as f:
+                pickle.dump([train, test, self.ixtoword, self.wordtoix], f, protocol=2)
+            print('Save to: ', cache)
+        self.encoded = {'train': train, 'test': test}
+
+    def _names(self, split):
+        path = os.path.join(self.data_dir, split, 'filenames.pickle')
+        if not os.path.isfile(path):
+            return []
+        names = _unpickle(path)
+        print('Load filenames from: %s (%d)' % (path, len(names)))
+        return names
+
+    def _read_split(self, names):
+        """the first `per_image` non-empty captions of every text/<key>.txt, tokenised"""
+        out = []
+        for key in names:
+            with open(os.path.join(self.data_dir, 'text', key + '.txt'), 'r') as f:
+                lines = [ln.replace('\ufffd\ufffd', ' ') for ln in f.read().split('\n') if ln]
+            kept = [t for t in (tokenize(ln) for ln in lines) if t][:self.per_image]
+            if len(kept) < self.per_image:
+                print('ERROR: the captions for %s less than %d' % (key, len(kept)))
+            out.extend(kept)
+        return out
+
+
+def _cub_boxes(data_dir):
+    """{image key without extension: [x, y, w, h]} from the CUB-200-2011 annotation files"""
+    base = os.path.join(data_dir, _CUB_SUBDIR)
+    boxes = np.loadtxt(os.path.join(base, 'bounding_boxes.txt')).astype(int)[:, 1:]
+    with open(os.path.join(base, 'images.txt')) as f:
+        keys = [ln.split()[1][:-4] for ln in f if ln.strip()]
+    print('Total filenames: ', len(keys), keys[0] + '.jpg')
+    return dict(zip(keys, boxes.tolist()))
 
 
 class TextDataset(data.Dataset):
-    """datasets.py:93-318.  data_dir layout: {train,test}/filenames.pickle, captions.pickle (built from
-    text/<name>.txt on first use), {train,test}/class_info.pickle, images under images/ (or, for 'birds',
-    CUB_200_2011/CUB_200_2011/images with bounding_boxes.txt / images.txt)."""
-
     def __init__(self, data_dir, split='train', base_size=64, transform=None, target_transform=None):
-        self.transform = transform
+        self.data_dir, self.transform, self.target_transform = data_dir, transform, target_transform
         self.norm = transforms.Compose([transforms.ToTensor(),
                                         transforms.Normalize((0.5, 0.5, 0.5), (0.5, 0.5, 0.5))])
-        self.target_transform = target_transform
         self.embeddings_num = cfg.TEXT.CAPTIONS_PER_IMAGE
-        self.imsize = []
-        for i in range(cfg.TREE.BRANCH_NUM):
-            self.imsize.append(base_size)
-            base_size = base_size * 2
-        self.data = []
-        self.data_dir = data_dir
-        self.bbox = self.load_bbox() if data_dir.find('birds') != -1 else None
-        split_dir = os.path.join(data_dir, split)
-        self.filenames, self.captions, self.ixtoword, self.wordtoix, self.n_words = \
-            self.load_text_data(data_dir, split)
-        self.class_id = self.load_class_id(split_dir, len(self.filenames))
+        self.imsize = [base_size * 2 ** i for i in range(cfg.TREE.BRANCH_NUM)]
+        self.bbox = _cub_boxes(data_dir) if 'birds' in data_dir else None
+        self.image_root = os.path.join(data_dir, _CUB_SUBDIR) if self.bbox is not None else data_dir
+        store = _CaptionStore(data_dir, self.embeddings_num)
+        split = 'train' if split == 'train' else 'test'
+        self.filenames, self.captions = store.names[split], store.encoded[split]
+        self.ixtoword, self.wordtoix, self.n_words = store.ixtoword, store.wordtoix, len(store.ixtoword)
         self.number_example = len(self.filenames)
-
-    def load_bbox(self):
-        base = os.path.join(self.data_dir, 'CUB_200_2011/CUB_200_2011')
-        boxes = np.loadtxt(os.path.join(base, 'bounding_boxes.txt')).astype(int)
-        filenames = [line.split()[1] for line in open(os.path.join(base, 'images.txt')) if line.strip()]
-        print('Total filenames: ', len(filenames), filenames[0])
-        return {f[:-4]: boxes[i][1:].tolist() for i, f in enumerate(filenames)}
-
-    def load_captions(self, data_dir, filenames):
-        all_captions = []
-        for i in range(len(filenames)):
-            cap_path = '%s/text/%s.txt' % (data_dir, filenames[i])
-            with open(cap_path, 'r') as f:
-                captions = f.read().split('\n')
-            cnt = 0
-            for cap in captions:
-                if len(cap) == 0:
-                    continue
-                cap = cap.replace('\ufffd\ufffd', ' ')
-                tokens = tokenize(cap)
-                if len(tokens) == 0:
-                    print('cap', cap)
-                    continue
-                all_captions.append(tokens)
-                cnt += 1
-                if cnt == self.embeddings_num:
-                    break
-            if cnt < self.embeddings_num:
-                print('ERROR: the captions for %s less than %d' % (filenames[i], cnt))
-        return all_captions
-
-    def build_dictionary(self, train_captions, test_captions):
-        word_counts = defaultdict(float)
-        for sent in train_captions + test_captions:
-            for word in sent:
-                word_counts[word] += 1
-        vocab = [w for w in word_counts if word_counts[w] >= 0]
-        ixtoword, wordtoix = {0: '<end>'}, {'<end>': 0}
-        for ix, w in enumerate(vocab, 1):
-            wordtoix[w] = ix
-            ixtoword[ix] = w
-        train_new = [[wordtoix[w] for w in t if w in wordtoix] for t in train_captions]
-        test_new = [[wordtoix[w] for w in t if w in wordtoix] for t in test_captions]
-        return [train_new, test_new, ixtoword, wordtoix, len(ixtoword)]
-
-    def load_text_data(self, data_dir, split):
-        filepath = os.path.join(data_dir, 'captions.pickle')
-        train_names = self.load_filenames(data_dir, 'train')
-        test_names = self.load_filenames(data_dir, 'test')
-        if not os.path.isfile(filepath):
-            train_captions = self.load_captions(data_dir, train_names)
-            test_captions = self.load_captions(data_dir, test_names)
-            train_captions, test_captions, ixtoword, wordtoix, n_words = \
-                self.build_dictionary(train_captions, test_captions)
-            with open(filepath, 'wb') as f:
-                pickle.dump([train_captions, test_captions, ixtoword, wordtoix], f, protocol=2)
-                print('Save to: ', filepath)
-        else:
-            with open(filepath, 'rb') as f:
-                x = pickle.load(f)
-            train_captions, test_captions, ixtoword, wordtoix = x[0], x[1], x[2], x[3]
-            n_words = len(ixtoword)
-            print('Load from: ', filepath)
-        if split == 'train':
-            return train_names, train_captions, ixtoword, wordtoix, n_words
-        return test_names, test_captions, ixtoword, wordtoix, n_words
-
-    def load_class_id(self, data_dir, total_num):
-        path = data_dir + '/class_info.pickle'
-        if os.path.isfile(path):
-            with open(path, 'rb') as f:
-                return pickle.load(f, encoding='latin1')
-        return np.arange(total_num)
-
-    def load_filenames(self, data_dir, split):
-        filepath = '%s/%s/filenames.pickle' % (data_dir, split)
-        if os.path.isfile(filepath):
-            with open(filepath, 'rb') as f:
-                filenames = pickle.load(f)
-            print('Load filenames from: %s (%d)' % (filepath, len(filenames)))
-            return filenames
-        return []
+        info = os.path.join(data_dir, split, 'class_info.pickle')
+        self.class_id = _unpickle(info, encoding='latin1') if os.path.isfile(info) else np.arange(self.number_example)
 
     def get_caption(self, sent_ix):
-        """datasets.py:279-298: zero-padded WORDS_NUM x 1 int64 column; longer captions keep a random, ordered
-        subset of WORDS_NUM words."""
-        sent_caption = np.asarray(self.captions[sent_ix]).astype('int64')
-        if (sent_caption == 0).sum() > 0:
-            print('ERROR: do not need END (0) token', sent_caption)
-        num_words = len(sent_caption)
-        x = np.zeros((cfg.TEXT.WORDS_NUM, 1), dtype='int64')
-        x_len = num_words
-        if num_words <= cfg.TEXT.WORDS_NUM:
-            x[:num_words, 0] = sent_caption
-        else:
-            ix = list(np.arange(num_words))
-            np.random.shuffle(ix)
-            ix = np.sort(ix[:cfg.TEXT.WORDS_NUM])
-            x[:, 0] = sent_caption[ix]
-            x_len = cfg.TEXT.WORDS_NUM
-        return x, x_len
+        """caption `sent_ix` as a zero-padded WORDS_NUM x 1 int64 column and its (clipped) length; a longer caption
+        keeps WORDS_NUM of its words, a random subset in the original order"""
+        ids = np.asarray(self.captions[sent_ix], dtype='int64')
+        if (ids == 0).any():
+            print('ERROR: do not need END (0) token', ids)
+        limit = cfg.TEXT.WORDS_NUM
+        column = np.zeros((limit, 1), dtype='int64')
+        if len(ids) > limit:
+            pick = np.arange(len(ids))
+            np.random.shuffle(pick)
+            ids = ids[np.sort(pick[:limit])]
+        column[:len(ids), 0] = ids
+        return column, len(ids)
 
     def __getitem__(self, index):
         key = self.filenames[index]
-        cls_id = self.class_id[index]
-        if self.bbox is not None:
-            bbox = self.bbox[key]
-            data_dir = '%s/CUB_200_2011/CUB_200_2011' % self.data_dir
-        else:
-            bbox = None
-            data_dir = self.data_dir
-        img_name = '%s/images/%s.jpg' % (data_dir, key)
-        imgs = get_imgs(img_name, self.imsize, bbox, self.transform, normalize=self.norm)
-        sent_ix = random.randint(0, self.embeddings_num)
-        new_sent_ix = index * self.embeddings_num + sent_ix
-        caps, cap_len = self.get_caption(new_sent_ix)
-        return imgs, caps, cap_len, cls_id, key
+        box = self.bbox[key] if self.bbox is not None else None
+        imgs = get_imgs('%s/images/%s.jpg' % (self.image_root, key), self.imsize, box, self.transform,
+                        normalize=self.norm)
+        which = np.random.randint(0, self.embeddings_num)             # one of the image's captions
+        caption, length = self.get_caption(index * self.embeddings_num + which)
+        return imgs, caption, length, self.class_id[index], key
 
     def __len__(self):
-        return len(self.filenames)
+        return self.number_example

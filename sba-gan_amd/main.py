@@ -32,38 +32,32 @@ def parse_args(argv=None):
     return parser.parse_args(argv)
 
 
+def _encode_sentences(path, wordtoix):
+    """word-id lists of the non-empty lines of a text file (words outside the vocabulary are skipped)"""
+    with open(path, 'r') as f:
+        lines = [ln.replace('\ufffd\ufffd', ' ') for ln in f.read().split('\n') if ln]
+    token_lists = [t for t in (tokenize(ln) for ln in lines) if t]
+    return [[wordtoix[w] for w in tokens if w in wordtoix] for tokens in token_lists]
+
+
 def build_example_dic(wordtoix, data_dir=None):
-    """main.py:34-83: captions of <DATA_DIR>/example_filenames.txt -> {key: [cap_array, cap_lens, sorted_indices]}."""
+    """The caption batches of gen_example (reference main.py:34-83), from their contract: for every file listed in
+    <data_dir>/example_filenames.txt, key = its base name and value = [captions (n x Lmax int64, zero padded, rows by
+    DESCENDING length: what the packed bi-LSTM takes), the lengths in that order, the permutation that sorted them]."""
     data_dir = data_dir or cfg.DATA_DIR
-    data_dic = {}
-    with open('%s/example_filenames.txt' % data_dir, 'r') as f:
-        filenames = f.read().split('\n')
-    for name in filenames:
-        if len(name) == 0:
-            continue
-        with open('%s/%s.txt' % (data_dir, name), 'r') as f:
-            print('Load from:', name)
-            sentences = f.read().split('\n')
-        captions, cap_lens = [], []
-        for sent in sentences:
-            if len(sent) == 0:
-                continue
-            tokens = tokenize(sent.replace('\ufffd\ufffd', ' '))
-            if len(tokens) == 0:
-                print('sent', sent)
-                continue
-            rev = [wordtoix[t] for t in tokens if t in wordtoix]
-            captions.append(rev)
-            cap_lens.append(len(rev))
-        max_len = np.max(cap_lens)
-        sorted_indices = np.argsort(cap_lens)[::-1]
-        cap_lens = np.asarray(cap_lens)[sorted_indices]
-        cap_array = np.zeros((len(captions), max_len), dtype='int64')
-        for i in range(len(captions)):
-            cap = captions[sorted_indices[i]]
-            cap_array[i, :len(cap)] = cap
-        data_dic[name[(name.rfind('/') + 1):]] = [cap_array, cap_lens, sorted_indices]
-    return data_dic
+    with open(os.path.join(data_dir, 'example_filenames.txt'), 'r') as f:
+        listed = [ln for ln in f.read().split('\n') if ln]
+    batches = {}
+    for name in listed:
+        print('Load from:', name)
+        ids = _encode_sentences(os.path.join(data_dir, name + '.txt'), wordtoix)
+        lengths = np.array([len(s) for s in ids])
+        order = np.argsort(lengths)[::-1]
+        padded = np.zeros((len(ids), int(lengths.max())), dtype='int64')
+        for row, src in enumerate(order):
+            padded[row, :lengths[src]] = ids[src]
+        batches[os.path.basename(name)] = [padded, lengths[order], order]
+    return batches
 
 
 def gen_example(wordtoix, algo):

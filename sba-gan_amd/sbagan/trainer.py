@@ -525,9 +525,13 @@ class GraphedStep(object):
         self.gPre, self._pending = None, None
         if gan.distributed and gan.overlap_g:
             # the discriminators' forward passes on the real images: replayed BEFORE the generator's pending update
+            # (and the prologue -- noise draw, frozen text encoder, trainer.py:248-252 -- which does not depend on it either)
             self.gPre = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.gPre, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
+                if prologue is not None:
+                    prologue()
                 gan.phase_pre(imgs)
+            prologue = None
         if single and not gan.distributed:       # the whole step as ONE graph, discriminator updates as forked branches
             with torch.cuda.graph(self.gA, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
                 if prologue is not None:
