@@ -57,6 +57,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-also', action='store_true', help='skip the extra 64 px / 128 px / f32 lines')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--dump-shapes', default=None, help='write the shapes of the time-dominant kernel (for '
+                                                        'tools/pmc_dominant.py) to this JSON file')
     ap.add_argument('--child', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -142,69 +144,140 @@ def measure_dominant_kernel(args, dev):
     kname = 'conv3x3_halo_kernel<64,64,ups>' if (args.dtype == 'bf16' and C == 64) else 'igemm_kernel<%s>' % args.dtype
     # HBM traffic per launch: rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KiB -> bytes) of
     # tools/pmc_dominant.py, committed under profiles/ (cannot be collected from inside this process)
-    traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_dominant_kernel.json')
-    if args.dtype == 'bf16' and args.branch == 3 and B == 20 and os.path.exists(pmc):
-        try:
-            traffic = int(json.load(open(pmc))['traffic_bytes_per_launch'])
-        except (KeyError, ValueError):
-            traffic = None
+    traffic = None      # (PMC traffic is reported for the time-dominant kernel: measure_igemm_kernels)
     return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak, 'unit': 'TFLOP/s',
             'frac': round(achieved / peak, 4), 'traffic': traffic,
             'kernel': '%s upBlock conv3x3 %d->64 @%dpx B=%d (+BN statistics epilogue)' % (kname, C, S, B),
             'kernel_ms': round(ms, 4), 'algorithmic_gflop_per_launch': round(flops / 1e9, 2)}
 
 
-def measure_igemm_family(args, dev, step, one_step):
-    """The time-dominant kernel family: every implicit-GEMM launch of one step (forward / data-gradient convs of
-    G, the discriminators and the Inception trunk: sba_conv_igemm, all tile configurations).  The geometries of
-    one eager step are recorded, each distinct one is then timed alone with events on the launch stream (10
-    launches), and achieved = sum(2*M*Cout*K) / sum(duration) over the step's launches."""
+DOMINANT = (1, 1)      # (family, tile) of sba_conv_igemm_plan: igemm_dma2_kernel<64, 64, 32, 32, 4> -- the kernel with the
+#                        largest share of the step's kernel time (profiles/r03_step_*_summary.txt: ~120 launches per step)
+DOMINANT_NAME = 'igemm_dma2_kernel<64, 64, 32, 32, 4>'
+GEOM_FIELDS = ('N', 'IH', 'IW', 'Cin', 'OH', 'OW', 'Cout', 'OHs', 'OWs', 'sy', 'sx', 'osy', 'osx', 'ooy', 'oox', 'ups',
+               'ntaps', 'x_cstride', 'x_coff', 'y_cstride', 'y_coff', 'relu', 'tile', 'ksplit')
+
+
+def geom_to_dict(g):
+    d = {k: int(getattr(g, k)) for k in GEOM_FIELDS}
+    d['ty'], d['tx'] = [int(g.ty[t]) for t in range(g.ntaps)], [int(g.tx[t]) for t in range(g.ntaps)]
+    return d
+
+
+def geom_from_dict(d):
+    from sbagan._lib import ConvGeom
+    g = ConvGeom()
+    for k in GEOM_FIELDS:
+        setattr(g, k, d[k])
+    for t in range(d['ntaps']):
+        g.ty[t], g.tx[t] = d['ty'][t], d['tx'][t]
+    return g
+
+
+def time_shape(g, dev, ws, st, n=10):
+    """one implicit-GEMM geometry launched alone, n times back to back, with events on the launch stream: us per launch"""
+    import ctypes
+    from sbagan import ops
+    from sbagan._lib import call
+    xcs, ycs = g.x_cstride or g.Cin, g.y_cstride or g.Cout
+    x = torch.randn(g.N, g.IH, g.IW, xcs, device=dev).bfloat16()
+    w = (torch.randn(g.Cout, g.ntaps, g.Cin, device=dev) / (g.Cin * g.ntaps) ** 0.5).bfloat16()
+    y = torch.empty(g.N, g.OH, g.OW, ycs, device=dev, dtype=torch.bfloat16)
+
+    def run():
+        call('sba_conv_igemm', 1, x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, ctypes.byref(g),
+             ws.data_ptr(), ops.WORKSPACE_BYTES, st)
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+
+
+def measure_igemm_kernels(args, dev, step, one_step, dump=None):
+    """The implicit-GEMM launches of one step (forward / data-gradient convs of G, the discriminators and the Inception
+    trunk through sba_conv_igemm, all tile configurations; the grouped Inception launches are listed, not timed here).
+    The geometries of one eager step are recorded, each distinct one is timed ALONE with events on the launch stream
+    (10 launches), and attributed to the kernel sba_conv_igemm_plan names for it.  Returns (roofline of the
+    time-dominant KERNEL, roofline of the whole family)."""
     import ctypes
     from sbagan import ops
     from sbagan._lib import ConvGeom, call
     if args.dtype != 'bf16':
-        return None
+        return None, None
     ops.IGEMM_LOG = []
     one_step()
     torch.cuda.synchronize()
     log, ops.IGEMM_LOG = ops.IGEMM_LOG, None
-    uniq = {}
+    uniq, grouped = {}, 0
     for g in log:
-        k = (ops.geom_key(g), g.x_cstride, g.y_cstride)
+        if isinstance(g, tuple):
+            grouped += 1
+            continue
+        k = (ops.geom_key(g), g.x_cstride, g.y_cstride, g.tile, g.ksplit)
         if k not in uniq:
             uniq[k] = [g, 0]
         uniq[k][1] += 1
     ws = ops.workspace(dev)
     st = torch.cuda.current_stream().cuda_stream
-    t_us = fl = 0.0
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fam = {'t': 0.0, 'fl': 0.0, 'n': 0}
+    dom = {'t': 0.0, 'fl': 0.0, 'by': 0.0, 'n': 0, 'shapes': []}
+    plan = (ctypes.c_int * 3)()
     for g0, count in uniq.values():
         g = ConvGeom()
         ctypes.memmove(ctypes.byref(g), ctypes.byref(g0), ctypes.sizeof(ConvGeom))
-        xcs, ycs = g.x_cstride or g.Cin, g.y_cstride or g.Cout
-        x = torch.randn(g.N, g.IH, g.IW, xcs, device=dev).bfloat16()
-        w = (torch.randn(g.Cout, g.ntaps, g.Cin, device=dev) / (g.Cin * g.ntaps) ** 0.5).bfloat16()
-        y = torch.empty(g.N, g.OH, g.OW, ycs, device=dev, dtype=torch.bfloat16)
-
-        def run():
-            call('sba_conv_igemm', 1, x.data_ptr(), w.data_ptr(), y.data_ptr(), None, None, ctypes.byref(g),
-                 ws.data_ptr(), ops.WORKSPACE_BYTES, st)
-        run()
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(10):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        t_us += e0.elapsed_time(e1) * 100.0 * count          # ms / 10 launches -> us per launch, x launches
-        fl += 2.0 * g.N * g.OHs * g.OWs * g.Cout * g.ntaps * g.Cin * count
-    achieved = fl / (t_us * 1e-6) / 1e12
-    return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS['bf16'], 'unit': 'TFLOP/s',
-            'frac': round(achieved / PEAK_TFLOPS['bf16'], 4), 'traffic': None,
-            'kernel': 'sba_conv_igemm family (igemm_dma2_kernel / igemm_dma_kernel / conv3x3_halo_kernel tiles): '
-                      '%d launches, %d distinct shapes per step' % (len(log), len(uniq)),
-            'kernel_ms_per_step': round(t_us / 1e3, 3), 'algorithmic_gflop_per_step': round(fl / 1e9, 1)}
+        us = time_shape(g, dev, ws, st)
+        M = g.N * g.OHs * g.OWs
+        fl = 2.0 * M * g.Cout * g.ntaps * g.Cin
+        fam['t'] += us * count
+        fam['fl'] += fl * count
+        fam['n'] += count
+        call('sba_conv_igemm_plan', 1, ctypes.byref(g), ops.WORKSPACE_BYTES, plan)
+        if (plan[0], plan[1]) == DOMINANT:
+            # algorithmic bytes: every input pixel / weight / output element once (bf16)
+            by = 2.0 * (g.N * g.IH * g.IW * g.Cin + g.Cout * g.ntaps * g.Cin + M * g.Cout)
+            dom['t'] += us * count
+            dom['fl'] += fl * count
+            dom['by'] += by * count
+            dom['n'] += count
+            dom['shapes'].append({'geom': geom_to_dict(g), 'count': count, 'us': round(us, 2), 'ksplit': int(plan[2])})
+    if dump:
+        with open(dump, 'w') as f:
+            json.dump({'kernel': DOMINANT_NAME, 'shapes': dom['shapes']}, f)
+    peak = PEAK_TFLOPS['bf16']
+    family = {'bound': 'mfma', 'achieved': round(fam['fl'] / (fam['t'] * 1e-6) / 1e12, 2), 'peak': peak, 'unit': 'TFLOP/s',
+              'frac': round(fam['fl'] / (fam['t'] * 1e-6) / 1e12 / peak, 4), 'traffic': None,
+              'kernel': 'sba_conv_igemm single launches, all kernels (igemm_dma2 / igemm_dma / conv3x3_halo / igemm): %d '
+                        'launches, %d distinct shapes per step (+ %d grouped Inception launches, not in this sum)'
+                        % (fam['n'], len(uniq), grouped),
+              'kernel_ms_per_step': round(fam['t'] / 1e3, 3), 'algorithmic_gflop_per_step': round(fam['fl'] / 1e9, 1)}
+    if not dom['n']:
+        return None, family
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_dominant_kernel.json')
+    if args.branch == 3 and args.batch == 20 and args.variant == 'model' and os.path.exists(pmc):
+        try:        # rocprofv3 PMC passes over exactly these shapes (tools/pmc_dominant.py; not collectable in-process)
+            rec = json.load(open(pmc))
+            if rec.get('launches_per_step') == dom['n']:
+                traffic = int(rec['traffic_bytes_per_launch'])
+        except (KeyError, ValueError):
+            traffic = None
+    ach = dom['fl'] / (dom['t'] * 1e-6) / 1e12
+    dominant = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                'traffic': traffic,
+                'kernel': '%s: the time-dominant kernel of the step (%d launches per step over %d distinct shapes: '
+                          'Inception 17x17 / 8x8 convs, discriminator tails, small generator layers); achieved = '
+                          'sum(2*M*Cout*K) / sum(duration), each shape timed alone' % (DOMINANT_NAME, dom['n'],
+                                                                                       len(dom['shapes'])),
+                'launches_per_step': dom['n'], 'kernel_avg_us': round(dom['t'] / dom['n'], 2),
+                'kernel_ms_per_step': round(dom['t'] / 1e3, 3),
+                'algorithmic_gflop_per_launch': round(dom['fl'] / dom['n'] / 1e9, 3),
+                'algorithmic_bytes_per_launch': int(dom['by'] / dom['n'])}
+    return dominant, family
 
 
 def cpu_baseline(args):
@@ -480,10 +553,13 @@ def main():
     }
     if rank == 0:
         if not args.no_roofline:
-            res['roofline'] = measure_dominant_kernel(args, dev)
-            fam = measure_igemm_family(args, dev, step, one_step)
+            big = measure_dominant_kernel(args, dev)
+            dominant, fam = measure_igemm_kernels(args, dev, step, one_step, dump=args.dump_shapes)
+            # `roofline` = the TIME-dominant kernel; the largest-FLOP launch and the whole family ride along
+            res['roofline'] = dominant if dominant is not None else big
+            res['roofline_largest_flop_kernel'] = big
             if fam is not None:
-                res['roofline_time_dominant'] = fam
+                res['roofline_igemm_family'] = fam
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(res), flush=True)

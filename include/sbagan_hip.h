@@ -126,6 +126,10 @@ int sba_conv_igemm(int dtype, const void* x, const void* w, void* y, const void*
 int sba_conv_igemm_bias(int dtype, const void* x, const void* w, void* y, const void* addend,
                         float* stats, const float* bias, const void* relu_mask, const sba_conv_geom* g,
                         void* workspace, int64_t workspace_bytes, void* stream);
+/* Which kernel sba_conv_igemm launches for a geometry (nothing is launched; measurement / reporting aid):
+ * plan[0] = family (0 halo-tile 3x3 conv3x3_halo_kernel, 1 igemm_dma2_kernel, 2 igemm_dma_kernel, 3 igemm_kernel),
+ * plan[1] = tile id (families 1 / 2: the ids of sba_conv_geom.tile) or configuration, plan[2] = K splits. */
+int sba_conv_igemm_plan(int dtype, const sba_conv_geom* g, int64_t workspace_bytes, int* plan);
 /* GROUPED launch: n <= SBA_GROUP_MAX independent convolutions -- no output of one is an input of another, their outputs
  * do not overlap -- as ONE grid (bf16 only, no split-K, no statistics; bias / ReLU (g->relu) / addend /
  * relu_mask per item as in sba_conv_igemm_bias).  For the branches of an Inception block at one depth level (model.py:226-262:

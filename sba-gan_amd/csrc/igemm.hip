@@ -620,7 +620,7 @@ __device__ __forceinline__ void igemm_dma_body(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
     const bf16_t* __restrict__ addend, float* __restrict__ stats, const sba_conv_geom& g, const int M,
     float* __restrict__ ws, int* __restrict__ tickets, const int slabs_per_split, const EpiX ex, const int gx,
-    const int gy, const int L, const int bz DMA_TRACE_PARAM) {
+    const int gy, const int L, const int bz, const int nmajor DMA_TRACE_PARAM) {
     typedef bf16_t T;
     constexpr int TM = WM / 32, TN = WN / 32, WAVES_N = BN / WN;
     constexpr int NW = (BM / WM) * (BN / WN), NT = NW * 64;
@@ -641,9 +641,20 @@ __device__ __forceinline__ void igemm_dma_body(
     float* s_stat = reinterpret_cast<float*>(lds_all + EPI_OFF + BM * 4);
 
     // workgroup -> tile: ids L and L + 8 share an XCD; the N tiles of an M tile take consecutive slots of one XCD
+    // M-major: the N tiles of an M tile (they share its input rows) take consecutive slots of one XCD, each XCD's L2 fetches
+    // the weights once (x read ~once, w up to 8 times); N-major (weight-heavy GEMM-like layers: a few M tiles against
+    // megabytes of weights): the M tiles of an N tile on one XCD -- its weight slice is fetched by that XCD only
     const int xcd = L & 7, q = L >> 3;
-    const int mt = xcd + 8 * (q / gy), nt = q - (q / gy) * gy;
-    if (mt >= gx) return;
+    int mt, nt;
+    if (nmajor) {
+        nt = xcd + 8 * (q / gx);
+        mt = q - (q / gx) * gx;
+        if (nt >= gy) return;
+    } else {
+        mt = xcd + 8 * (q / gy);
+        nt = q - (q / gy) * gy;
+        if (mt >= gx) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
@@ -838,9 +849,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
     const bf16_t* __restrict__ addend, float* __restrict__ stats, const sba_conv_geom g, const int M,
     float* __restrict__ ws, int* __restrict__ tickets, const int slabs_per_split, const EpiX ex, const int gx,
-    const int gy DMA_TRACE_PARAM) {
+    const int gy, const int nmajor DMA_TRACE_PARAM) {
     igemm_dma_body<BM, BN, WM, WN, KS, D>(x, w, y, addend, stats, g, M, ws, tickets, slabs_per_split, ex, gx, gy,
-                                          (int)blockIdx.x, (int)blockIdx.z DMA_TRACE_ARG_FWD);
+                                          (int)blockIdx.x, (int)blockIdx.z, nmajor DMA_TRACE_ARG_FWD);
 }
 
 // ---------------------------------------------------------------------------
@@ -867,7 +878,7 @@ __device__ __forceinline__ void igemm_dma2_body(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
     const bf16_t* __restrict__ addend, float* __restrict__ stats, const sba_conv_geom& g, const int M,
     float* __restrict__ ws, int* __restrict__ tickets, const int slabs_per_split, const EpiX ex, const int gx,
-    const int gy, const int L, const int bz DMA_TRACE_PARAM) {
+    const int gy, const int L, const int bz, const int nmajor DMA_TRACE_PARAM) {
     typedef bf16_t T;
     constexpr int TM = WM / 32, TN = WN / 32, WAVES_N = BN / WN;
     constexpr int NW = (BM / WM) * (BN / WN), NT = NW * 64;
@@ -886,9 +897,20 @@ __device__ __forceinline__ void igemm_dma2_body(
     int* rowoff = reinterpret_cast<int*>(lds_all + EPI_OFF);
     float* s_stat = reinterpret_cast<float*>(lds_all + EPI_OFF + BM * 4);
 
+    // M-major: the N tiles of an M tile (they share its input rows) take consecutive slots of one XCD, each XCD's L2 fetches
+    // the weights once (x read ~once, w up to 8 times); N-major (weight-heavy GEMM-like layers: a few M tiles against
+    // megabytes of weights): the M tiles of an N tile on one XCD -- its weight slice is fetched by that XCD only
     const int xcd = L & 7, q = L >> 3;
-    const int mt = xcd + 8 * (q / gy), nt = q - (q / gy) * gy;
-    if (mt >= gx) return;
+    int mt, nt;
+    if (nmajor) {
+        nt = xcd + 8 * (q / gx);
+        mt = q - (q / gx) * gx;
+        if (nt >= gy) return;
+    } else {
+        mt = xcd + 8 * (q / gy);
+        nt = q - (q / gy) * gy;
+        if (mt >= gx) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
@@ -1112,9 +1134,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma2_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
     const bf16_t* __restrict__ addend, float* __restrict__ stats, const sba_conv_geom g, const int M,
     float* __restrict__ ws, int* __restrict__ tickets, const int slabs_per_split, const EpiX ex, const int gx,
-    const int gy DMA_TRACE_PARAM) {
+    const int gy, const int nmajor DMA_TRACE_PARAM) {
     igemm_dma2_body<BM, BN, WM, WN, D>(x, w, y, addend, stats, g, M, ws, tickets, slabs_per_split, ex, gx, gy,
-                                       (int)blockIdx.x, (int)blockIdx.z DMA_TRACE_ARG_FWD);
+                                       (int)blockIdx.x, (int)blockIdx.z, nmajor DMA_TRACE_ARG_FWD);
 }
 
 // ---------------------------------------------------------------------------
@@ -1129,7 +1151,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma2_kernel(
 struct GroupItem {
     const bf16_t* x; const bf16_t* w; bf16_t* y; const bf16_t* addend; const float* bias; const void* mask;
     sba_conv_geom g;
-    int M, gx, gy, tile_begin;
+    int M, gx, gy, tile_begin, nmajor, pad;
 };
 struct GroupArgs { int n; int pad; GroupItem it[SBA_GROUP_MAX]; };
 
@@ -1143,7 +1165,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma2_group_k
     const sba_conv_geom g = it.g;
     igemm_dma2_body<BM, BN, WM, WN, D>(it.x, it.w, it.y, it.addend, nullptr, g, it.M, nullptr, nullptr,
                                        g.ntaps * (g.Cin / 64), EpiX{it.bias, it.mask, 0}, it.gx, it.gy,
-                                       (int)blockIdx.x - it.tile_begin, 0 DMA_TRACE_ARG_FWD);
+                                       (int)blockIdx.x - it.tile_begin, 0, it.nmajor DMA_TRACE_ARG_FWD);
 }
 
 // the same for members whose Cin is a multiple of 32 only (32-channel slabs, first-generation body)
@@ -1157,7 +1179,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma_group_ke
     const sba_conv_geom g = it.g;
     igemm_dma_body<BM, BN, WM, WN, KS, D>(it.x, it.w, it.y, it.addend, nullptr, g, it.M, nullptr, nullptr,
                                           g.ntaps * (g.Cin / 32), EpiX{it.bias, it.mask, 0}, it.gx, it.gy,
-                                          (int)blockIdx.x - it.tile_begin, 0 DMA_TRACE_ARG_FWD);
+                                          (int)blockIdx.x - it.tile_begin, 0, it.nmajor DMA_TRACE_ARG_FWD);
 }
 
 // ---------------------------------------------------------------------------
@@ -2431,6 +2453,14 @@ static int* splitk_tickets(float* ws, int64_t ws_bytes, int M, int Cout, int til
     return reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + ws_bytes - SPLITK_TICKET_BYTES);
 }
 
+// N-major tile numbering (see igemm_dma2_body) when the weights outweigh the input tensor.  SBA_IGEMM_NMAJOR=0 disables it.
+static int nmajor_for(const sba_conv_geom& g) {
+    static int en = -1;
+    if (en < 0) { const char* e = getenv("SBA_IGEMM_NMAJOR"); en = (e && e[0] == '0') ? 0 : 1; }
+    const int64_t wb = (int64_t)g.Cout * g.ntaps * g.Cin, xb = (int64_t)g.N * g.IH * g.IW * g.Cin;
+    return (en && wb > xb) ? 1 : 0;
+}
+
 template <int BM, int BN, int WM, int WN, int KS, int D>
 static void launch_dma(const bf16_t* xp, const bf16_t* wp, bf16_t* yp, const bf16_t* ap, float* stats,
                        const sba_conv_geom& g, int M, int nslabs, int split, float* ws, int64_t ws_bytes, hipStream_t st,
@@ -2442,10 +2472,11 @@ static void launch_dma(const bf16_t* xp, const bf16_t* wp, bf16_t* yp, const bf1
         split = cdiv(nslabs, sps);
     }
     const int gx = cdiv(M, BM), gy = cdiv(g.Cout, BN);
-    dim3 grid(8 * cdiv(gx, 8) * gy, 1, split);
+    const int nmajor = nmajor_for(g);
+    dim3 grid(nmajor ? 8 * cdiv(gy, 8) * gx : 8 * cdiv(gx, 8) * gy, 1, split);
     int* tickets = splitk_tickets(ws, ws_bytes, M, g.Cout, (int)grid.x);
     SBA_LAUNCH((igemm_dma_kernel<BM, BN, WM, WN, KS, D>), grid, dim3(NT), 0, st, xp, wp, yp, ap, stats, g, M,
-               split > 1 ? ws : (float*)nullptr, split > 1 ? tickets : (int*)nullptr, sps, ex, gx, gy DMA_TRACE_ARG);
+               split > 1 ? ws : (float*)nullptr, split > 1 ? tickets : (int*)nullptr, sps, ex, gx, gy, nmajor DMA_TRACE_ARG);
     if (split > 1 && !tickets) {
         dim3 fgrid(cdiv(g.Cout / 4, 256), cdiv(M, 8));
         SBA_LAUNCH((splitk_finish_kernel<bf16_t>), fgrid, dim3(256), 0, st, ws, yp, ap, stats, g, M, ex);
@@ -2463,10 +2494,11 @@ static void launch_dma2(const bf16_t* xp, const bf16_t* wp, bf16_t* yp, const bf
         split = cdiv(nslabs64, sps);
     }
     const int gx = cdiv(M, BM), gy = cdiv(g.Cout, BN);
-    dim3 grid(8 * cdiv(gx, 8) * gy, 1, split);
+    const int nmajor = nmajor_for(g);
+    dim3 grid(nmajor ? 8 * cdiv(gy, 8) * gx : 8 * cdiv(gx, 8) * gy, 1, split);
     int* tickets = splitk_tickets(ws, ws_bytes, M, g.Cout, (int)grid.x);
     SBA_LAUNCH((igemm_dma2_kernel<BM, BN, WM, WN, D>), grid, dim3(NT), 0, st, xp, wp, yp, ap, stats, g, M,
-               split > 1 ? ws : (float*)nullptr, split > 1 ? tickets : (int*)nullptr, sps, ex, gx, gy DMA_TRACE_ARG);
+               split > 1 ? ws : (float*)nullptr, split > 1 ? tickets : (int*)nullptr, sps, ex, gx, gy, nmajor DMA_TRACE_ARG);
     if (split > 1 && !tickets) {
         dim3 fgrid(cdiv(g.Cout / 4, 256), cdiv(M, 8));
         SBA_LAUNCH((splitk_finish_kernel<bf16_t>), fgrid, dim3(256), 0, st, ws, yp, ap, stats, g, M, ex);
@@ -2536,10 +2568,13 @@ static void launch_halo(const sba_conv_geom& g, const bf16_t* x, const bf16_t* w
 template <typename T>
 int launch_igemm(const void* x, const void* w, void* y, const void* addend, float* stats,
                  const sba_conv_geom& g, void* workspace, int64_t ws_bytes, hipStream_t st,
-                 const EpiX ex = EpiX{nullptr, nullptr, 0}) {
+                 const EpiX ex = EpiX{nullptr, nullptr, 0}, int* plan = nullptr) {
+    // plan != NULL: do not launch -- report the kernel this geometry goes to: plan[0] = family (0 halo-tile 3x3, 1 LDS-DMA
+    // gen 2 (64-channel slabs), 2 LDS-DMA gen 1, 3 register-staged), plan[1] = tile id / configuration, plan[2] = K splits
     const int M = g.N * g.OHs * g.OWs;
     const T* xp = (const T*)x; const T* wp = (const T*)w; T* yp = (T*)y; const T* ap = (const T*)addend;
     if (sizeof(T) == 2 && halo_ok(g)) {
+        if (plan) { plan[0] = 0; plan[1] = g.ups ? 1 : 0; plan[2] = 1; return SBA_OK; }
         launch_halo(g, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, (const bf16_t*)addend, stats, ex, st);
         return SBA_CHECK_LAUNCH();
     }
@@ -2608,6 +2643,7 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
             const int ns64 = nslabs / 2;
             int sp = split;
             if (sp > ns64 / 2) sp = ns64 / 2 > 0 ? ns64 / 2 : 1;
+            if (plan) { plan[0] = 1; plan[1] = tile; plan[2] = sp; return SBA_OK; }
             switch (tile) {
                 case 1: launch_dma2<64, 64, 32, 32, 4>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
                 case 2: launch_dma2<64, 64, 32, 32, 8>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
@@ -2622,6 +2658,7 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
                 default: launch_dma2<96, 128, 32, 128, 5>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
             }
         }
+        if (plan && tile != 11) { plan[0] = 2; plan[1] = tile; plan[2] = split; return SBA_OK; }
         switch (tile) {
             case 1: launch_dma<64, 64, 32, 32, 2, 4>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
             case 2: launch_dma<64, 64, 32, 32, 2, 8>(xb, wb, yb, ab, stats, g, M, nslabs, split, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
@@ -2637,6 +2674,7 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
             default: best = 4; best_split = split; break;      // 11: the register-staged 320x128 tile below
         }
     }
+    if (plan) { plan[0] = 3; plan[1] = best; plan[2] = best_split; return SBA_OK; }
     switch (best) {
         case 0: launch_cfg<T, 128, 128, 64, 64, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
         case 1: launch_cfg<T, 256, 64, 64, 64, 1>(xp, wp, yp, ap, stats, g, M, nslabs, best_split, ws, st, ex); break;
@@ -2724,6 +2762,16 @@ extern "C" int sba_conv_igemm_bias(int dtype, const void* x, const void* w, void
     return SBA_E_ARG;
 }
 
+extern "C" int sba_conv_igemm_plan(int dtype, const sba_conv_geom* g, int64_t workspace_bytes, int* plan) {
+    if (!plan || (dtype != SBA_F32 && dtype != SBA_BF16) || !geom_ok(g, dtype)) return SBA_E_ARG;
+    static char dummy_ws[16];
+    void* ws = workspace_bytes > 0 ? (void*)dummy_ws : nullptr;       // (only its presence and size enter the decision)
+    if (dtype == SBA_F32) return launch_igemm<float>(nullptr, nullptr, nullptr, nullptr, nullptr, *g, ws, workspace_bytes,
+                                                     nullptr, EpiX{nullptr, nullptr, 0}, plan);
+    return launch_igemm<bf16_t>(nullptr, nullptr, nullptr, nullptr, nullptr, *g, ws, workspace_bytes, nullptr,
+                                EpiX{nullptr, nullptr, 0}, plan);
+}
+
 template <int BM, int BN, int WM, int WN, int D, int KS = 0>
 static int launch_group(const sba_conv_group_item* items, int n, hipStream_t st) {
     GroupArgs A;
@@ -2739,8 +2787,10 @@ static int launch_group(const sba_conv_group_item* items, int n, hipStream_t st)
         it.M = g.N * g.OHs * g.OWs;
         it.gx = cdiv(it.M, BM);
         it.gy = cdiv(g.Cout, BN);
+        it.nmajor = nmajor_for(g);
+        it.pad = 0;
         it.tile_begin = tiles;
-        tiles += 8 * cdiv(it.gx, 8) * it.gy;
+        tiles += it.nmajor ? 8 * cdiv(it.gy, 8) * it.gx : 8 * cdiv(it.gx, 8) * it.gy;
     }
     for (int i = n; i < SBA_GROUP_MAX; ++i) A.it[i] = A.it[0];
     constexpr int NT = (BM / WM) * (BN / WN) * 64;

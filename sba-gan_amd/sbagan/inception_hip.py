@@ -259,6 +259,8 @@ class InceptionHIP(object):
             if GROUP_TILE:
                 tile = GROUP_TILE
             call('sba_conv_igemm_group', _lib.SBA_BF16, len(part), arr, tile, ops._stream())
+            if ops.IGEMM_LOG is not None:       # (bench.py's per-kernel accounting: these ran in the grouped kernel)
+                ops.IGEMM_LOG.append(('group', tile, [it[5] for it in part]))
         self._keep = []             # temporaries the collected launches read (ReLU-masked gradients)
 
     def conv(self, name, x, out=None):
