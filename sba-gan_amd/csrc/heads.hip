@@ -5,6 +5,8 @@
 //   - logits head           conv4x4 s4 (8ndf->1)+sigmoid on the 4x4 map (D_GET_LOGITS, model.py:590-607)
 //   - conditioning concat   (model.py:597-600)
 // Images stay in the reference's NCHW f32 layout at the boundary; features are NHWC.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -231,6 +233,121 @@ __global__ __launch_bounds__(256) void d_stem_fwd_kernel(const float* __restrict
             o.set(k, a > 0.f ? a : 0.2f * a);
         }
         st16(op + cv * V, o);
+    }
+}
+
+// The same forward on the bf16 matrix cores (bf16 output): out^T[co][pix] = sum_k w[co][k] patch[pix][k], K = 48 = three
+// 16-deep steps of v_mfma_f32_32x32x16_bf16 with the PIXEL axis as the MFMA's N (lane) axis -- lane (pixel, group g) loads
+// the 8 patch values k = 16 s + 8 g .. + 8 of its pixel straight from the f32 image (no LDS), the weights are the A
+// operands (registers, loaded once per wave).  Image values and weights are f32: both are split into hi + lo bf16 parts
+// (3 MFMAs per step: hi*hi + hi*lo + lo*hi), so the products carry ~16 mantissa bits and the result, rounded to bf16 like
+// the VALU kernel's, agrees with it to that rounding.  The VALU kernel above spends 48 x C FMAs per pixel on the vector
+// pipe (4 GFLOP at 256 px, 2B images: 90 us); here the 115 MB of HBM traffic are what is left.
+template <int MT>
+__global__ __launch_bounds__(256) void d_stem_fwd_mfma_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                              bf16_t* __restrict__ out, int N, int S, int tiles_per_wave) {
+    constexpr int C = 32 * MT;
+    constexpr int ROWB = C * 2 + 16;
+    __shared__ __attribute__((aligned(16))) unsigned char s_out[4 * 32 * ROWB];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int pl = lane & 31, kg = lane >> 5;
+    bf16x8_t a_hi[MT][3], a_lo[MT][3];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            bf16x8_t hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // contraction index of step s: k = (ci = s, kh = 2 kg + (j >> 2), kw = j & 3) -- any order will do as long as
+                // both operands use it; this one makes a lane's 8 patch values two runs of 4 consecutive image floats
+                const float v = w[(32 * mt + pl) * 48 + ((2 * kg + (j >> 2)) * 4 + (j & 3)) * 3 + s];
+                const bf16_t h = f2bf(v);
+                hi[j] = (short)h;
+                lo[j] = (short)f2bf(v - bf2f(h));
+            }
+            a_hi[mt][s] = hi;
+            a_lo[mt][s] = lo;
+        }
+    const int O = S / 2;
+    const int64_t total = (int64_t)N * O * O;
+    const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wid) * tiles_per_wave;
+    for (int t = 0; t < tiles_per_wave; ++t) {
+        const int64_t p0 = (tile0 + t) * 32;
+        if (p0 >= total) break;                               // (wave-uniform)
+        const int64_t p = p0 + pl;
+        const bool live = p < total;
+        const int64_t pc = live ? p : 0;
+        const int ox = (int)(pc % O), oy = (int)((pc / O) % O), n = (int)(pc / ((int64_t)O * O));
+        const float* ib = img + (int64_t)n * 3 * S * S;
+        bf16x8_t b_hi[3], b_lo[3];
+        const int ix0 = 2 * ox - 1;
+        const bool inner = ix0 >= 0 && ix0 + 3 < S;           // all four columns inside the image: one 16-byte load per row
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {                         // s = input channel
+            float v[8];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int iy = 2 * oy + 2 * kg + hh - 1;
+                const bool rok = live && iy >= 0 && iy < S;
+                const float* rp = ib + ((int64_t)s * S + (rok ? iy : 0)) * S;
+                if (rok && inner) {
+                    struct __attribute__((packed, aligned(4))) F4 { float f[4]; };
+                    const F4 q = *reinterpret_cast<const F4*>(rp + ix0);
+                    v[4 * hh] = q.f[0]; v[4 * hh + 1] = q.f[1]; v[4 * hh + 2] = q.f[2]; v[4 * hh + 3] = q.f[3];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ix = ix0 + u;
+                        v[4 * hh + u] = (rok && ix >= 0 && ix < S) ? rp[ix] : 0.f;
+                    }
+                }
+            }
+            bf16x8_t hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bf16_t h = f2bf(v[j]);
+                hi[j] = (short)h;
+                lo[j] = (short)f2bf(v[j] - bf2f(h));
+            }
+            b_hi[s] = hi;
+            b_lo[s] = lo;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[mt][s], b_hi[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[mt][s], b_lo[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[mt][s], b_hi[s], acc, 0, 0, 0);
+            }
+            // this lane holds channels 32 mt + 8 g4 + 4 kg .. + 4 of its pixel: through the wave's LDS tile [pixel][C]
+            // (rows padded by 16 B) so that the global stores are whole 16-byte row pieces, 1 KB per instruction
+            unsigned char* row = s_out + wid * (32 * ROWB) + pl * ROWB + (32 * mt + 4 * kg) * 2;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const float a = acc[4 * g4 + u]; v[u] = a > 0.f ? a : 0.2f * a; }
+                uint2 o;
+                o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                *reinterpret_cast<uint2*>(row + 16 * g4) = o;
+            }
+        }
+        // (wave-private tile: a wave's LDS accesses complete in order, no barrier needed)
+        constexpr int CPR = C / 8;                                // 16-byte pieces per pixel row
+#pragma unroll
+        for (int i = 0; i < 32 * CPR / 64; ++i) {
+            const int piece = lane + 64 * i, r = piece / CPR, cc = piece - r * CPR;
+            if (p0 + r < total) {
+                const uint4 v = *reinterpret_cast<const uint4*>(s_out + wid * (32 * ROWB) + r * ROWB + cc * 16);
+                *reinterpret_cast<uint4*>(out + (p0 + r) * C + cc * 8) = v;
+            }
+        }
     }
 }
 
@@ -551,6 +668,18 @@ extern "C" int sba_d_stem_fwd(int dtype, const float* img, const float* w, void*
     if (!img || !w || !out || N <= 0 || S <= 0 || S % 2 || C <= 0 || C % STEM_CB || C > 256) return SBA_E_ARG;
     const int64_t pix = (int64_t)N * (S / 2) * (S / 2);
     if ((pix + 255) / 256 > 0x7fffffff) return SBA_E_ARG;
+    static int mfma = -1;       // SBA_STEM_MFMA=0: the VALU kernel for bf16 as well (A/B aid)
+    if (mfma < 0) { const char* e = getenv("SBA_STEM_MFMA"); mfma = (e && e[0] == '0') ? 0 : 1; }
+    if (dtype == SBA_BF16 && mfma && (C == 32 || C == 64 || C == 128)) {
+        const int64_t tiles = (pix + 31) / 32;
+        const int tpw = tiles >= 16384 ? 4 : (tiles >= 4096 ? 2 : 1);
+        const dim3 grid((unsigned)((tiles + 4 * tpw - 1) / (4 * tpw)));
+        hipStream_t st = (hipStream_t)stream;
+        if (C == 32) SBA_LAUNCH((d_stem_fwd_mfma_kernel<1>), grid, dim3(256), 0, st, img, w, (bf16_t*)out, N, S, tpw);
+        else if (C == 64) SBA_LAUNCH((d_stem_fwd_mfma_kernel<2>), grid, dim3(256), 0, st, img, w, (bf16_t*)out, N, S, tpw);
+        else SBA_LAUNCH((d_stem_fwd_mfma_kernel<4>), grid, dim3(256), 0, st, img, w, (bf16_t*)out, N, S, tpw);
+        return SBA_CHECK_LAUNCH();
+    }
     SBA_DISPATCH(dtype, {
         SBA_LAUNCH((d_stem_fwd_kernel<T>), dim3((unsigned)((pix + 255) / 256), C / STEM_CB), dim3(256), 0,
                            (hipStream_t)stream, img, w, (T*)out, N, S, C);
