@@ -281,9 +281,11 @@ def measure_igemm_kernels(args, dev, step, one_step, dump=None):
 
 
 def cpu_baseline(args):
-    """The oracle (CPU restatement of the reference step, fp32, `kind: port`) on the host cores: SURVEY.md 8d's
-    three configurations on a bounded sample (~30 s of CPU work) -- (1) stage 1 only, B=4: 3 warm-up + 10 timed
-    steps, median; 3-stage B=4: 1 warm-up + 5 timed, median (= `value`); 3-stage B=20: one step."""
+    """The oracle (CPU restatement of the reference step, fp32, `kind: port`) on the host cores, with the SAME work as
+    the GPU line: the generator-loss term runs the Inception-v3 CNN_ENCODER (the repo's nn.Module definition evaluated
+    by PyTorch on the CPU, frozen, eval mode: forward + backward to the fake image) exactly as the GPU step runs it on
+    the HIP kernels.  SURVEY.md 8d's three configurations on a bounded sample (~30 s of CPU work): 3-stage B=4: 1 warm-up
+    + 4 timed steps, median (= `value`); stage 1 only B=4: 2 warm-up + 6 timed; 3-stage B=20: one step."""
     import statistics
     from oracle import fill
     from oracle import sbagan_oracle as O
@@ -297,7 +299,14 @@ def cpu_baseline(args):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))
     torch.set_num_threads(cores)
-    enc = fill.StandInImageEncoder(256)
+    from sbagan.encoders import CNN_ENCODER
+    torch.manual_seed(101)
+    enc_mod = CNN_ENCODER(256).eval()
+    for p in enc_mod.parameters():
+        p.requires_grad_(False)
+
+    def enc(x):
+        return enc_mod(x)
 
     def run(branch, B, warm, timed):
         x = make_inputs(FULL, B, 18, branch=branch, lmax=18, tag=500)
@@ -312,13 +321,14 @@ def cpu_baseline(args):
             if s >= warm:
                 ts.append(time.time() - t0)
         return B / statistics.median(ts)
-    main = run(args.branch, 4, 1, 5)
-    also = [{'config': 'stage 1 only (64 px), B=4: 3 warm-up + 10 timed steps, median', 'value': round(run(1, 4, 3, 10), 3)}]
+    main = run(args.branch, 4, 1, 4)
+    also = [{'config': 'stage 1 only (64 px), B=4: 2 warm-up + 6 timed steps, median', 'value': round(run(1, 4, 2, 6), 3)}]
     if args.branch == 3:
         also.append({'config': '3-stage, B=20: one step', 'value': round(run(3, 20, 0, 1), 3)})
     return {'value': round(main, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': '%d-stage step at B=4 (bird_style dims, fp32, stand-in image encoder), 1 warm-up + 5 timed '
-                      'steps, median; torch CPU threads=%d' % (args.branch, cores), 'also': also}
+            'sample': '%d-stage step at B=4 (bird_style dims, fp32, Inception-v3 image encoder INCLUDED: forward + '
+                      'backward to the fake image, as in the GPU line), 1 warm-up + 4 timed steps, median; torch CPU '
+                      'threads=%d' % (args.branch, cores), 'also': also}
 
 
 class _LightEncoder(object):
