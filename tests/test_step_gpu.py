@@ -131,8 +131,11 @@ def test_discriminator_loss(dev, dt, which):
         r = rel_l2(p.grad, Q[n].grad)
         got.append(p.grad.detach().float().cpu().flatten())
         refs.append(Q[n].grad.detach().float().flatten())
-        # per tensor: tight in f32; loose in bf16 (near-cancelling sums such as BN beta gradients)
-        if r > (3e-3 if dt == torch.float32 else 0.35):
+        # per tensor: tight in f32.  bf16: 0.08 (D_NET64) .. 0.17 (D_NET256) on EVERY trunk tensor, at B = 3 and at B = 20
+        # alike (measured in the deterministic mode): the incoming gradient dz of each BatchNorm is stored in bf16
+        # (2^-9 per element) and its backward subtracts mean(dz) and xhat * mean(dz * xhat) -- where the common part
+        # dominates, the residual inherits the rounding of the whole, ~3 % per layer; the loss itself is within 2e-4
+        if r > (3e-3 if dt == torch.float32 else 0.25):
             bad.append((n, r))
     assert not bad, bad
     allr = rel_l2(torch.cat(got), torch.cat(refs))
