@@ -595,10 +595,10 @@ def bn_act_forward(y, stats, bn, act, residual=None, groups=1):
 BN_FUSED_BWD_ROWS = int(os.environ.get('SBA_BN_FUSED_ROWS', '2560'))       # rows per group up to which the one-launch backward is used
 
 
-def bn_act_backward(y, dout, st, bn, act, need_param_grad=True):
+def bn_act_backward(y, dout, st, bn, act, need_param_grad=True, out=None):
     N, C, H, W = y.shape
     Co = C // 2 if act == ACT_GLU else C
-    dy = torch.empty(y.shape, dtype=_act_dtype(y), device=y.device, memory_format=CL)
+    dy = out if out is not None else torch.empty(y.shape, dtype=_act_dtype(y), device=y.device, memory_format=CL)
     dg = db = None
     if need_param_grad:
         dg, db = param_grad(bn.weight), param_grad(bn.bias)
@@ -1136,6 +1136,9 @@ def _bce_meta(offs, targets, weights, dev):
     return meta
 
 
+GROUP_COND_HEADS = os.environ.get('SBA_GROUP_COND_HEADS', '1') != '0'
+
+
 class DHeadsFn(torch.autograd.Function):
     """Every head of one discriminator's loss term as ONE autograd node: the conditional heads
     (cat with the sentence code, jointConv + BatchNorm + LeakyReLU, logits; model.py:594-607), the unconditional
@@ -1169,10 +1172,43 @@ class DHeadsFn(torch.autograd.Function):
             offs.append(offs[-1] + s)
         prob = torch.empty(offs[-1], dtype=torch.float32, device=dev)
         tape = []
-        for (r0, rows, c0, tgt, wt, seg) in heads:
+        # The conditional heads of one term (real / fake / wrong pairs, losses.py:143-149) share jointConv's weights: their
+        # inputs go into ONE tensor, one conv / data-gradient / weight-gradient launch serves all of them (M = 944 rows at
+        # B = 20 instead of three GEMM-like launches of 320 / 320 / 304 rows, each with its own K split + finishing launch);
+        # BatchNorm stays per head, in the reference's call order (batch statistics and running-statistic updates of three
+        # separate module calls).
+        cond_idx = [i for i, hd in enumerate(heads) if hd[2] is not None]
+        grouped = GROUP_COND_HEADS and len(cond_idx) >= 2 and cnet.jointConv._layer().bn.training
+        xin_all = y_all = None
+        slices = {}
+        if grouped:
+            layer = cnet.jointConv._layer()
+            E = cond.shape[1]
+            total = sum(heads[i][1] for i in cond_idx)
+            xin_all = empty_act(total, C + E, 4, 4, feats)
+            off = 0
+            for i in cond_idx:
+                r0, rows, c0 = heads[i][0], heads[i][1], heads[i][2]
+                call('sba_cond_cat_fwd', dt, _p(feats[r0:r0 + rows]), _p(cond[c0:c0 + rows]), _p(xin_all[off:off + rows]),
+                     rows, C, E, _stream())
+                slices[i] = (off, rows)
+                off += rows
+            y_all, _ = conv_forward(xin_all, layer.pw, '3x3', want_stats=False, pre_bn=True)
+        for hi, (r0, rows, c0, tgt, wt, seg) in enumerate(heads):
             h = feats[r0:r0 + rows]
             pslice = prob[offs[seg]:offs[seg] + rows]
-            if c0 is not None:
+            if c0 is not None and grouped:
+                layer = cnet.jointConv._layer()
+                off = slices[hi][0]
+                xin, y = xin_all[off:off + rows], y_all[off:off + rows]
+                if rows * 16 <= BN_FUSED_BWD_ROWS:
+                    hc, st = bn_act_forward_fused(y, layer.bn, ACT_LRELU, 1)
+                else:
+                    hc, st = bn_act_forward(y, bn_stats(y, 1), layer.bn, ACT_LRELU)
+                o = cnet.outlogits[0]
+                call('sba_logits_fwd', dt, _p(hc), _p(o.weight), _p(o.bias), _p(pslice), rows, K, _stream())
+                tape.append((xin, y, st, hc))
+            elif c0 is not None:
                 layer = cnet.jointConv._layer()
                 E = cond.shape[1]
                 xin = empty_act(rows, C + E, 4, 4, feats)
@@ -1196,6 +1232,7 @@ class DHeadsFn(torch.autograd.Function):
         call('sba_bce_multi', _p(prob), _p(meta[0]), _p(meta[1]), _p(meta[2]), len(heads), _p(loss), _p(dprob),
              _stream())
         ctx.netD, ctx.heads, ctx.offs, ctx.tape = netD, heads, offs, tape
+        ctx.grouped = (xin_all, y_all, slices) if grouped else None
         ctx.has_cond = cond is not None
         ctx.cond_shape = None if cond is None else tuple(cond.shape)
         ctx.save_for_backward(feats, prob, dprob)
@@ -1227,9 +1264,26 @@ class DHeadsFn(torch.autograd.Function):
                 written.append((r0, r0 + rows))
             return 1 if inside else 0
 
+        dy_all = None
+        if ctx.grouped is not None:
+            xin_all, y_all, slices = ctx.grouped
+            dy_all = torch.empty(y_all.shape, dtype=_act_dtype(y_all), device=y_all.device, memory_format=CL)
         for i in order:
             r0, rows, c0, tgt, wt, seg = heads[i]
             ps, ds = prob[offs[seg]:offs[seg] + rows], d[offs[seg]:offs[seg] + rows]
+            if c0 is not None and dy_all is not None:
+                # grouped conditional heads: this head's BatchNorm backward into its rows of dy_all; the conv gradients
+                # follow once, below
+                xin, y, st, hc = ctx.tape[i]
+                layer = cnet.jointConv._layer()
+                o = cnet.outlogits[0]
+                dhc = torch.empty_like(hc)
+                call('sba_logits_bwd', dt, _p(hc), _p(o.weight), _p(ps), _p(ds), _p(dhc),
+                     _p(param_grad(o.weight)) if need_p else None, _p(param_grad(o.bias)) if need_p else None,
+                     rows, K, 0, _stream())
+                off = slices[i][0]
+                bn_act_backward(y, dhc, st, layer.bn, ACT_LRELU, need_p, out=dy_all[off:off + rows])
+                continue
             if c0 is None:
                 o = unet.outlogits[0]
                 if not (need_feats or need_p):
@@ -1255,6 +1309,22 @@ class DHeadsFn(torch.autograd.Function):
                 dh = dfeats[r0:r0 + rows] if need_feats else torch.empty_like(feats[r0:r0 + rows])
                 call('sba_cond_cat_bwd', dt, _p(dxin), _p(dh), _p(dcond[c0:c0 + rows]) if need_cond else None,
                      rows, C, E, mode(r0, rows) if need_feats else 0, _stream())
+        if dy_all is not None:
+            layer = cnet.jointConv._layer()
+            if need_p:
+                conv_wgrad_overlapped(xin_all, dy_all, layer.conv.weight, '3x3')
+            if need_feats or need_cond:
+                dxin_all = conv_dgrad(dy_all, layer.pw, '3x3', (4, 4))
+                E = xin_all.shape[1] - C
+                for i in order:
+                    r0, rows, c0, tgt, wt, seg = heads[i]
+                    if c0 is None:
+                        continue
+                    off = slices[i][0]
+                    dh = dfeats[r0:r0 + rows] if need_feats else torch.empty_like(feats[r0:r0 + rows])
+                    call('sba_cond_cat_bwd', dt, _p(dxin_all[off:off + rows]), _p(dh),
+                         _p(dcond[c0:c0 + rows]) if need_cond else None, rows, C, E,
+                         mode(r0, rows) if need_feats else 0, _stream())
         if need_feats:
             covered = sorted(written)
             assert covered and covered[0][0] == 0 and covered[-1][1] == feats.shape[0] and \
