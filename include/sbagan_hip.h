@@ -79,7 +79,7 @@ typedef struct sba_conv_geom {
      * that add with atomics ignore it.  0 = always accumulate. */
     int32_t first_write;
 } sba_conv_geom;
-#define SBA_IGEMM_TILES 12
+#define SBA_IGEMM_TILES 14
 
 const char* sba_version(void);
 
@@ -103,6 +103,13 @@ int sba_set_deterministic(int on, void* scratch, int64_t scratch_bytes);
 int sba_get_deterministic(void);
 int sba_det_reset(void);
 int64_t sba_det_high_water(void);
+/* Scratch ring for two-stage reductions in the DEFAULT mode (optional; NULL / 0 removes it).  Launches whose workgroups
+ * would all add into the same few hundred addresses at their end (sba_d_stem_bwd's and sba_img_head_bwd's weight
+ * gradients) then store per-workgroup partial sums into the ring and a second small launch folds them into the
+ * destination; without a ring they use f32 atomics (correct, ~30 us slower per launch at 256 px).  Device memory,
+ * 256-byte aligned, >= 1 MiB; a launch takes at most a quarter of it (larger requests fall back to atomics); regions
+ * are handed out round-robin, so size it for the launches of one whole step (64 MiB covers the B = 20 step). */
+int sba_set_reduce_scratch(void* scratch, int64_t scratch_bytes);
 /* SBA_BN_STAT_SLOTS the library was compiled with (the host sizes its statistics buffers with it) */
 int sba_bn_stat_slots(void);
 

@@ -146,3 +146,10 @@ float* sba_det_alloc(int64_t nfloats);
 // dst[j * dst_stride + i] (+)= sum_{p < P, in order} part[(j * P + p) * n + i]   for j < J, i < n
 //   mode 0: dst += sum;  mode 1: dst = sum
 void sba_det_fold(const float* part, int J, int P, int64_t n, float* dst, int64_t dst_stride, int mode, hipStream_t st);
+// DEFAULT mode, two-stage reduction (sba_set_reduce_scratch in sbagan_hip.h): a launch whose workgroups would all add into
+// the same few hundred addresses AT ITS END (the stem / image-head weight gradients: ~800 workgroups x 3072 same-address
+// f32 atomics = a 30 us tail) stores per-workgroup partial sums into this ring instead and sba_fold_add adds them to the
+// destination (32 slots per thread, then one atomic).  nullptr = no ring set or request too large: fall back to atomics.
+float* sba_reduce_alloc(int64_t nfloats);
+// dst[i] += sum_{p < P} part[p * n + i]   (unordered: f32 atomics between groups of 32 slots)
+void sba_fold_add(const float* part, int P, int64_t n, float* dst, hipStream_t st);

@@ -25,9 +25,46 @@ __global__ __launch_bounds__(256) void det_fold_kernel(const float* __restrict__
     float* d = dst + (int64_t)j * dst_stride + i;
     *d = mode == 1 ? s : *d + s;
 }
+// default mode: the same fold spread over the chip -- a thread adds up 32 partial sums, then ONE atomic per (32 slots, output)
+__global__ __launch_bounds__(256) void fold_add_kernel(const float* __restrict__ part, const int P, const int64_t n,
+                                                       float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int q0 = blockIdx.y * 32, q1 = min(q0 + 32, P);
+    float s = 0.f;
+    for (int q = q0; q < q1; ++q) s += part[(int64_t)q * n + i];
+    atomicAdd(&dst[i], s);
+}
+
+char* r_ring = nullptr;
+int64_t r_bytes = 0, r_off = 0;
 }  // namespace
 
 bool sba_det_on() { return g_on; }
+
+float* sba_reduce_alloc(int64_t nfloats) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int64_t bytes = ((nfloats * 4 + 255) / 256) * 256;
+    if (!r_ring || bytes > r_bytes / 4) return nullptr;     // (a launch may take a quarter of the ring at most)
+    if (r_off + bytes > r_bytes) r_off = 0;
+    float* p = reinterpret_cast<float*>(r_ring + r_off);
+    r_off += bytes;
+    return p;
+}
+
+void sba_fold_add(const float* part, int P, int64_t n, float* dst, hipStream_t st) {
+    if (P <= 0 || n <= 0) return;
+    SBA_LAUNCH(fold_add_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)((P + 31) / 32)), dim3(256), 0, st, part, P, n, dst);
+}
+
+extern "C" int sba_set_reduce_scratch(void* scratch, int64_t scratch_bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (scratch && (scratch_bytes < (1 << 20) || ((uintptr_t)scratch & 255) != 0)) return SBA_E_ARG;
+    r_ring = reinterpret_cast<char*>(scratch);
+    r_bytes = scratch ? scratch_bytes : 0;
+    r_off = 0;
+    return SBA_OK;
+}
 
 float* sba_det_alloc(int64_t nfloats) {
     std::lock_guard<std::mutex> lk(g_mu);

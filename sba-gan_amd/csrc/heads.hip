@@ -504,6 +504,559 @@ __global__ __launch_bounds__(256) void d_stem_dgrad_kernel(const float* __restri
     for (int ci = 0; ci < 3; ++ci) dimg[(((int64_t)n * 3 + ci) * S + iy) * S + ix] = acc[ci];
 }
 
+// fragment of columns [c32, c32 + 32) over the 16 pixel rows of a slice whose rows are 192 B apart: 8 consecutive
+// pixels per lane via ds_read_b64_tr_b16 (same addressing as WgFrag<bf16_t>::load of igemm.hip)
+__device__ __forceinline__ bf16x8_t stem_tr_frag(const unsigned char* slice, const int c32, const int lane) {
+    constexpr int ROWS = 192;
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const int cbase = c32 + 16 * (g16 & 1), kbase = 8 * (g16 >> 1);
+    const int q = i16 >> 2, p = i16 & 3;
+    const unsigned char* a0 = slice + (kbase + q) * ROWS + (cbase + 4 * p) * 2;
+    typedef __attribute__((address_space(3))) s16x4_t* lptr;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * ROWS));
+    bf16x8_t r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+// ------------------------------------------------------------------ stem backward on the bf16 matrix cores
+// (bf16 activations, C = 64: every discriminator of the 3-stage model).  f32 quantities -- dpre = dout * lrelu'(out),
+// the weights, the image -- enter the MFMAs as hi + lo bf16 parts (hi*hi + hi*lo + lo*hi, as in d_stem_fwd_mfma_kernel):
+// the products carry ~16 mantissa bits, the sums are f32.
+__device__ __forceinline__ void split_hi_lo(const float v, short& hi, short& lo) {
+    const bf16_t h = f2bf(v);
+    hi = (short)h;
+    lo = (short)f2bf(v - bf2f(h));
+}
+// dpre of 8 channels (one 16-byte chunk of dout / out) as hi / lo fragments
+__device__ __forceinline__ void dpre_hi_lo(const uint4 dv, const uint4 ov, uint4& hi, uint4& lo) {
+    const uint32_t d[4] = {dv.x, dv.y, dv.z, dv.w}, o[4] = {ov.x, ov.y, ov.z, ov.w};
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float d0 = __uint_as_float(d[q] << 16), d1 = __uint_as_float(d[q] & 0xffff0000u);
+        const float o0 = __uint_as_float(o[q] << 16), o1 = __uint_as_float(o[q] & 0xffff0000u);
+        short h0, l0, h1, l1;
+        split_hi_lo(o0 > 0.f ? d0 : 0.2f * d0, h0, l0);
+        split_hi_lo(o1 > 0.f ? d1 : 0.2f * d1, h1, l1);
+        h[q] = (uint32_t)(uint16_t)h0 | ((uint32_t)(uint16_t)h1 << 16);
+        l[q] = (uint32_t)(uint16_t)l0 | ((uint32_t)(uint16_t)l1 << 16);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// DATA GRADIENT.  The 2 x 2 block of image pixels (2 by + a, 2 bx + b) is read by the 3 x 3 neighbourhood of output
+// positions around (by, bx):
+//   dimg[ci][2 by + a][2 bx + b] = sum_{dy, dx = -1..1} sum_co dpre[by + dy][bx + dx][co] * w[co][kh][kw][ci],
+//   kh = a + 1 - 2 dy, kw = b + 1 - 2 dx  (no term unless both lie in 0..3)
+// -- a 3 x 3 stride-1 convolution of dpre with 12 "channels" (ci, a, b), K = 9 * 64 = 576 = 18 steps of
+// v_mfma_f32_16x16x32_bf16: the (zero-filled) weights are the A operand, 16 rows (12 used), kept in registers for the
+// whole launch (persistent workgroups); 16 consecutive positions of one map row are the B columns.  A workgroup stages
+// the (8 + 2) x (16 + 2) positions of its tile ONCE, as hi / lo bf16 rows of 144 B (conflict-free ds_read_b128); the
+// accumulator of lane (position, ci) is exactly the 2 x 2 pixel block of channel ci: two 8-byte stores, 128 B per
+// 16 lanes.  (The VALU kernel above: 27 x 64 FMAs per pixel on the vector pipe, 154 us at 256 px.)
+__global__ __launch_bounds__(256, 2) void d_stem_dgrad_mfma_kernel(const float* __restrict__ w,
+                                                                   const bf16_t* __restrict__ out,
+                                                                   const bf16_t* __restrict__ dout,
+                                                                   float* __restrict__ dimg, const int N, const int S,
+                                                                   const int ntiles) {
+    constexpr int C = 64, TH = 8, TW = 16, HR = TH + 2, HC = TW + 2, ROWB = 2 * C + 16, NCH = HR * HC * 8;
+    constexpr int NI = (NCH + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char s_hi[HR * HC * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char s_lo[HR * HC * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    bf16x8_t a_hi[18], a_lo[18];
+    {
+        const int ci = m >> 2, a = (m >> 1) & 1, b = m & 1;
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+            const int tap = st >> 1, s2 = st & 1;
+            const int kh = a + 1 - 2 * (tap / 3 - 1), kw = b + 1 - 2 * (tap % 3 - 1);
+            const bool ok = m < 12 && kh >= 0 && kh < 4 && kw >= 0 && kw < 4;
+            bf16x8_t hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int co = 32 * s2 + 8 * g + j;
+                const float v = ok ? w[co * 48 + (kh * 4 + kw) * 3 + ci] : 0.f;
+                short h, l;
+                split_hi_lo(v, h, l);
+                hi[j] = h;
+                lo[j] = l;
+            }
+            a_hi[st] = hi;
+            a_lo[st] = lo;
+        }
+    }
+    const int O = S / 2, tiles_x = O / TW, tiles_y = O / TH;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int txi = tile % tiles_x, tyi = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int by0 = tyi * TH, bx0 = txi * TW;
+        __syncthreads();                // the previous tile's fragment reads are done
+        uint4 dv[NI], ov[NI];
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = tid + 256 * u, p = i >> 3, ch = i & 7;
+            const int hy = p / HC, hx = p - hy * HC;
+            const int oy = by0 + hy - 1, ox = bx0 + hx - 1;
+            const bool ok = i < NCH && oy >= 0 && oy < O && ox >= 0 && ox < O;
+            dv[u] = make_uint4(0, 0, 0, 0);
+            ov[u] = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const int64_t q = (((int64_t)n * O + oy) * O + ox) * C + ch * 8;
+                dv[u] = *reinterpret_cast<const uint4*>(dout + q);
+                ov[u] = *reinterpret_cast<const uint4*>(out + q);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = tid + 256 * u, p = i >> 3, ch = i & 7;
+            if (i < NCH) {
+                uint4 hi, lo;
+                dpre_hi_lo(dv[u], ov[u], hi, lo);
+                *reinterpret_cast<uint4*>(s_hi + p * ROWB + ch * 16) = hi;
+                *reinterpret_cast<uint4*>(s_lo + p * ROWB + ch * 16) = lo;
+            }
+        }
+        __syncthreads();
+        f32x4_t acc[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) acc[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+            const int tap = st >> 1, s2 = st & 1;
+            const int ty = tap / 3, tx = tap % 3;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int p = (2 * wid + r + ty) * HC + m + tx;
+                const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(s_hi + p * ROWB + (4 * s2 + g) * 16);
+                const bf16x8_t bl = *reinterpret_cast<const bf16x8_t*>(s_lo + p * ROWB + (4 * s2 + g) * 16);
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[st], bh, acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[st], bl, acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[st], bh, acc[r], 0, 0, 0);
+            }
+        }
+        // D layout: column = lane & 15 (position), rows 4 g .. 4 g + 3 = (ci = g; a, b)
+        if (g < 3) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int by = by0 + 2 * wid + r, bx = bx0 + m;
+                float* o0 = dimg + (((int64_t)n * 3 + g) * S + 2 * by) * S + 2 * bx;
+                *reinterpret_cast<float2*>(o0) = make_float2(acc[r][0], acc[r][1]);
+                *reinterpret_cast<float2*>(o0 + S) = make_float2(acc[r][2], acc[r][3]);
+            }
+        }
+    }
+}
+
+// WEIGHT GRADIENT.  dw[co][k] += sum_pix dpre[pix][co] * patch[pix][k]: the contraction runs over PIXELS, both operands
+// are pixel-major, so the fragments are read with ds_read_b64_tr_b16 (WgFrag of igemm.hip: 4 pixels x 16 columns
+// transposed per 16-lane group).  Per 64-pixel tile the workgroup stages dpre [64][64] and the patches [64][48 (+16 zero)]
+// as hi / lo bf16 rows of 192 B; wave (i, j) accumulates its 32 (co) x 32 (k') tile with 4 x 3 v_mfma_f32_32x32x16_bf16.
+// Patch columns are kept as k' = ci * 16 + kh * 4 + kw (a thread's four consecutive image floats = one 8-byte LDS
+// write); the epilogue maps them back to the weight layout [kh][kw][ci].  (Before: f32 operands and
+// v_mfma_f32_32x32x2_f32 -- 1/8 of the bf16 rate -- with a scalar patch gather: 194 us at 256 px, 2B images.)
+__global__ __launch_bounds__(256, 2) void d_stem_wgrad_mfma_kernel(const float* __restrict__ img,
+                                                                   const bf16_t* __restrict__ out,
+                                                                   const bf16_t* __restrict__ dout,
+                                                                   float* __restrict__ dw, const int N, const int S,
+                                                                   const int tiles_per_block, const int det) {
+    constexpr int C = 64, ROWS = 192;
+    __shared__ __attribute__((aligned(16))) unsigned char s_dh[64 * ROWS];
+    __shared__ __attribute__((aligned(16))) unsigned char s_dl[64 * ROWS];
+    __shared__ __attribute__((aligned(16))) unsigned char s_ph[64 * ROWS];
+    __shared__ __attribute__((aligned(16))) unsigned char s_pl[64 * ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int it = wid >> 1, jt = wid & 1;
+    const int O = S / 2;
+    const int64_t total = (int64_t)N * O * O;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (tid < 128) {        // patch columns 48 .. 63 stay zero
+        unsigned char* base = ((tid & 64) ? s_pl : s_ph) + (tid & 63) * ROWS + 96;
+        *reinterpret_cast<uint4*>(base) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(base + 16) = make_uint4(0, 0, 0, 0);
+    }
+    // the next tile's global loads are issued before the current tile's MFMAs: their latency hides behind them
+    uint4 dv[2], ov[2];
+    float pv[3][4];
+    auto fetch = [&](const int64_t p0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 256 * u, t = i >> 3, ch = i & 7;
+            const int64_t pp = p0 + t;
+            dv[u] = make_uint4(0, 0, 0, 0);
+            ov[u] = make_uint4(0, 0, 0, 0);
+            if (pp < total) {
+                dv[u] = *reinterpret_cast<const uint4*>(dout + pp * C + ch * 8);
+                ov[u] = *reinterpret_cast<const uint4*>(out + pp * C + ch * 8);
+            }
+        }
+        const int t = tid & 63, kh = wid;
+        const int64_t pp = p0 + t;
+        const bool live = pp < total;
+        const int64_t pc = live ? pp : 0;
+        const int ox = (int)(pc % O), oy = (int)((pc / O) % O), n = (int)(pc / ((int64_t)O * O));
+        const int iy = 2 * oy + kh - 1, ix0 = 2 * ox - 1;
+        const bool rok = live && iy >= 0 && iy < S;
+        const bool inner = ix0 >= 0 && ix0 + 3 < S;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+            const float* rp = img + (((int64_t)n * 3 + ci) * S + (rok ? iy : 0)) * S;
+            if (rok && inner) {
+                struct __attribute__((packed, aligned(4))) F4 { float f[4]; };
+                const F4 q = *reinterpret_cast<const F4*>(rp + ix0);
+                pv[ci][0] = q.f[0]; pv[ci][1] = q.f[1]; pv[ci][2] = q.f[2]; pv[ci][3] = q.f[3];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ix = ix0 + u;
+                    pv[ci][u] = (rok && ix >= 0 && ix < S) ? rp[ix] : 0.f;
+                }
+            }
+        }
+    };
+    const int64_t pbase = (int64_t)blockIdx.x * tiles_per_block * 64;
+    if (pbase < total) fetch(pbase);
+    for (int tile = 0; tile < tiles_per_block; ++tile) {
+        const int64_t p0 = pbase + (int64_t)tile * 64;
+        if (p0 >= total) break;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 256 * u, t = i >> 3, ch = i & 7;
+            uint4 hi, lo;
+            dpre_hi_lo(dv[u], ov[u], hi, lo);
+            *reinterpret_cast<uint4*>(s_dh + t * ROWS + ch * 16) = hi;
+            *reinterpret_cast<uint4*>(s_dl + t * ROWS + ch * 16) = lo;
+        }
+        {
+            const int t = tid & 63, kh = wid;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                short h[4], l[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) split_hi_lo(pv[ci][u], h[u], l[u]);
+                uint2 hv, lv;
+                hv.x = (uint32_t)(uint16_t)h[0] | ((uint32_t)(uint16_t)h[1] << 16);
+                hv.y = (uint32_t)(uint16_t)h[2] | ((uint32_t)(uint16_t)h[3] << 16);
+                lv.x = (uint32_t)(uint16_t)l[0] | ((uint32_t)(uint16_t)l[1] << 16);
+                lv.y = (uint32_t)(uint16_t)l[2] | ((uint32_t)(uint16_t)l[3] << 16);
+                *reinterpret_cast<uint2*>(s_ph + t * ROWS + (ci * 16 + kh * 4) * 2) = hv;
+                *reinterpret_cast<uint2*>(s_pl + t * ROWS + (ci * 16 + kh * 4) * 2) = lv;
+            }
+        }
+        __syncthreads();
+        if (tile + 1 < tiles_per_block && p0 + 64 < total) fetch(p0 + 64);
+#pragma unroll
+        for (int k16 = 0; k16 < 4; ++k16) {
+            const bf16x8_t ah = stem_tr_frag(s_dh + 16 * k16 * ROWS, 32 * it, lane);
+            const bf16x8_t al = stem_tr_frag(s_dl + 16 * k16 * ROWS, 32 * it, lane);
+            const bf16x8_t bh = stem_tr_frag(s_ph + 16 * k16 * ROWS, 32 * jt, lane);
+            const bf16x8_t bl = stem_tr_frag(s_pl + 16 * k16 * ROWS, 32 * jt, lane);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        }
+    }
+    const int kp = 32 * jt + (lane & 31);
+    if (kp < 48) {
+        const int ci = kp >> 4, kh = (kp >> 2) & 3, kw = kp & 3;
+        const int k = (kh * 4 + kw) * 3 + ci;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            // deterministic mode: dw = the scratch ring, one [C][48] slot per workgroup, folded in order afterwards
+            // det = 1: dw = a scratch ring (deterministic mode, or the default mode's two-stage reduction): one [C][48] slot
+            // per workgroup, folded afterwards
+            if (det) dw[(int64_t)blockIdx.x * C * 48 + co * 48 + k] = acc[r];
+            else atomicAdd(&dw[co * 48 + k], acc[r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ image head forward on the bf16 matrix cores
+// (bf16 features, C = 32).  img^T[co][pix] = tanh(sum_tap sum_ci w[co][tap][ci] h[pix + tap][ci]): one
+// v_mfma_f32_16x16x32_bf16 per tap -- K = 32 IS one tap's channels -- with 16 consecutive pixels of a map row as the B
+// columns; the weights (f32: hi + lo parts, 2 MFMAs per tap) are the A rows (3 of 16 used) and stay in registers.
+// Persistent workgroups own 8 x 32-pixel tiles and stage the (8 + 2) x (32 + 2) feature rows ONCE in LDS (80-byte rows:
+// conflict-free ds_read_b128 for the nine shifted views); the next tile's global loads are issued before the current
+// tile's MFMAs.  Lanes 0..15 hold the three channels of their pixel: 64-byte row stores into the NCHW image.
+// (Reading the nine shifted rows straight from global memory instead was latency-bound at 1.2 TB/s: 9x the bytes in
+// flight per pixel.  The VALU kernel above: 27 x 32 FMAs per pixel, 70 us at 256 px.)
+// tanh with the hardware exponential and reciprocal (the library tanhf is ~90 instructions, executed for a whole wave
+// while only the 16 lanes that hold an image row have data: more issue cycles than the tile's MFMAs): absolute error
+// <= 2e-7, and the odd series below 0.1 keeps that RELATIVE accuracy for small arguments
+__device__ __forceinline__ float tanh_fast(const float x) {
+    const float e = __expf(2.f * x);
+    const float big = 1.f - 2.f * __frcp_rn(e + 1.f);
+    const float x2 = x * x;
+    const float small = x * (1.f + x2 * (-0.33333334f + x2 * 0.13333334f));
+    return fabsf(x) < 0.1f ? small : big;
+}
+__global__ __launch_bounds__(256, 2) void img_head_fwd_mfma_kernel(const bf16_t* __restrict__ h,
+                                                                   const float* __restrict__ w,
+                                                                   float* __restrict__ img, const int N, const int H,
+                                                                   const int W, const int ntiles) {
+    constexpr int C = 32, TH = 8, TW = 32, HC = TW + 2, ROWB = 80, NCH = (TH + 2) * HC * 4, NI = (NCH + 255) / 256;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    __shared__ __attribute__((aligned(16))) unsigned char s_h[(TH + 2) * HC * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    bf16x8_t a_hi[9], a_lo[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        bf16x8_t hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = m < 3 ? w[(m * 9 + tap) * C + 8 * g + j] : 0.f;
+            short hh, ll;
+            split_hi_lo(v, hh, ll);
+            hi[j] = hh;
+            lo[j] = ll;
+        }
+        a_hi[tap] = hi;
+        a_lo[tap] = lo;
+    }
+    const int tiles_x = W / TW, tiles_y = H / TH;
+    u32x4_t ph[NI];
+    auto fetch = [&](const int tile) __attribute__((always_inline)) {
+        const int txi = tile % tiles_x, tyi = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int y0 = tyi * TH, x0 = txi * TW;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = tid + 256 * u, p = i >> 2, ch = i & 3;
+            const int hy = p / HC, hx = p - hy * HC;
+            const int y = y0 + hy - 1, x = x0 + hx - 1;
+            ph[u] = u32x4_t{0u, 0u, 0u, 0u};
+            if (i < NCH && y >= 0 && y < H && x >= 0 && x < W)
+                ph[u] = *reinterpret_cast<const u32x4_t*>(h + (((int64_t)n * H + y) * W + x) * C + ch * 8);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int txi = tile % tiles_x, tyi = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int y0 = tyi * TH, x0 = txi * TW;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int i = tid + 256 * u, p = i >> 2, ch = i & 3;
+            if (i < NCH) *reinterpret_cast<u32x4_t*>(s_h + p * ROWB + ch * 16) = ph[u];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int yl = 2 * wid + (q >> 1), xl = 16 * (q & 1) + m;
+            f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const bf16x8_t bf = *reinterpret_cast<const bf16x8_t*>(s_h + ((yl + tap / 3) * HC + xl + tap % 3) * ROWB + g * 16);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[tap], bf, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[tap], bf, acc, 0, 0, 0);
+            }
+            if (g == 0) {           // D rows 0..2 = co, column = pixel
+                float* o = img + (((int64_t)n * 3) * H + y0 + yl) * W + x0 + xl;
+                const int64_t cs = (int64_t)H * W;
+                o[0] = tanh_fast(acc[0]);
+                o[cs] = tanh_fast(acc[1]);
+                o[2 * cs] = tanh_fast(acc[2]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ image head backward on the bf16 matrix cores
+// (bf16 activations, C = 32: GET_IMAGE_G of every stage, model.py:426-437).  With D[pix][k] = dpre[co][y - kh + 1][x - kw + 1],
+// k = (co, kh, kw) (27 of 32 columns), dpre = dimg * (1 - img^2):
+//   dh[pix][ci] = sum_k D[pix][k] w[k][ci]          -- K = 32: two v_mfma_f32_32x32x16_bf16 steps per 32 pixels
+//   dw[k][ci]  += sum_pix D[pix][k] h[pix][ci]      -- K = pixels: D^T fragments = 8 consecutive floats of a dpre row,
+//                                                      h fragments via ds_read_b64_tr_b16 from the staged bf16 tile
+// D and w are f32 quantities: hi + lo bf16 parts (hi*hi + hi*lo + lo*hi); h is bf16 as stored.  A workgroup is
+// persistent, owns 8 x 32-pixel tiles, stages dpre with a one-pixel halo (f32, 4 KB) and the h tile (16 KB), keeps its
+// dw tile in registers over all its tiles and leaves ONE [27][32] partial sum per workgroup (scratch ring + fold, or
+// f32 atomics).  The next tile's global loads are issued before the current tile's MFMAs.  (The VALU / f32-MFMA kernel
+// above: 27 x 32 FMAs per pixel on the vector pipe + 106 KB of LDS, one workgroup per CU: 201 us at 256 px.)
+__host__ __device__ constexpr int img_head_doff(const int k) {     // offset of D[.][k] inside the halo tile (rows of 36, 10 per co)
+    return k < 27 ? (k / 9) * 360 + (2 - (k % 9) / 3) * 36 + (2 - k % 3) : -1;
+}
+__global__ __launch_bounds__(256, 2) void img_head_bwd_mfma_kernel(const bf16_t* __restrict__ h,
+                                                                   const float* __restrict__ w,
+                                                                   const float* __restrict__ img,
+                                                                   const float* __restrict__ dimg,
+                                                                   bf16_t* __restrict__ dh, float* __restrict__ dw,
+                                                                   const int N, const int H, const int W,
+                                                                   const int accumulate, const int ntiles,
+                                                                   float* __restrict__ part) {
+    constexpr int C = 32, TH = 8, TW = 32, HC = TW + 2, RS = 36, CS = (TH + 2) * RS, NDP = 3 * (TH + 2) * HC;
+    constexpr int NU = (NDP + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float s_dp[3 * CS + 64];
+    __shared__ __attribute__((aligned(16))) unsigned char s_h[TH * TW * 64];        // [pixel][32 ci] bf16; later: [4][27*32] f32
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l32 = lane & 31, g = lane >> 5;
+    // dh: A = w^T (rows ci), B = D (columns = the 32 pixels of a tile row)
+    bf16x8_t wa_hi[2], wa_lo[2];
+    static_assert(RS == 36 && CS == 360, "img_head_doff");
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        bf16x8_t hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * st + 8 * g + j;
+            const float v = k < 27 ? w[k * C + l32] : 0.f;
+            short hh, ll;
+            split_hi_lo(v, hh, ll);
+            hi[j] = hh;
+            lo[j] = ll;
+        }
+        wa_hi[st] = hi;
+        wa_lo[st] = lo;
+    }
+    // dw: A = D^T (row k = l32: 8 consecutive pixels of one dpre row), B = h (column ci = l32, transposing read)
+    const bool krow = l32 < 27;
+    const int offk = krow ? (l32 / 9) * CS + (2 - (l32 % 9) / 3) * RS + (2 - l32 % 3) : 0;
+    f32x16_t wacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wacc[r] = 0.f;
+    for (int i = tid; i < 3 * CS + 64; i += 256) s_dp[i] = 0.f;
+
+    const int tiles_x = W / TW, tiles_y = H / TH;
+    float pt[NU], pg[NU];
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    u32x4_t ph[4];
+    auto fetch = [&](const int tile) __attribute__((always_inline)) {
+        const int txi = tile % tiles_x, tyi = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int y0 = tyi * TH, x0 = txi * TW;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int i = tid + 256 * u;
+            const int co = i / ((TH + 2) * HC), rem = i - co * ((TH + 2) * HC);
+            const int hy = rem / HC, hx = rem - hy * HC;
+            const int y = y0 + hy - 1, x = x0 + hx - 1;
+            const bool ok = i < NDP && y >= 0 && y < H && x >= 0 && x < W;
+            pt[u] = 0.f;
+            pg[u] = 0.f;
+            if (ok) {
+                const int64_t o = (((int64_t)n * 3 + co) * H + y) * W + x;
+                pt[u] = img[o];
+                pg[u] = dimg[o];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u, p = i >> 2, ch = i & 3;
+            const int64_t pix = ((int64_t)n * H + y0 + (p >> 5)) * W + x0 + (p & 31);
+            ph[u] = *reinterpret_cast<const u32x4_t*>(h + pix * C + ch * 8);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int txi = tile % tiles_x, tyi = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int y0 = tyi * TH, x0 = txi * TW;
+        __syncthreads();            // the previous tile's reads are done (first tile: s_dp cleared)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int i = tid + 256 * u;
+            if (i < NDP) {
+                const int co = i / ((TH + 2) * HC), rem = i - co * ((TH + 2) * HC);
+                const int hy = rem / HC, hx = rem - hy * HC;
+                s_dp[co * CS + hy * RS + hx] = pg[u] * (1.f - pt[u] * pt[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<u32x4_t*>(s_h + (tid + 256 * u) * 16) = ph[u];
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int yl = 2 * wid + rr;
+            // ---- dh of the 32 pixels of tile row yl
+            f32x16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* db = s_dp + yl * RS + l32;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8_t bh, bl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int oa = img_head_doff(16 * st + j), ob = img_head_doff(16 * st + 8 + j);     // (compile-time)
+                    const int o = g ? ob : oa;
+                    const float v = o >= 0 ? db[o >= 0 ? o : 0] : 0.f;
+                    short hh, ll;
+                    split_hi_lo(v, hh, ll);
+                    bh[j] = hh;
+                    bl[j] = ll;
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_lo[st], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_hi[st], bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_hi[st], bh, acc, 0, 0, 0);
+            }
+            // D layout: column = l32 (pixel), rows (r & 3) + 8 (r >> 2) + 4 g (ci): 4 consecutive channels per r >> 2
+            {
+                const int64_t pix = ((int64_t)n * H + y0 + yl) * W + x0 + l32;
+                bf16_t* op = dh + pix * C + 4 * g;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4] = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                    if (accumulate) {
+                        const uint2 pr = *reinterpret_cast<const uint2*>(op + 8 * q);
+                        v[0] += __uint_as_float(pr.x << 16); v[1] += __uint_as_float(pr.x & 0xffff0000u);
+                        v[2] += __uint_as_float(pr.y << 16); v[3] += __uint_as_float(pr.y & 0xffff0000u);
+                    }
+                    uint2 o;
+                    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                    o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(op + 8 * q) = o;
+                }
+            }
+            // ---- dw += D^T h over the same 32 pixels: two 16-pixel steps
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const float* ab = s_dp + offk + yl * RS + 16 * half + 8 * g;
+                bf16x8_t ah, al;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = krow ? ab[j] : 0.f;
+                    short hh, ll;
+                    split_hi_lo(v, hh, ll);
+                    ah[j] = hh;
+                    al[j] = ll;
+                }
+                const unsigned char* slice = s_h + (yl * TW + 16 * half) * 64;
+                const int g16 = lane >> 4, i16 = lane & 15;
+                const unsigned char* a0 = slice + (8 * (g16 >> 1) + (i16 >> 2)) * 64 + (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
+                typedef __attribute__((address_space(3))) s16x4_t* lptr;
+                const s16x4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
+                const s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * 64));
+                bf16x8_t hb;
+                hb[0] = lo4[0]; hb[1] = lo4[1]; hb[2] = lo4[2]; hb[3] = lo4[3];
+                hb[4] = hi4[0]; hb[5] = hi4[1]; hb[6] = hi4[2]; hb[7] = hi4[3];
+                wacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, hb, wacc, 0, 0, 0);
+                wacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, hb, wacc, 0, 0, 0);
+            }
+        }
+    }
+    // the four waves' dw tiles, added in wave order, then one [27][32] partial sum per workgroup
+    __syncthreads();
+    float* s_r = reinterpret_cast<float*>(s_h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (k < 27) s_r[wid * (27 * C) + k * C + l32] = wacc[r];
+    }
+    __syncthreads();
+    for (int o = tid; o < 27 * C; o += 256) {
+        const float v = ((s_r[o] + s_r[27 * C + o]) + s_r[2 * 27 * C + o]) + s_r[3 * 27 * C + o];
+        if (part) part[(int64_t)blockIdx.x * 27 * C + o] = v;
+        else atomicAdd(&dw[o], v);
+    }
+}
+
 // ------------------------------------------------------------------ logits head
 template <typename T>
 __global__ __launch_bounds__(256) void logits_fwd_kernel(const T* __restrict__ h, const float* __restrict__ w,
@@ -639,6 +1192,15 @@ extern "C" int sba_img_head_fwd(int dtype, const void* h, const float* w, float*
     if (!h || !w || !img || N <= 0 || H <= 0 || W <= 0) return SBA_E_ARG;
     const int64_t total = (int64_t)N * H * W;
     if (total > 0x7fffffffLL * 64) return SBA_E_ARG;
+    static int mfma = -1;       // SBA_HEAD_MFMA=0: the VALU kernel for bf16 as well (A/B aid)
+    if (mfma < 0) { const char* e = getenv("SBA_HEAD_MFMA"); mfma = (e && e[0] == '0') ? 0 : 1; }
+    if (dtype == SBA_BF16 && mfma && C_ == 32 && W % 32 == 0 && H % 8 == 0 && total / 256 <= 0x7fffffff) {
+        const int ntiles = (int)(total / 256);
+        const int blocks = ntiles < 1024 ? ntiles : 1024;       // persistent: four workgroups per CU
+        SBA_LAUNCH(img_head_fwd_mfma_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, w, img,
+                   N, H, W, ntiles);
+        return SBA_CHECK_LAUNCH();
+    }
     SBA_DISPATCH(dtype, CH_SWITCH(C_, SBA_LAUNCH((img_head_fwd_kernel<T, C>), dim3(cdiv(total, 256)),
                                                         dim3(256), 0, (hipStream_t)stream, (const T*)h, w, img, N,
                                                         H, W)));
@@ -650,6 +1212,22 @@ extern "C" int sba_img_head_bwd(int dtype, const void* h, const float* w, const 
     if (!h || !w || !img || !dimg || !dh || !dw || N <= 0 || H <= 0 || W <= 0) return SBA_E_ARG;
     if (C_ > 64) return SBA_E_ARG;       // LDS budget of the fused wgrad contraction
     const int64_t total = (int64_t)N * H * W;
+    static int mfma = -1;       // SBA_HEAD_MFMA=0: the VALU / f32-MFMA kernel for bf16 as well (A/B aid)
+    if (mfma < 0) { const char* e = getenv("SBA_HEAD_MFMA"); mfma = (e && e[0] == '0') ? 0 : 1; }
+    if (dtype == SBA_BF16 && mfma && C_ == 32 && W % 32 == 0 && H % 8 == 0 && total / 256 <= 0x7fffffff) {
+        const int ntiles = (int)(total / 256);
+        const int blocks = ntiles < 1024 ? ntiles : 1024;       // persistent: four workgroups per CU
+        hipStream_t st = (hipStream_t)stream;
+        float* part = nullptr;
+        const bool det = sba_det_on();
+        if (det) { part = sba_det_alloc((int64_t)blocks * 27 * 32); if (!part) return SBA_E_ARG; }
+        else if (blocks > 64) part = sba_reduce_alloc((int64_t)blocks * 27 * 32);      // (none: atomics)
+        SBA_LAUNCH(img_head_bwd_mfma_kernel, dim3(blocks), dim3(256), 0, st, (const bf16_t*)h, w, img, dimg,
+                   (bf16_t*)dh, dw, N, H, W, accumulate, ntiles, part);
+        if (part && det) sba_det_fold(part, 1, blocks, 27 * 32, dw, 0, 0, st);
+        else if (part) sba_fold_add(part, blocks, 27 * 32, dw, st);
+        return SBA_CHECK_LAUNCH();
+    }
     SBA_DISPATCH(dtype, CH_SWITCH(C_, {
         const size_t sh = sizeof(float) * (27 * C + 256 * (C + 1) + 256 * 33 + 32 * C);
         set_lds(img_head_bwd_kernel<T, C>, sh);
@@ -691,6 +1269,33 @@ extern "C" int sba_d_stem_bwd(int dtype, const float* img, const float* w, const
                               float* dimg, float* dw, int N, int S, int C, void* stream) {
     if (!img || !w || !out || !dout || N <= 0 || S <= 0 || S % 2 || C <= 0 || C % 32 || C > 256) return SBA_E_ARG;
     hipStream_t st = (hipStream_t)stream;
+    static int mfma = -1;       // SBA_STEM_MFMA=0: the VALU / f32-MFMA kernels for bf16 as well (A/B aid)
+    if (mfma < 0) { const char* e = getenv("SBA_STEM_MFMA"); mfma = (e && e[0] == '0') ? 0 : 1; }
+    const bool mm = dtype == SBA_BF16 && mfma && C == 64;
+    if (dw && mm) {
+        const int64_t pix = (int64_t)N * (S / 2) * (S / 2);
+        const int64_t tiles = (pix + 63) / 64;
+        int tpb = (int)((tiles + 767) / 768);       // three workgroups per CU (48 KB of LDS each)
+        if (tpb < 1) tpb = 1;
+        const int blocks = (int)((tiles + tpb - 1) / tpb);
+        float* part = nullptr;
+        const bool det = sba_det_on();
+        if (det) { part = sba_det_alloc((int64_t)blocks * C * 48); if (!part) return SBA_E_ARG; }
+        else if (blocks > 64) part = sba_reduce_alloc((int64_t)blocks * C * 48);    // (none: atomics)
+        SBA_LAUNCH(d_stem_wgrad_mfma_kernel, dim3(blocks), dim3(256), 0, st, img, (const bf16_t*)out,
+                   (const bf16_t*)dout, part ? part : dw, N, S, tpb, part ? 1 : 0);
+        if (part && det) sba_det_fold(part, 1, blocks, (int64_t)C * 48, dw, 0, 0, st);
+        else if (part) sba_fold_add(part, blocks, (int64_t)C * 48, dw, st);
+        dw = nullptr;
+    }
+    if (dimg && mm && (S / 2) % 16 == 0) {
+        const int64_t ntiles = (int64_t)N * (S / 2 / 16) * (S / 2 / 8);
+        if (ntiles > 0x7fffffff) return SBA_E_ARG;
+        const int blocks = ntiles < 512 ? (int)ntiles : 512;       // persistent: two workgroups per CU
+        SBA_LAUNCH(d_stem_dgrad_mfma_kernel, dim3(blocks), dim3(256), 0, st, w, (const bf16_t*)out,
+                   (const bf16_t*)dout, dimg, N, S, (int)ntiles);
+        dimg = nullptr;
+    }
     if (dw) {
         const int64_t pix = (int64_t)N * (S / 2) * (S / 2);
         const int64_t tiles = (pix + 63) / 64;

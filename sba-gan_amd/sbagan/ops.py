@@ -358,6 +358,24 @@ def workspace(device):
     return ws
 
 
+_REDUCE_SCRATCH = {}
+REDUCE_SCRATCH_BYTES = int(os.environ.get('SBA_REDUCE_SCRATCH_MB', '64')) << 20
+
+
+def reduce_scratch(device):
+    """The ring for the default mode's two-stage reductions (include/sbagan_hip.h: sba_set_reduce_scratch), handed to
+    the library the first time an operator that uses it runs on `device` (SBA_REDUCE_SCRATCH_MB=0: none, atomics)."""
+    if device not in _REDUCE_SCRATCH:
+        buf = None
+        if REDUCE_SCRATCH_BYTES:
+            with torch.cuda.stream(torch.cuda.default_stream(device)):
+                buf = torch.empty(REDUCE_SCRATCH_BYTES, dtype=torch.uint8, device=device)
+            torch.cuda.current_stream(device).wait_stream(torch.cuda.default_stream(device))
+            call('sba_set_reduce_scratch', buf.data_ptr(), REDUCE_SCRATCH_BYTES)
+        _REDUCE_SCRATCH[device] = buf
+    return _REDUCE_SCRATCH[device]
+
+
 # ---- measured tile table (tools/tune_igemm.py -> sbagan/igemm_table.json) --------------------------------
 # key -> [tile, ksplit]: the tile configuration / K split of sba_conv_igemm that was fastest for that layer shape
 # on an MI355X (bf16).  Shapes that are not in the table use the library's rule table (tile = 0).
@@ -988,6 +1006,7 @@ class ImgHeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, weight):
         h = as_act(h)
+        reduce_scratch(h.device)         # (allocated here, outside any later graph capture of the backward)
         N, C, H, W = h.shape
         if not weight.is_contiguous(memory_format=CL):
             raise RuntimeError('img head weight must be channels_last')
@@ -1014,6 +1033,7 @@ class DStemFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, weight):
         _need_gpu(img)
+        reduce_scratch(img.device)       # (allocated here, outside any later graph capture of the backward)
         img = img.float().contiguous()
         N, _, S, S2 = img.shape
         assert S == S2

@@ -243,6 +243,40 @@ def test_inception_conv_geometries(dev, dt, geom):
     close(gx[..., :I].permute(0, 3, 1, 2), gx_ref, dt, 'dx')
 
 
+# ------------------------------------------------------------------ every bf16 tile configuration, forced
+# sba_conv_geom.tile / .ksplit (include/sbagan_hip.h) pick the kernel instantiation; the measured table only ever uses a
+# few per shape, so each id is forced here on the weight-streaming shapes of the discriminator tails (model.py:560-607:
+# 4x4 maps, M = 16 B rows): one full 320-row tile, a ragged one (B - 1 = 19 images), two M tiles, a ragged 5x5 map.
+SKINNY_CASES = [(20, 4, 128, 192), (19, 4, 64, 72), (40, 4, 128, 64), (7, 5, 192, 136)]
+
+
+@pytest.mark.parametrize('case', SKINNY_CASES)
+def test_igemm_every_tile_configuration(dev, case):
+    import ctypes
+    from sbagan import _lib, ops
+    from sbagan.inception_hip import _geom
+    N, S, I, O = case
+    dt = torch.bfloat16
+    x = fill.unit((N, I, S, S), 21)
+    w = fill.unit((O, I, 3, 3), 22) / np.sqrt(9 * I)
+    bias = 0.1 * fill.uniform((O,), 23)
+    ref = torch.relu(F.conv2d(rounded(x, dt), rounded(w, dt), bias, 1, 1))
+    xa = x.permute(0, 2, 3, 1).contiguous().to(dev).to(dt)
+    wa = w.permute(0, 2, 3, 1).contiguous().to(dev).to(dt)          # [Cout][tap][Cin]
+    ba = bias.to(dev)
+    ws = ops.workspace(dev)
+    taps = [(t // 3 - 1, t % 3 - 1) for t in range(9)]
+    for tile in range(1, _lib.IGEMM_TILES + 1):
+        for ksplit in (1, 3):
+            g = _geom(N, S, S, I, S, S, O, taps, relu=1)
+            g.tile, g.ksplit = tile, ksplit
+            y = torch.full((N, S, S, O), 7.0, dtype=dt, device=dev)
+            _lib.call('sba_conv_igemm_bias', _lib.SBA_BF16, xa.data_ptr(), wa.data_ptr(), y.data_ptr(), None, None,
+                      ba.data_ptr(), None, ctypes.byref(g), ws.data_ptr(), ops.WORKSPACE_BYTES, ops._stream())
+            torch.cuda.synchronize()
+            close(y.permute(0, 3, 1, 2), ref, dt, 'tile %d split %d' % (tile, ksplit))
+
+
 @pytest.mark.parametrize('dt', DTYPES)
 def test_maxpool3x3s2_pairs(dev, dt):
     """max_pool2d(3, 2) of the image encoder (model.py:215,221 and the reduction blocks): forward, the backward that
@@ -491,6 +525,71 @@ def test_image_head_and_d_stem_and_logits(dev, dt):
     close(f, fr, dt, 'D feat', scale=3); close(pc, pr_c, dt, 'cond prob', scale=3); close(pu, pr_u, dt, 'uncond prob', scale=3)
     close(xa.grad, xr.grad, dt, 'dimg', scale=5)
     _check_module(d, Q, dt, '', gscale=5)
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 32), (3, 64, 64), (20, 128, 128), (1, 8, 96), (2, 12, 48)])
+def test_image_head_matrix_cores(dev, shape):
+    """GET_IMAGE_G (model.py:426-437), bf16 features, W % 32 == 0 and H % 8 == 0: forward and backward (dh and dw)
+    on the bf16 matrix cores with hi + lo split f32 operands (the ragged 20 x 23 map of
+    test_image_head_and_d_stem_and_logits and the 12 x 48 one here stay on the VALU kernels).
+    dh is a bf16 tensor (2^-9 relative rounding per element), dw f32.  20 x 128 x 128: 1280 tiles on 1024 persistent
+    workgroups, partial sums through the scratch ring; then the same launch accumulating into an existing dh."""
+    from sbagan import _lib, nets, ops
+    ops.set_compute_dtype(torch.bfloat16)
+    N, H, W = shape
+    ngf = 32
+    h = rounded(fill.unit((N, ngf, H, W), 41), torch.bfloat16)
+    w = fill.unit((3, ngf, 3, 3), 42) / np.sqrt(9 * ngf)
+    dimg = fill.unit((N, 3, H, W), 43)
+    hr, wr = h.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = torch.tanh(F.conv2d(hr, wr, None, 1, 1))
+    gh, gw = torch.autograd.grad(ref, [hr, wr], dimg)
+    head = nets.GET_IMAGE_G(ngf)
+    _load(head, {'img.0.weight': w}, dev)
+    ha = act(h, torch.bfloat16, dev).requires_grad_(True)
+    img = head(ha)
+    img.backward(dimg.to(dev))
+    torch.cuda.synchronize()
+    assert rel_l2(img.cpu(), ref) <= 1e-4, rel_l2(img.cpu(), ref)       # forward: one 16x16x32 MFMA pair per tap
+    # the kernel differentiates tanh at ITS forward value (f32 accumulation order differs from torch's conv in the last bits)
+    assert rel_l2(ha.grad.float().cpu(), gh) <= 4e-3, rel_l2(ha.grad.float().cpu(), gh)
+    assert rel_l2(head.img[0].weight.grad.cpu(), gw) <= 3e-4, rel_l2(head.img[0].weight.grad.cpu(), gw)
+    # accumulate = 1: dh += ...
+    dh = ha.grad.detach().clone()
+    dw = torch.zeros_like(head.img[0].weight)
+    _lib.call('sba_img_head_bwd', _lib.SBA_BF16, ha.data_ptr(), head.img[0].weight.data_ptr(), img.data_ptr(),
+              dimg.to(dev).data_ptr(), dh.data_ptr(), dw.data_ptr(), N, H, W, ngf, 1, ops._stream())
+    torch.cuda.synchronize()
+    assert rel_l2(dh.float().cpu(), 2 * gh) <= 6e-3
+    assert rel_l2(dw.cpu(), gw) <= 3e-4
+
+
+@pytest.mark.parametrize('shape', [(3, 64), (2, 128), (3, 32), (1, 24), (2, 256)])
+def test_d_stem_backward_matrix_cores(dev, shape):
+    """encode_image_by_16times' first conv (model.py:563-564), bf16 activations: data and weight gradient on the bf16 matrix
+    cores with hi + lo split f32 operands -- held to the torch f32 gradients far below the bf16 bound (the operands of the
+    contraction are exact to ~16 bits; only dout itself is a bf16 tensor).  O = 12 (S = 24): ragged pixel tiles in the weight
+    gradient, the data gradient on the VALU kernel; S = 256: the persistent data-gradient workgroups walk several tiles."""
+    from sbagan import ops
+    ops.set_compute_dtype(torch.bfloat16)
+    N, S = shape
+    img = fill.uniform((N, 3, S, S), 31)
+    w = fill.unit((64, 3, 4, 4), 32) / np.sqrt(48)
+    xr, wr = img.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    pre = F.conv2d(xr, wr, None, 2, 1)
+    dy = rounded(fill.unit(tuple(pre.shape), 33), torch.bfloat16)
+    wp = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
+    xa = img.to(dev).requires_grad_(True)
+    out = ops.DStemFn.apply(xa, wp)
+    out.backward(act(dy, torch.bfloat16, dev))
+    torch.cuda.synchronize()
+    close(out, F.leaky_relu(pre, 0.2), torch.bfloat16, 'out')
+    # the LeakyReLU slope follows the sign of the STORED activation (a pre-activation within rounding of zero may have
+    # either sign; a handful of flipped slopes among 10^6 outputs would dominate the bound below)
+    slope = torch.where(out.detach().float().cpu() > 0, 1.0, 0.2)
+    gx, gw = torch.autograd.grad(pre, [xr, wr], dy * slope)
+    assert rel_l2(xa.grad.cpu(), gx) <= 3e-4, rel_l2(xa.grad.cpu(), gx)
+    assert rel_l2(wp.grad.cpu(), gw) <= 3e-4, rel_l2(wp.grad.cpu(), gw)
 
 
 @pytest.mark.parametrize('dt', DTYPES)

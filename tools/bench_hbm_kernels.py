@@ -32,6 +32,7 @@ def timeit(fn, n=10):
 def main():
     dev = torch.device('cuda:0')
     ops.set_compute_dtype(torch.bfloat16)
+    ops.reduce_scratch(dev)          # the ring of the two-stage weight-gradient reductions, as the operators set it
     B, C = 20, 32
     st = torch.cuda.current_stream().cuda_stream
     rows = []
