@@ -79,7 +79,7 @@ typedef struct sba_conv_geom {
      * that add with atomics ignore it.  0 = always accumulate. */
     int32_t first_write;
 } sba_conv_geom;
-#define SBA_IGEMM_TILES 14
+#define SBA_IGEMM_TILES 15
 
 const char* sba_version(void);
 

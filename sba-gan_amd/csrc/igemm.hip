@@ -2623,7 +2623,8 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
         // tile ids (include/sbagan_hip.h: sba_conv_geom.tile): BM x BN, slabs per stage, ring depth
         //   1/2: 64x64 (64 / 128 KB of LDS)   3/4: 96x64 (72 / 144 KB)   5/6: 128x64 (48 / 144 KB)
         //   7/8: 128x128 (64 / 128 KB)        9/10: 256x64 (60 / 120 KB) 11: 320x128 register-staged   12: 96x128 (120 KB)
-        //   13: 320x64 (5 waves, 150 KB) / 14: 160x64 (5 waves, 120 KB): the WHOLE batch of a 4x4 map (M = 16 B = 320) in one
+        //   13: 320x64 (5 waves, 150 KB) / 14: 160x64 (5 waves, 120 KB) / 15: 160x64 with a 2-stage ring (60 KB: two
+        //   workgroups per CU): the WHOLE batch of a 4x4 map (M = 16 B = 320) in one
         //   M tile -- every weight byte is staged once per M tile, so these weight-streaming layers (4..38 MB of weights
         //   against 320..640 rows) move 1/3..1/5 of the L2->LDS bytes of the 64- / 96-row tiles; Cin % 64 == 0 only
         // the deep rings keep ~100 KB of loads in flight per CU: an L2-hit load takes ~1 us under load, so a
@@ -2641,7 +2642,7 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
         if (det) split = 1;
         static int gen2 = -1;       // SBA_IGEMM_DMA2=0: first-generation kernels only (A/B aid)
         if (gen2 < 0) { const char* e = getenv("SBA_IGEMM_DMA2"); gen2 = (e && e[0] == '0') ? 0 : 1; }
-        if ((tile == 13 || tile == 14) && !(gen2 && g.Cin % 64 == 0)) {       // gen-2 only: back to the rules
+        if (tile >= 13 && tile <= 15 && !(gen2 && g.Cin % 64 == 0)) {       // gen-2 only: back to the rules
             static const int rule_tile[4] = {7, 9, 5, 1};
             tile = best <= 3 ? rule_tile[best] : 11;
             split = det ? 1 : best_split;
@@ -2665,6 +2666,7 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
                 case 10: launch_dma2<256, 64, 64, 64, 4>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
                 case 13: launch_dma2<320, 64, 64, 64, 3>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
                 case 14: launch_dma2<160, 64, 32, 64, 4>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+                case 15: launch_dma2<160, 64, 32, 64, 2>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
                 default: launch_dma2<96, 128, 32, 128, 5>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
             }
         }

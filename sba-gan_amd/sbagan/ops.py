@@ -511,20 +511,26 @@ SIDE_WGRAD = False
 _COMPANION, _KEEPALIVE = {}, {}
 
 
-def conv_wgrad_overlapped(x, dy, param, kind):
-    if not SIDE_WGRAD:
-        return conv_wgrad(x, dy, param, kind)
+def _companion(device, *keep):
+    """the companion of the current stream, ordered behind everything issued to the current stream so far; `keep` =
+    tensors the companion's launches read (held until the join)"""
     cur = torch.cuda.current_stream()
     key = cur.cuda_stream
     comp = _COMPANION.get(key)
     if comp is None:
-        comp = _COMPANION[key] = torch.cuda.Stream(device=x.device)
+        comp = _COMPANION[key] = torch.cuda.Stream(device=device)
         _KEEPALIVE[key] = []
-    param_grad(param)                     # allocate (if needed) on the caller's stream
     comp.wait_stream(cur)
-    with torch.cuda.stream(comp):
+    _KEEPALIVE[key].extend(keep)
+    return comp
+
+
+def conv_wgrad_overlapped(x, dy, param, kind):
+    if not SIDE_WGRAD:
+        return conv_wgrad(x, dy, param, kind)
+    param_grad(param)                     # allocate (if needed) on the caller's stream
+    with torch.cuda.stream(_companion(x.device, x, dy)):
         conv_wgrad(x, dy, param, kind)
-    _KEEPALIVE[key].extend((x, dy))
 
 
 def join_wgrads():
@@ -767,7 +773,14 @@ class LinearFn(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = param_grad(weight) if ctx.needs_input_grad[1] else None
         db = param_grad(ctx.bias) if (ctx.bias is not None and ctx.needs_input_grad[2]) else None
-        call('sba_linear_bwd', _p(x), _p(weight), _p(dy), _p(dx), _p(dw), _p(db), B, K, N, _stream())
+        if SIDE_WGRAD and dx is not None and dw is not None:
+            # the chain of dense layers at the END of the generator's backward pass (MAPPING_NET, INIT_STAGE_G.fc,
+            # CA_NET.fc): only dx continues the chain -- dW / db go to the weight-gradient companion stream
+            with torch.cuda.stream(_companion(x.device, x, dy)):
+                call('sba_linear_bwd', _p(x), _p(weight), _p(dy), None, _p(dw), _p(db), B, K, N, _stream())
+            call('sba_linear_bwd', _p(x), _p(weight), _p(dy), _p(dx), None, None, B, K, N, _stream())
+        else:
+            call('sba_linear_bwd', _p(x), _p(weight), _p(dy), _p(dx), _p(dw), _p(db), B, K, N, _stream())
         return dx, None, None
 
 
@@ -837,7 +850,13 @@ class FcBnGluFn(torch.autograd.Function):
         call('sba_bn1d_glu_bwd', _dt(dout), _p(y), _p(dout), _p(bn.weight), _p(bn.bias), _p(ctx.aux[0]),
              _p(ctx.aux[1]), _p(dy), _p(param_grad(bn.weight)), _p(param_grad(bn.bias)), B, F, _stream())
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        call('sba_linear_bwd', _p(x), _p(weight), _p(dy), _p(dx), _p(param_grad(weight)), None, B, K, F, _stream())
+        dw = param_grad(weight)
+        if SIDE_WGRAD and dx is not None:       # (as LinearFn: the weight gradient beside the rest of the chain)
+            with torch.cuda.stream(_companion(x.device, x, dy)):
+                call('sba_linear_bwd', _p(x), _p(weight), _p(dy), None, _p(dw), None, B, K, F, _stream())
+            call('sba_linear_bwd', _p(x), _p(weight), _p(dy), _p(dx), None, None, B, K, F, _stream())
+        else:
+            call('sba_linear_bwd', _p(x), _p(weight), _p(dy), _p(dx), _p(dw), None, B, K, F, _stream())
         return dx, None, None, None, None
 
 

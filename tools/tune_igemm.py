@@ -14,9 +14,9 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import torch  # noqa: E402
 
-NTILES = 14
-TILE_BM = {1: 64, 2: 64, 3: 96, 4: 96, 5: 128, 6: 128, 7: 128, 8: 128, 9: 256, 10: 256, 11: 320, 12: 96, 13: 320, 14: 160}
-TILE_BN = {1: 64, 2: 64, 3: 64, 4: 64, 5: 64, 6: 64, 7: 128, 8: 128, 9: 64, 10: 64, 11: 128, 12: 128, 13: 64, 14: 64}
+NTILES = 15
+TILE_BM = {1: 64, 2: 64, 3: 96, 4: 96, 5: 128, 6: 128, 7: 128, 8: 128, 9: 256, 10: 256, 11: 320, 12: 96, 13: 320, 14: 160, 15: 160}
+TILE_BN = {1: 64, 2: 64, 3: 64, 4: 64, 5: 64, 6: 64, 7: 128, 8: 128, 9: 64, 10: 64, 11: 128, 12: 128, 13: 64, 14: 64, 15: 64}
 
 
 def main():
@@ -102,7 +102,7 @@ def main():
         cands = []
         for tile in range(1, NTILES + 1):
             bm, bn = TILE_BM[tile], TILE_BN[tile]
-            if bm >= 2 * M + 64 or (bn == 128 and g.Cout <= 64) or (tile in (13, 14) and (g.Cin % 64 or M > 4096)):
+            if bm >= 2 * M + 64 or (bn == 128 and g.Cout <= 64) or (tile in (13, 14, 15) and (g.Cin % 64 or M > 4096)):
                 continue
             tiles = -(-M // bm) * -(-g.Cout // bn)
             splits = [1]
@@ -118,8 +118,9 @@ def main():
             t_best = t_rule
         total_rule += t_rule * count
         total_best += t_best * count
-        report.append('%-44s x%-3d M=%-6d N=%-5d K=%-6d rule %7.1f us  best %7.1f us  tile %2d split %2d'
-                      % (k, count, M, g.Cout, g.ntaps * g.Cin, t_rule, cands[0][0], tile, sp))
+        report.append('%-44s x%-3d M=%-6d N=%-5d K=%-6d rule %7.1f us  best %7.1f us  tile %2d split %2d   next: %s'
+                      % (k, count, M, g.Cout, g.ntaps * g.Cin, t_rule, cands[0][0], tile, sp,
+                         ', '.join('%d/%d %.1f' % (t2, s2, u2) for u2, t2, s2 in cands[1:5])))
         print(report[-1], flush=True)
     print('sum over one step: rule table %.3f ms -> measured table %.3f ms' % (total_rule / 1e3, total_best / 1e3))
     if os.environ.get('TUNE_OUT'):
