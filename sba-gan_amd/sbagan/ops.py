@@ -508,6 +508,9 @@ def conv_wgrad(x, dy, param, kind):
 # before the optimizer reads the gradients; tensors handed to the companion are kept alive until
 # that join (no record_stream: safe under hipGraph capture).
 SIDE_WGRAD = False
+HOME_STREAM = None       # raw handle of the stream whose companion join_wgrads() will join (set by the trainer at the start of
+#                          a backward pass): the dense layers use the companion only from there -- their backward may be
+#                          replayed on a side stream (the mapping network's), whose companion nobody would join
 _COMPANION, _KEEPALIVE = {}, {}
 
 
@@ -773,7 +776,7 @@ class LinearFn(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = param_grad(weight) if ctx.needs_input_grad[1] else None
         db = param_grad(ctx.bias) if (ctx.bias is not None and ctx.needs_input_grad[2]) else None
-        if SIDE_WGRAD and dx is not None and dw is not None:
+        if SIDE_WGRAD and HOME_STREAM == _stream() and dx is not None and dw is not None:
             # the chain of dense layers at the END of the generator's backward pass (MAPPING_NET, INIT_STAGE_G.fc,
             # CA_NET.fc): only dx continues the chain -- dW / db go to the weight-gradient companion stream
             with torch.cuda.stream(_companion(x.device, x, dy)):
@@ -851,7 +854,7 @@ class FcBnGluFn(torch.autograd.Function):
              _p(ctx.aux[1]), _p(dy), _p(param_grad(bn.weight)), _p(param_grad(bn.bias)), B, F, _stream())
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dw = param_grad(weight)
-        if SIDE_WGRAD and dx is not None:       # (as LinearFn: the weight gradient beside the rest of the chain)
+        if SIDE_WGRAD and HOME_STREAM == _stream() and dx is not None:       # (as LinearFn: beside the rest of the chain)
             with torch.cuda.stream(_companion(x.device, x, dy)):
                 call('sba_linear_bwd', _p(x), _p(weight), _p(dy), None, _p(dw), None, B, K, F, _stream())
             call('sba_linear_bwd', _p(x), _p(weight), _p(dy), _p(dx), None, None, B, K, F, _stream())

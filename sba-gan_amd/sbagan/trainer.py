@@ -12,6 +12,7 @@ then discards (trainer.py:270,287) are not computed: D parameters are frozen for
 backward, which changes no result.
 """
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -330,6 +331,7 @@ class GANStep(object):
         fake_imgs, mu, logvar = self._ctx
         mark = self._mark
         ops.SIDE_WGRAD = self.overlap_wgrad
+        ops.HOME_STREAM = torch.cuda.current_stream().cuda_stream
         for p in self._d_params:
             p.requires_grad_(False)
         self.flatG.zero_grad()
@@ -385,7 +387,17 @@ class GANStep(object):
         streams = self._d_streams()[:nD] if self.concurrent_d else [main] * nD
         self.phase_pre(imgs, streams)         # (data-parallel: beside the generator's pending gradient exchange)
         self.finish()
+        # discriminator i reads fake image i only: its update forks from the point where that image has been issued
+        # (64 px: after the first stage, 128 px: after the second), not from the end of the generator's forward pass
+        img_ready = [None] * nD
+        if self.early_d and self.concurrent_d:
+            def on_image(i):
+                if i < nD - 1:
+                    img_ready[i] = torch.cuda.Event()
+                    img_ready[i].record()
+            self.netG.on_image = on_image
         self.phase_a(sent_emb, words_embs, mask, noise, eps)
+        self.netG.on_image = None
         mark('g_forward')
         # The three discriminator updates are independent of each other (different networks, the
         # same detached fakes): each runs on its own HIP stream so that the small launches of the
@@ -394,7 +406,10 @@ class GANStep(object):
         for i in range(nD):
             st = streams[i]
             if st is not main:
-                st.wait_stream(main)
+                if img_ready[i] is not None:
+                    st.wait_event(img_ready[i])
+                else:
+                    st.wait_stream(main)
             with torch.cuda.stream(st):
                 tails.append(self.phase_d(i, imgs, sent_emb, forked=st is not main))
         if self.early_damsm:
@@ -416,6 +431,7 @@ class GANStep(object):
             self.phase_events.append((name, e))
 
     concurrent_d = True
+    early_d = os.environ.get('SBA_EARLY_D', '1') == '1'      # fork the 64 / 128 px discriminator updates inside the G forward
     early_damsm = True           # DAMSM terms + their image gradient beside the discriminator updates (phase_e)
     overlap_wgrad = True
     overlap_wgrad_d = False      # companion streams inside the (already concurrent) discriminator updates cost
