@@ -169,8 +169,38 @@ def damsm_image_terms(image_encoder, fake_img, words_embs, sent_emb, match_label
     return w_loss.detach(), s_loss.detach(), grad
 
 
+def _g_term(netD, features, sent_emb):
+    """the adversarial term of generator_loss for one discriminator's features of the fake images (losses.py:168-186)"""
+    if FUSED_HEADS:
+        n = features.size(0)
+        if netD.UNCOND_DNET is not None:
+            return ops.d_heads(netD, features, sent_emb, ((0, n, 0, 1., 1., 1), (0, n, None, 1., 1., 0)))
+        return ops.d_heads(netD, features, sent_emb, ((0, n, 0, 1., 1., 0),))
+    cond_logits = netD.COND_DNET(features, sent_emb)
+    if netD.UNCOND_DNET is not None:
+        logits = netD.UNCOND_DNET(features)
+        return ops.BCEMultiFn.apply((1., 1.), (1., 1.), logits, cond_logits)
+    return ops.BCEMultiFn.apply((1.,), (1.,), cond_logits)
+
+
+def generator_d_term(netD, fake_img, sent_emb):
+    """One discriminator's term of generator_loss (losses.py:168-186) on its own, together with its gradient with
+    respect to the fake images: returns (g_loss, d g_loss / d fake_img).
+
+    The term needs discriminator i AFTER its update and fake image i, nothing else: a trainer can evaluate it -- forward
+    through the discriminator, backward to the image -- on the stream of that discriminator's update, right behind its
+    optimizer step, while the other discriminators are still updating, and hand the image gradients to the generator's
+    single backward pass later (generator_loss(..., d_terms=...), backward_with_image_grads); by linearity the parameter
+    gradients are those of the reference's backward pass of errG_total.  The discriminator's parameters must not
+    require gradients (the reference computes and discards them, trainer.py:270,287)."""
+    leaf = fake_img.detach().requires_grad_(True)
+    g_loss = _g_term(netD, netD(leaf), sent_emb)
+    (grad,) = torch.autograd.grad(g_loss, leaf)
+    return g_loss.detach(), grad
+
+
 def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sent_emb, match_labels,
-                   cap_lens, class_ids, streams=None, damsm=None):
+                   cap_lens, class_ids, streams=None, damsm=None, d_terms=None):
     """losses.py:164-206.  Returns (errG_total, logs) where logs is a dict of device scalars
     {'g_loss0', ..., 'w_loss', 's_loss'} (format with .item() outside the step).
 
@@ -180,7 +210,10 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
 
     damsm (optional, the (w_loss, s_loss, image gradient) of damsm_image_terms): the ranking terms were
     evaluated ahead of time; errG_total then carries their VALUES (same summation order as the reference) and the
-    caller back-propagates with `backward_with_image_grad`."""
+    caller back-propagates with `backward_with_image_grad`.
+
+    d_terms (optional, the g_loss values of generator_d_term, one per discriminator): likewise for the adversarial
+    terms; the caller back-propagates with `backward_with_image_grads`."""
     import contextlib
     numDs = len(netsD)
     batch_size = real_labels.size(0)
@@ -195,23 +228,11 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
 
     terms = []
     for i in range(numDs):
-        with branch(i):
-            features = netsD[i](fake_imgs[i])
-            if FUSED_HEADS:
-                n = features.size(0)
-                if netsD[i].UNCOND_DNET is not None:
-                    g_loss = ops.d_heads(netsD[i], features, sent_emb, ((0, n, 0, 1., 1., 1), (0, n, None, 1., 1., 0)))
-                else:
-                    g_loss = ops.d_heads(netsD[i], features, sent_emb, ((0, n, 0, 1., 1., 0),))
-                terms.append(g_loss)
-                logs['g_loss%d' % i] = g_loss.detach()
-                continue
-            cond_logits = netsD[i].COND_DNET(features, sent_emb)
-            if netsD[i].UNCOND_DNET is not None:
-                logits = netsD[i].UNCOND_DNET(features)
-                g_loss = ops.BCEMultiFn.apply((1., 1.), (1., 1.), logits, cond_logits)
-            else:
-                g_loss = ops.BCEMultiFn.apply((1.,), (1.,), cond_logits)
+        if d_terms is not None:         # evaluated ahead of time (generator_d_term): the VALUES, same summation order
+            g_loss = d_terms[i]
+        else:
+            with branch(i):
+                g_loss = _g_term(netsD[i], netsD[i](fake_imgs[i]), sent_emb)
         terms.append(g_loss)
         logs['g_loss%d' % i] = g_loss.detach()
     if damsm is not None:
@@ -238,6 +259,13 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
     logs['w_loss'] = w_loss.detach()
     logs['s_loss'] = s_loss.detach()
     return errG_total, logs
+
+
+def backward_with_image_grads(errG_total, fake_imgs, image_grads):
+    """One backward pass for errG_total whose adversarial AND ranking terms were evaluated ahead of time
+    (generator_loss(..., d_terms=..., damsm=...)): their gradients enter at the generator's images; errG_total itself
+    carries the graph of the KL term only."""
+    torch.autograd.backward([errG_total] + list(fake_imgs), [None] + list(image_grads))
 
 
 def backward_with_image_grad(errG_total, fake_img, image_grad):

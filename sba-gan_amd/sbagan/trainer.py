@@ -18,7 +18,8 @@ import torch
 import torch.distributed as dist
 
 from miscc.config import cfg
-from miscc.losses import (KL_loss, backward_with_image_grad, damsm_image_terms, discriminator_loss,
+from miscc.losses import (KL_loss, backward_with_image_grad, backward_with_image_grads, damsm_image_terms,
+                          discriminator_loss, generator_d_term,
                           generator_loss)
 
 from . import ops
@@ -174,6 +175,7 @@ class GANStep(object):
             first = next(getattr(d, name).parameters()) if name else None
             self._bucket_off.append(None if first is None else f.offset_of[id(first)])
         self._real_feats = [None] * len(netsD)
+        self._g_terms = [None] * len(netsD)
         self._g_pending = None
         self._d_buckets = {}
 
@@ -327,6 +329,17 @@ class GANStep(object):
             self.phase_d_opt(i)
         return tail
 
+    def phase_g_term(self, i, sent_emb):
+        """Discriminator i's term of the generator loss and its gradient w.r.t. fake image i, on the CURRENT stream --
+        the stream discriminator i has just been updated on.  The term depends on that update and on the image only, so
+        it runs behind discriminator i's optimizer step while the larger discriminators are still updating, instead of
+        behind the slowest of them (losses.py:168-186 evaluates the terms inside generator_loss, after all updates)."""
+        netD = self.netsD[i]
+        for p in netD.parameters():
+            p.requires_grad_(False)         # (phase_b_bwd restores them after the generator's backward pass)
+        value, grad = generator_d_term(netD, self._ctx[0][i], sent_emb)
+        self._g_terms[i] = (value, grad)
+
     def phase_b_bwd(self, sent_emb, words_embs, cap_lens, class_ids):
         fake_imgs, mu, logvar = self._ctx
         mark = self._mark
@@ -336,17 +349,28 @@ class GANStep(object):
             p.requires_grad_(False)
         self.flatG.zero_grad()
         damsm = getattr(self, '_damsm', None) if self.early_damsm else None
+        d_terms = self._g_terms if (damsm is not None and all(t is not None for t in self._g_terms)) else None
         errG_total, logs = generator_loss(self.netsD, self.image_encoder, fake_imgs, self.real_labels, words_embs,
                                           sent_emb, self.match_labels, cap_lens, class_ids,
-                                          streams=self._d_streams() if self.concurrent_d else None, damsm=damsm)
+                                          streams=self._d_streams() if self.concurrent_d else None, damsm=damsm,
+                                          d_terms=None if d_terms is None else [t[0] for t in d_terms])
         kl = KL_loss(mu, logvar)
         errG_total = errG_total + kl
         mark('g_loss_forward')
-        if damsm is not None:
+        if d_terms is not None:
+            grads = [t[1] for t in d_terms]
+            if not torch.cuda.is_current_stream_capturing():
+                for g in grads:             # produced on the discriminators' streams, consumed on this one
+                    g.record_stream(torch.cuda.current_stream())
+            grads[-1] = grads[-1] + damsm[2]
+            backward_with_image_grads(errG_total, fake_imgs, grads)
+            self._damsm = None
+        elif damsm is not None:
             backward_with_image_grad(errG_total, fake_imgs[-1], damsm[2])
             self._damsm = None
         else:
             errG_total.backward()
+        self._g_terms = [None] * len(self.netsD)
         ops.join_wgrads()
         mark('g_backward')
         for p in self._d_params:
@@ -412,6 +436,9 @@ class GANStep(object):
                     st.wait_stream(main)
             with torch.cuda.stream(st):
                 tails.append(self.phase_d(i, imgs, sent_emb, forked=st is not main))
+            if self.early_g_terms and self.early_damsm and st is not main:
+                with torch.cuda.stream(tails[-1]):
+                    self.phase_g_term(i, sent_emb)
         if self.early_damsm:
             # on the ORIGIN stream (the discriminator updates are the forks): the image encoder forks streams of
             # its own, and a fork inside a forked branch crashes hipStreamEndCapture on ROCm 7.2
@@ -432,6 +459,8 @@ class GANStep(object):
 
     concurrent_d = True
     early_d = os.environ.get('SBA_EARLY_D', '1') == '1'      # fork the 64 / 128 px discriminator updates inside the G forward
+    early_g_terms = os.environ.get('SBA_EARLY_G_TERMS', '1') == '1'      # each discriminator's generator-loss term right
+    #                                                                  behind its own update (phase_g_term)
     early_damsm = True           # DAMSM terms + their image gradient beside the discriminator updates (phase_e)
     overlap_wgrad = True
     overlap_wgrad_d = False      # companion streams inside the (already concurrent) discriminator updates cost
