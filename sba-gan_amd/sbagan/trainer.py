@@ -83,13 +83,27 @@ class FusedAdam(object):
         self.state = torch.zeros(4, dtype=torch.int32, device=flat.data.device)
 
     def step(self, grad_scale=1.0):
+        self.prepare()
+        self.step_range(0, self.flat.n, grad_scale)
+        self.done()
+
+    # the same update in pieces: prepare() once (step counter, bias corrections on the device), step_range over disjoint
+    # element ranges of the flat buffer in any order / on any streams ordered behind prepare(), done() once
+    def prepare(self):
+        call('sba_adam_prepare', self.state.data_ptr(), self.lr, self.betas[0], self.betas[1],
+             torch.cuda.current_stream().cuda_stream)
+
+    def step_range(self, lo, hi, grad_scale=1.0):
         f = self.flat
-        st = torch.cuda.current_stream().cuda_stream
-        call('sba_adam_prepare', self.state.data_ptr(), self.lr, self.betas[0], self.betas[1], st)
-        call('sba_adam_step', f.data.data_ptr(), f.grad.data_ptr(), f.m.data_ptr(), f.v.data_ptr(),
-             None if f.avg is None else f.avg.data_ptr(), None, self.state.data_ptr(), f.n,
-             self.betas[0], self.betas[1], self.eps, float(grad_scale), st)
-        f.epoch[0] += 1          # this network's packed weights are stale; the others are not
+        if hi <= lo:
+            return
+        b = 4 * lo
+        call('sba_adam_step', f.data.data_ptr() + b, f.grad.data_ptr() + b, f.m.data_ptr() + b, f.v.data_ptr() + b,
+             None if f.avg is None else f.avg.data_ptr() + b, None, self.state.data_ptr(), hi - lo,
+             self.betas[0], self.betas[1], self.eps, float(grad_scale), torch.cuda.current_stream().cuda_stream)
+
+    def done(self):
+        self.flat.epoch[0] += 1          # this network's packed weights are stale; the others are not
 
 
 def prepare_labels(batch_size, device):
@@ -176,6 +190,8 @@ class GANStep(object):
             self._bucket_off.append(None if first is None else f.offset_of[id(first)])
         self._real_feats = [None] * len(netsD)
         self._g_terms = [None] * len(netsD)
+        self._adam_early = [None] * len(netsD)
+        self._forked_d = False
         self._g_pending = None
         self._d_buckets = {}
 
@@ -262,7 +278,8 @@ class GANStep(object):
         self.flatD[i].zero_grad()
         rf = self._real_feats[i]
         self._real_feats[i] = None
-        split = ((self.distributed and self.bucket_d) or self.force_overlap_layout) and \
+        split = ((self.distributed and self.bucket_d) or self.force_overlap_layout or
+                 (self.bucket_adam and self._forked_d)) and \
             self._bucket_off[i] is not None and not ops.SIDE_WGRAD
         if rf is None:
             netD.clear_cuts(record=split)
@@ -294,15 +311,31 @@ class GANStep(object):
         bucket by bucket); returns (the stream on which the update must continue -- the weight-gradient companion
         when `forked`, see ops.wgrad_tail_stream --, the exchange handles to wait for)"""
         handles = []
+        self._adam_early[i] = None
         if self.phase_d_bwd_tail(i, imgs, sent_emb):
             if self.distributed:
                 handles.append(self.exchange.start(self.flatD[i].grad[self._bucket_off[i]:]))
+            elif forked and self.bucket_adam:
+                # The backward pass has reached the bucket boundary: the gradients of the tail + heads (D_NET256: 60.6 M of
+                # 71.9 M parameters) are complete.  Their Adam update -- 280 of the 334 us of an HBM-bound launch that
+                # otherwise sits on this discriminator's critical chain -- starts now on a side stream, beside the
+                # large-map trunk's backward pass; the rest of the chain continues on that stream (a one-way edge: ROCm
+                # 7.2's stream capture does not survive a fork that is joined back into a forked stream).
+                side = self._adam_stream(i)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self.optD[i].prepare()
+                    self.optD[i].step_range(self._bucket_off[i], self.flatD[i].n, 1.0 / self.world)
+                self._adam_early[i] = side
             self.phase_d_bwd_rest(i)
             split = True
         else:
             split = False
         if forked:
             tail = ops.wgrad_tail_stream()
+            if self._adam_early[i] is not None:
+                self._adam_early[i].wait_stream(tail)
+                tail = self._adam_early[i]
         else:
             ops.join_wgrads()
             tail = torch.cuda.current_stream()
@@ -319,10 +352,22 @@ class GANStep(object):
 
     def phase_d_opt(self, i):
         """Adam step of discriminator i (its averaged gradient must be in place)."""
+        if self._adam_early[i] is not None:      # the tail bucket was updated beside the backward pass (phase_d_bwd)
+            self.optD[i].step_range(0, self._bucket_off[i], 1.0 / self.world)
+            self.optD[i].done()
+            self._adam_early[i] = None
+            return
         self.optD[i].step(1.0 / self.world)
 
+    def _adam_stream(self, i):
+        if getattr(self, '_adam_streams', None) is None:
+            self._adam_streams = [torch.cuda.Stream(device=self.device) for _ in self.netsD]
+        return self._adam_streams[i]
+
     def phase_d(self, i, imgs, sent_emb, forked):
+        self._forked_d = bool(forked) and not self.distributed
         tail, handles = self.phase_d_bwd(i, imgs, sent_emb, forked)
+        self._forked_d = False
         with torch.cuda.stream(tail):
             for h in handles:
                 self._allreduce_wait(h)
@@ -459,11 +504,17 @@ class GANStep(object):
 
     concurrent_d = True
     early_d = os.environ.get('SBA_EARLY_D', '1') == '1'      # fork the 64 / 128 px discriminator updates inside the G forward
+    bucket_adam = os.environ.get('SBA_BUCKET_ADAM', '0') == '1'      # D_NET128 / D_NET256: Adam of the tail + heads beside the
+    #                                                                  trunk's backward pass (phase_d_bwd).  Correct (the GPU
+    #                                                                  suite passes with it on) but measured SLOWER: 11.50
+    #                                                                  against 11.29 ms -- the HBM-bound update competes with
+    #                                                                  the trunk's weight gradients, and the split backward
+    #                                                                  pass adds a graph boundary.  Off.
     early_g_terms = os.environ.get('SBA_EARLY_G_TERMS', '1') == '1'      # each discriminator's generator-loss term right
     #                                                                  behind its own update (phase_g_term)
     early_damsm = True           # DAMSM terms + their image gradient beside the discriminator updates (phase_e)
     overlap_wgrad = True
-    overlap_wgrad_d = False      # companion streams inside the (already concurrent) discriminator updates cost
+    overlap_wgrad_d = os.environ.get('SBA_OVERLAP_WGRAD_D', '0') == '1'      # companion streams inside the (already concurrent) discriminator updates cost
                                  # 1.5 ms under hipGraph replay: ROCm 7.2 runs graph branches nearly serially
 
     def _e_stream(self):
