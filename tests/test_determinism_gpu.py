@@ -167,6 +167,56 @@ def test_step_is_bit_reproducible_in_every_launch_mode(dev, det, encoder, dt):
     assert lib.sba_det_high_water() < ops.DET_SCRATCH_BYTES, 'one step must fit the scratch ring'
 
 
+@pytest.mark.parametrize('encoder,dt', [('standin', torch.float32), ('inception', torch.bfloat16)])
+def test_dependency_relaxations_do_not_change_a_bit(dev, det, encoder, dt):
+    """The step's fine-grained dependencies (every discriminator's generator-loss term right behind
+    its own update with the image gradients handed to the generator's single backward pass, the 64 / 128 px updates
+    forked from the point their fake image is issued, MAPPING_NET on a side stream) only reorder launches: one step from
+    the same state with all of them OFF -- the reference's order, trainer.py:261-299 -- and with all of them ON must
+    agree bit for bit in every loss, gradient, parameter, Adam-updated weight, EMA value, BatchNorm buffer and image;
+    so must the Adam update issued in two pieces (FusedAdam.step_range) and the bucketed discriminator update."""
+    from sbagan import nets, ops
+    from sbagan.synth import synthetic_batch
+    ops.set_compute_dtype(dt)
+    B = 20
+    b = synthetic_batch(B, device=dev, seed=100)
+    gen = torch.Generator(device='cpu')
+    gen.manual_seed(4321)
+    noise = torch.randn((B, 100), generator=gen).to(dev)
+    eps = torch.randn((B, 100), generator=gen).to(dev)
+    args = (b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'], b['class_ids'], noise)
+    st = _build_step(dev, B, encoder=encoder)
+    if encoder == 'standin':
+        st.image_encoder = _OrderedStandIn(256, device=dev)
+    orig = st.phase_a
+    st.phase_a = lambda se, we, m, nz, e=None: orig(se, we, m, nz, eps)
+    for _ in range(2):
+        st.step(*args)
+    torch.cuda.synchronize()
+    snap = st.snapshot()
+
+    def run(relaxed, bucket=False):
+        st.restore(snap)
+        st.early_g_terms = st.early_d = relaxed
+        st.bucket_adam = bucket
+        nets._GBase.fork_mapping = relaxed
+        try:
+            out = st.step(*args)
+            torch.cuda.synchronize()
+            return _state(st, out)
+        finally:
+            st.early_g_terms = st.early_d = True
+            st.bucket_adam = False
+            nets._GBase.fork_mapping = True
+
+    tag = '%s_%s' % (encoder, str(dt).split('.')[-1])
+    ref = run(False)
+    d = _diff(run(True), ref, 'relaxed_' + tag)
+    assert not d, ('relaxed dependencies vs the reference order', d[:8])
+    d = _diff(run(True, bucket=True), ref, 'bucket_adam_' + tag)
+    assert not d, ('bucketed discriminator update vs one Adam launch', d[:8])
+
+
 def test_small_batch_discriminator_gradients_are_reproducible(dev, det):
     """The 'bimodal' run-to-run differences of round 2 (a discriminator / generator-loss gradient at B = 3..4 moving by
     ~2e-3 between two f32 runs, tests/test_kernels_gpu.py::test_generator_loss_vs_oracle, tests/dist_worker.py) under
