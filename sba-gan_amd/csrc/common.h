@@ -95,7 +95,9 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
     return r;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp): the IEEE division of `1.f / (...)` expands to ~10 instructions (div_scale, rcp, four
+// FMAs, div_fmas, div_fixup) -- a fifth of the per-element work of the GLU BatchNorm passes, which are VALU-bound
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 // hipGetLastError() is per-thread and STICKY across unrelated runtime calls of the host framework (an
 // event query that returned hipErrorNotReady is enough): clear it before every launch so that
