@@ -494,7 +494,7 @@ def main():
             try:
                 from sbagan.trainer import ReplayedStep
                 g3 = ReplayedStep(step, *a, recorded_prologue=encode,
-                                  max_streams=int(os.environ.get('SBA_REPLAY_STREAMS', '8')), verbose=True)
+                                  max_streams=int(os.environ.get('SBA_REPLAY_STREAMS', '4')), verbose=True)
                 for _ in range(2):
                     g3.replay()
                 torch.cuda.synchronize()

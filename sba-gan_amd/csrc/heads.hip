@@ -272,20 +272,21 @@ __global__ __launch_bounds__(256) void d_stem_fwd_mfma_kernel(const float* __res
     const int O = S / 2;
     const int64_t total = (int64_t)N * O * O;
     const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wid) * tiles_per_wave;
-    for (int t = 0; t < tiles_per_wave; ++t) {
-        const int64_t p0 = (tile0 + t) * 32;
-        if (p0 >= total) break;                               // (wave-uniform)
+    // the 24 image floats of lane (pixel, kg) for one tile; the NEXT tile's are fetched before the current tile's MFMAs
+    // (a load -> wait -> compute -> store loop pays the HBM latency once per tile)
+    float vn[3][8];
+    auto fetch = [&](const int64_t p0) __attribute__((always_inline)) {
         const int64_t p = p0 + pl;
         const bool live = p < total;
         const int64_t pc = live ? p : 0;
-        const int ox = (int)(pc % O), oy = (int)((pc / O) % O), n = (int)(pc / ((int64_t)O * O));
+        // (32-bit: the host checks N * O * O < 2^31 -- a 64-bit division is ~200 instructions)
+        const uint32_t pq = (uint32_t)pc / (uint32_t)O;
+        const int ox = (int)((uint32_t)pc - pq * (uint32_t)O), n = (int)(pq / (uint32_t)O), oy = (int)(pq - (uint32_t)n * (uint32_t)O);
         const float* ib = img + (int64_t)n * 3 * S * S;
-        bf16x8_t b_hi[3], b_lo[3];
         const int ix0 = 2 * ox - 1;
         const bool inner = ix0 >= 0 && ix0 + 3 < S;           // all four columns inside the image: one 16-byte load per row
 #pragma unroll
         for (int s = 0; s < 3; ++s) {                         // s = input channel
-            float v[8];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int iy = 2 * oy + 2 * kg + hh - 1;
@@ -294,25 +295,35 @@ __global__ __launch_bounds__(256) void d_stem_fwd_mfma_kernel(const float* __res
                 if (rok && inner) {
                     struct __attribute__((packed, aligned(4))) F4 { float f[4]; };
                     const F4 q = *reinterpret_cast<const F4*>(rp + ix0);
-                    v[4 * hh] = q.f[0]; v[4 * hh + 1] = q.f[1]; v[4 * hh + 2] = q.f[2]; v[4 * hh + 3] = q.f[3];
+                    vn[s][4 * hh] = q.f[0]; vn[s][4 * hh + 1] = q.f[1]; vn[s][4 * hh + 2] = q.f[2]; vn[s][4 * hh + 3] = q.f[3];
                 } else {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int ix = ix0 + u;
-                        v[4 * hh + u] = (rok && ix >= 0 && ix < S) ? rp[ix] : 0.f;
+                        vn[s][4 * hh + u] = (rok && ix >= 0 && ix < S) ? rp[ix] : 0.f;
                     }
                 }
             }
+        }
+    };
+    if (tile0 * 32 < total) fetch(tile0 * 32);
+    for (int t = 0; t < tiles_per_wave; ++t) {
+        const int64_t p0 = (tile0 + t) * 32;
+        if (p0 >= total) break;                               // (wave-uniform)
+        bf16x8_t b_hi[3], b_lo[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
             bf16x8_t hi, lo;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const bf16_t h = f2bf(v[j]);
+                const bf16_t h = f2bf(vn[s][j]);
                 hi[j] = (short)h;
-                lo[j] = (short)f2bf(v[j] - bf2f(h));
+                lo[j] = (short)f2bf(vn[s][j] - bf2f(h));
             }
             b_hi[s] = hi;
             b_lo[s] = lo;
         }
+        if (t + 1 < tiles_per_wave && p0 + 32 < total) fetch(p0 + 32);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             f32x16_t acc;
@@ -700,7 +711,8 @@ __global__ __launch_bounds__(256, 2) void d_stem_wgrad_mfma_kernel(const float* 
         const int64_t pp = p0 + t;
         const bool live = pp < total;
         const int64_t pc = live ? pp : 0;
-        const int ox = (int)(pc % O), oy = (int)((pc / O) % O), n = (int)(pc / ((int64_t)O * O));
+        const uint32_t pq = (uint32_t)pc / (uint32_t)O;          // (32-bit divisions: N * O * O < 2^31, checked by the host)
+        const int ox = (int)((uint32_t)pc - pq * (uint32_t)O), n = (int)(pq / (uint32_t)O), oy = (int)(pq - (uint32_t)n * (uint32_t)O);
         const int iy = 2 * oy + kh - 1, ix0 = 2 * ox - 1;
         const bool rok = live && iy >= 0 && iy < S;
         const bool inner = ix0 >= 0 && ix0 + 3 < S;
@@ -1248,7 +1260,7 @@ extern "C" int sba_d_stem_fwd(int dtype, const float* img, const float* w, void*
     if ((pix + 255) / 256 > 0x7fffffff) return SBA_E_ARG;
     static int mfma = -1;       // SBA_STEM_MFMA=0: the VALU kernel for bf16 as well (A/B aid)
     if (mfma < 0) { const char* e = getenv("SBA_STEM_MFMA"); mfma = (e && e[0] == '0') ? 0 : 1; }
-    if (dtype == SBA_BF16 && mfma && (C == 32 || C == 64 || C == 128)) {
+    if (dtype == SBA_BF16 && mfma && (C == 32 || C == 64 || C == 128) && pix < 0x7fffffff) {
         const int64_t tiles = (pix + 31) / 32;
         const int tpw = tiles >= 16384 ? 4 : (tiles >= 4096 ? 2 : 1);
         const dim3 grid((unsigned)((tiles + 4 * tpw - 1) / (4 * tpw)));
@@ -1271,7 +1283,7 @@ extern "C" int sba_d_stem_bwd(int dtype, const float* img, const float* w, const
     hipStream_t st = (hipStream_t)stream;
     static int mfma = -1;       // SBA_STEM_MFMA=0: the VALU / f32-MFMA kernels for bf16 as well (A/B aid)
     if (mfma < 0) { const char* e = getenv("SBA_STEM_MFMA"); mfma = (e && e[0] == '0') ? 0 : 1; }
-    const bool mm = dtype == SBA_BF16 && mfma && C == 64;
+    const bool mm = dtype == SBA_BF16 && mfma && C == 64 && (int64_t)N * (S / 2) * (S / 2) < 0x7fffffff;
     if (dw && mm) {
         const int64_t pix = (int64_t)N * (S / 2) * (S / 2);
         const int64_t tiles = (pix + 63) / 64;

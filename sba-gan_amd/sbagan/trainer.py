@@ -766,7 +766,7 @@ class ReplayedStep(object):
     Same contract as GraphedStep for parameters changed behind its back (resync())."""
 
     def __init__(self, gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, prologue=None,
-                 recorded_prologue=None, max_streams=8, verbose=False):
+                 recorded_prologue=None, max_streams=4, verbose=False):
         """prologue: called eagerly before every replay (after the random draws); recorded_prologue: deterministic
         launches recorded in front of the step (e.g. the frozen text encoder's forward, trainer.py:248-252)."""
         if gan.distributed:
@@ -795,6 +795,11 @@ class ReplayedStep(object):
         raw = self.graph.raw_cuda_graph()
         self.handle = ctypes.c_void_p()
         from ._lib import lib
+        # 4 = the number of hardware queues a process gets by default (GPU_MAX_HW_QUEUES): one replay stream per queue.
+        # More streams share queues in an order the runtime picks (two independent chains on one queue run back to
+        # back): 8 streams 11.31 ms, 6: 11.18, 5: 11.15, **4: 11.05**, 3: 11.7, 2: 12.5; raising GPU_MAX_HW_QUEUES instead
+        # is far worse (5: 13.2 ms, 6: 19.8, 8: 20.7) -- profiles/r03_ab_replay_streams.txt
+        max_streams = int(os.environ.get('SBA_REPLAY_STREAMS', max_streams))
         rc = lib.sba_replay_create(ctypes.c_void_p(int(raw)), int(max_streams), 1 if verbose else 0,
                                    ctypes.byref(self.handle))
         if rc != 0:
