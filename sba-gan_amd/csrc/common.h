@@ -95,9 +95,11 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
     return r;
 }
 
-// v_exp_f32 + v_rcp_f32 (1 ulp): the IEEE division of `1.f / (...)` expands to ~10 instructions (div_scale, rcp, four
-// FMAs, div_fmas, div_fixup) -- a fifth of the per-element work of the GLU BatchNorm passes, which are VALU-bound
-__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+// (IEEE division on purpose.  `__builtin_amdgcn_rcpf(1.f + __expf(-x))` -- v_rcp_f32, 1 ulp -- makes the VALU-bound GLU
+// BatchNorm backward reduce 10 % faster (63 -> 56 us at 256 px, profiles/r03_bn_passes.txt), ~20 us per step; but the
+// bf16 step-0 losses sit at the 1e-3 bar as the end of a random walk of roundings, and that one-ulp
+// change moved errD2 of the B = 20 golden step from 9.3e-4 to 1.6e-3.  Not worth the margin.)
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 // hipGetLastError() is per-thread and STICKY across unrelated runtime calls of the host framework (an
 // event query that returned hipErrorNotReady is enough): clear it before every launch so that
