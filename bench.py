@@ -490,6 +490,24 @@ def main():
             except Exception as e:      # capture is an optimisation, never a requirement
                 sys.stderr.write('graph capture failed (%s: %s)\n' % (type(e).__name__, e))
                 torch.cuda.synchronize()
+        if args.graph in (1, 2) and os.environ.get('SBA_PHASE_REPLAY', '0') == '1':
+            # the same per-phase captures re-issued by the native replayer (GraphedStep(native=True): the gradient exchange
+            # stays between the phases).  Bit-identical to the eager step (tests/test_determinism_gpu.py) but measured
+            # SLOWER than hipGraphLaunch of the same phases (14.7 against 14.0 ms single-GPU, 16.1 against 15.5 with the
+            # data-parallel decomposition): ten replayers' fork streams on four hardware queues.  Off by default.
+            try:
+                from sbagan.trainer import GraphedStep
+                g2 = GraphedStep(step, *a, prologue=lambda: noise.normal_(0, 1), recorded_prologue=encode, native=True)
+                for _ in range(2):
+                    g2.replay()
+                torch.cuda.synchronize()
+                cands['replayed-phases'] = g2
+            except Exception as e:
+                import traceback
+                sys.stderr.write('per-phase launch replayer unavailable (%s: %s)\n' % (type(e).__name__, e))
+                if os.environ.get('SBA_BENCH_TRACEBACK') == '1':
+                    traceback.print_exc()
+                torch.cuda.synchronize()
         if args.graph in (2, 3) and not multi:
             try:
                 from sbagan.trainer import ReplayedStep

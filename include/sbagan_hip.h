@@ -425,12 +425,15 @@ int sba_lstm_bidir_fwd(const int64_t* captions, const int64_t* cap_lens, const f
  * stream, a fork takes the next of at most max_streams -- and stores the launch list; sba_replay_launch
  * re-issues the nodes in topological order as plain asynchronous launches on those streams, with events only
  * where a dependency crosses streams; it begins after everything already queued on `stream` and `stream` waits
- * for its end.  Unlike hipGraphLaunch on ROCm 7.2, independent branches then really run concurrently, at ~3 us
+ * for its end.  flags: bit 0 = print a summary to stderr; bit 1 = issue the first chain of the graph on `stream`
+ * ITSELF (for the per-phase graphs: a single-chain graph then uses no stream of its own -- a process has 4 hardware
+ * queues by default and every extra stream shares one; max_streams = 4 is the measured optimum for the whole step).
+ * Do not set bit 1 for callers on the NULL stream.  Unlike hipGraphLaunch on ROCm 7.2, independent branches then really run concurrently, at ~3 us
  * of host time per launch.  The graph must outlive the handle (kernel arguments live in its nodes); the handle
  * owns its streams and events.  Returns SBA_E_UNSUPPORTED for node kinds it cannot re-issue (callers fall
  * back to hipGraphLaunch).  info8 = {nodes, kernels, copies, memsets, streams, cross-stream waits, events, 0}.
  * This is the one entry point family that creates HIP objects (streams / events), at create time only. */
-int sba_replay_create(void* hip_graph, int max_streams, int verbose, void** out_handle);
+int sba_replay_create(void* hip_graph, int max_streams, int flags, void** out_handle);
 int sba_replay_launch(void* handle, void* stream);
 int sba_replay_info(void* handle, int* info8);
 int sba_replay_destroy(void* handle);

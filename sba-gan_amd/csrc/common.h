@@ -100,6 +100,9 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 // bf16 step-0 losses sit at the 1e-3 bar as the end of a random walk of roundings, and that one-ulp
 // change moved errD2 of the B = 20 golden step from 9.3e-4 to 1.6e-3.  Not worth the margin.)
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// the BACKWARD passes' recomputation of the gate (bn_bwd_reduce / apply / fused): v_rcp_f32.  Step-0 losses depend on
+// forward kernels only; gradients move by one ulp of the gate (their bounds are 10x wider than the losses')
+__device__ __forceinline__ float sigmoid_bwd_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 // hipGetLastError() is per-thread and STICKY across unrelated runtime calls of the host framework (an
 // event query that returned hipErrorNotReady is enough): clear it before every launch so that

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const YT* __restrict
                 for (int k = 0; k < V; ++k) {
                     const float n = a.get(k) * sc[k] + sh[k];
                     const float gp = gt.get(k) * scg[k] + shg[k];
-                    const float s = sigmoidf_(gp), dd = d.get(k);
+                    const float s = sigmoid_bwd_(gp), dd = d.get(k);
                     const float dza = dd * s, dzg = dd * n * s * (1.f - s);
                     s0[k] += dza;
                     s1[k] += dza * (a.get(k) - mn[k]) * rs[k];
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const YT* __restrict_
                 const int ca = c + k, cg = Co + c + k;
                 const float n = a.get(k) * scale[ca] + shift[ca];
                 const float gp = gt.get(k) * scale[cg] + shift[cg];
-                const float s = sigmoidf_(gp), dd = d.get(k);
+                const float s = sigmoid_bwd_(gp), dd = d.get(k);
                 const float dza = dd * s, dzg = dd * n * s * (1.f - s);
                 const float xa = (a.get(k) - mean[ca]) * rstd[ca];
                 const float xg = (gt.get(k) - mean[cg]) * rstd[cg];
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const YT* __restrict_
             for (int k = 0; k < V; ++k) {
                 const float n = a.get(k) * sc[0][k] + sh[0][k];
                 const float gp = gt.get(k) * sc[NV - 1][k] + sh[NV - 1][k];
-                const float sg = sigmoidf_(gp), dd = d.get(k);
+                const float sg = sigmoid_bwd_(gp), dd = d.get(k);
                 dz[0][k] = dd * sg;
                 dz[NV - 1][k] = dd * n * sg * (1.f - sg);
                 xh[0][k] = (a.get(k) - mn[0][k]) * rs[0][k];

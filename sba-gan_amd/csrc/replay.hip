@@ -10,6 +10,7 @@
 // kernels, copies and fills), the graph is walked here (nodes, parameters, edges), every node is given a stream
 // (a chain keeps its stream, a fork takes the next one) and each replay re-issues the nodes in topological order
 // with hipLaunchKernel / hipMemcpyAsync / hipMemsetAsync: ~3 us of host time per launch, real concurrency.
+// The first chain runs on the CALLER's stream; only forks get streams of the replayer's own.
 //
 // The graph object must outlive the replayer (kernel argument buffers belong to the graph's nodes).
 #include <hip/hip_runtime.h>
@@ -61,8 +62,10 @@ static bool is_1d(const hipMemcpy3DParms& p) {
 
 }  // namespace
 
-extern "C" int sba_replay_create(void* hip_graph, int max_streams, int verbose, void** out) {
+extern "C" int sba_replay_create(void* hip_graph, int max_streams, int flags, void** out) {
     if (!hip_graph || !out || max_streams < 1 || max_streams > 32) return SBA_E_ARG;
+    const int verbose = flags & 1;
+    const bool on_caller = (flags & 2) != 0;
     hipGraph_t graph = (hipGraph_t)hip_graph;
     size_t n = 0;
     RCHECK(hipGraphGetNodes(graph, nullptr, &n));
@@ -182,8 +185,12 @@ extern "C" int sba_replay_create(void* hip_graph, int max_streams, int verbose, 
             ++R->n_waits;
         }
     }
-    R->streams.resize(used_streams);
-    for (int s = 0; s < used_streams; ++s)
+    // flags bit 1: stream 0 of the assignment IS the caller's stream (sba_replay_launch): a single-chain graph -- one phase
+    // of the step -- then needs no stream of its own (a process has only 4 hardware queues by default; every extra stream
+    // shares one).  Not for a caller on the NULL stream: the whole step with its main chain there measured 12.0 against
+    // 11.15 ms on a stream of the replayer's own.
+    R->streams.assign(used_streams, nullptr);
+    for (int s = on_caller ? 1 : 0; s < used_streams; ++s)
         if (hipStreamCreateWithFlags(&R->streams[s], hipStreamNonBlocking) != hipSuccess) { delete R; return SBA_E_LAUNCH; }
     for (auto& e : R->events)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete R; return SBA_E_LAUNCH; }
@@ -210,10 +217,11 @@ extern "C" int sba_replay_launch(void* handle, void* stream) {
     static int timing = -1;     // SBA_REPLAY_TIMING=1: print the host time one replay takes to issue (tuning aid)
     if (timing < 0) { const char* e = getenv("SBA_REPLAY_TIMING"); timing = (e && e[0] == '1') ? 1 : 0; }
     const auto t0 = std::chrono::steady_clock::now();
-    RCHECK(hipEventRecord(R->start, caller));
-    for (hipStream_t s : R->streams) RCHECK(hipStreamWaitEvent(s, R->start, 0));
+    const bool own0 = !R->streams.empty() && R->streams[0] != nullptr;
+    if (R->streams.size() > 1 || own0) RCHECK(hipEventRecord(R->start, caller));
+    for (size_t s = own0 ? 0 : 1; s < R->streams.size(); ++s) RCHECK(hipStreamWaitEvent(R->streams[s], R->start, 0));
     for (RNode& r : R->nodes) {
-        hipStream_t s = R->streams[r.stream];
+        hipStream_t s = R->streams[r.stream] ? R->streams[r.stream] : caller;
         for (int e : r.waits) RCHECK(hipStreamWaitEvent(s, R->events[e], 0));
         switch (r.type) {
             case hipGraphNodeTypeKernel:
@@ -242,7 +250,7 @@ extern "C" int sba_replay_launch(void* handle, void* stream) {
         }
         if (r.record >= 0) RCHECK(hipEventRecord(R->events[r.record], s));
     }
-    for (size_t s = 0; s < R->streams.size(); ++s) {
+    for (size_t s = own0 ? 0 : 1; s < R->streams.size(); ++s) {
         hipEvent_t e = R->events[R->tail_event[s]];
         RCHECK(hipEventRecord(e, R->streams[s]));
         RCHECK(hipStreamWaitEvent(caller, e, 0));
@@ -267,7 +275,7 @@ extern "C" int sba_replay_info(void* handle, int* info8) {
 extern "C" int sba_replay_destroy(void* handle) {
     if (!handle) return SBA_E_ARG;
     Replayer* R = (Replayer*)handle;
-    for (hipStream_t s : R->streams) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    for (hipStream_t s : R->streams) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     for (hipEvent_t e : R->events) if (e) (void)hipEventDestroy(e);
     if (R->start) (void)hipEventDestroy(R->start);
     delete R;

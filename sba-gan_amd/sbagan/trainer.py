@@ -394,7 +394,7 @@ class GANStep(object):
             p.requires_grad_(False)
         self.flatG.zero_grad()
         damsm = getattr(self, '_damsm', None) if self.early_damsm else None
-        d_terms = self._g_terms if (damsm is not None and all(t is not None for t in self._g_terms)) else None
+        d_terms = self._g_terms if all(t is not None for t in self._g_terms) else None
         errG_total, logs = generator_loss(self.netsD, self.image_encoder, fake_imgs, self.real_labels, words_embs,
                                           sent_emb, self.match_labels, cap_lens, class_ids,
                                           streams=self._d_streams() if self.concurrent_d else None, damsm=damsm,
@@ -407,7 +407,9 @@ class GANStep(object):
             if not torch.cuda.is_current_stream_capturing():
                 for g in grads:             # produced on the discriminators' streams, consumed on this one
                     g.record_stream(torch.cuda.current_stream())
-            grads[-1] = grads[-1] + damsm[2]
+            if damsm is not None:
+                grads[-1] = grads[-1] + damsm[2]
+            # (damsm None: errG_total carries the graph of the ranking terms, evaluated inside generator_loss)
             backward_with_image_grads(errG_total, fake_imgs, grads)
             self._damsm = None
         elif damsm is not None:
@@ -481,13 +483,21 @@ class GANStep(object):
                     st.wait_stream(main)
             with torch.cuda.stream(st):
                 tails.append(self.phase_d(i, imgs, sent_emb, forked=st is not main))
-            if self.early_g_terms and self.early_damsm and st is not main:
+            if self.early_g_terms and st is not main:
                 with torch.cuda.stream(tails[-1]):
                     self.phase_g_term(i, sent_emb)
         if self.early_damsm:
             # on the ORIGIN stream (the discriminator updates are the forks): the image encoder forks streams of
             # its own, and a fork inside a forked branch crashes hipStreamEndCapture on ROCm 7.2
-            self.phase_e(sent_emb, words_embs, cap_lens, class_ids)
+            es = getattr(self, '_warm_e_stream', None)
+            if es is None:
+                self.phase_e(sent_emb, words_embs, cap_lens, class_ids)
+            else:       # (eager warm-up before a per-phase capture that gives this phase its own stream: per-stream
+                #          workspaces and the encoder's buffers must exist before the capture)
+                es.wait_stream(main)
+                with torch.cuda.stream(es):
+                    self.phase_e(sent_emb, words_embs, cap_lens, class_ids)
+                main.wait_stream(es)
         for st in streams + tails:
             if st is not main:
                 main.wait_stream(st)
@@ -568,6 +578,33 @@ class GANStep(object):
 _CAPTURE_MODE = 'thread_local'
 
 
+class _NativeGraph(object):
+    """One captured phase re-issued by the native replayer (csrc/replay.hip) instead of hipGraphLaunch: its first chain
+    runs on the CALLER's stream (phase graphs are single chains apart from the weight-gradient companion), so phases
+    replayed on different streams really overlap -- hipGraph launches on different streams do not, on ROCm 7.2."""
+
+    def __init__(self, graph, max_streams=2):
+        self.graph = graph                       # keeps the hipGraph (and the kernel arguments in its nodes) alive
+        self.handle = ctypes.c_void_p()
+        from ._lib import lib
+        rc = lib.sba_replay_create(ctypes.c_void_p(int(graph.raw_cuda_graph())), int(max_streams), 2,
+                                   ctypes.byref(self.handle))      # flags = 2: the first chain on the caller's stream
+        if rc != 0:
+            raise RuntimeError('sba_replay_create failed (%d)' % rc)
+
+    def replay(self):
+        call('sba_replay_launch', self.handle, torch.cuda.current_stream().cuda_stream)
+
+    def __del__(self):
+        h = getattr(self, 'handle', None)
+        if h:
+            try:
+                call('sba_replay_destroy', h)
+            except Exception:
+                pass
+            self.handle = None
+
+
 class GraphedStep(object):
     """GANStep replayed from captured hipGraphs: one graph for the generator forward, one PER
     DISCRIMINATOR update -- replayed concurrently, each on its own stream -- and one for the generator
@@ -580,8 +617,24 @@ class GraphedStep(object):
     or editing parameters run one eager `gan.step` (or rebuild the GraphedStep) before replaying again."""
 
     def __init__(self, gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, prologue=None,
-                 single=False):
+                 single=False, native=False, recorded_prologue=None):
+        """native: re-issue every phase with the native replayer (_NativeGraph) instead of hipGraphLaunch.  Random draws
+        cannot be recorded then (a captured Philox kernel reads an offset only torch's own graph replay advances):
+        `prologue` runs EAGERLY at the start of replay(), the conditioning noise eps is drawn eagerly into a static
+        tensor, and deterministic launches that belong in front of the step go to `recorded_prologue`."""
+        self.native = bool(native)
+        self._eager_prologue = None
+        self.eps = None
+        if self.native:
+            self._eager_prologue, prologue = prologue, recorded_prologue
+            self.eps = torch.empty((noise.shape[-2], cfg.GAN.CONDITION_DIM), dtype=torch.float32, device=gan.device)
+            self.eps.normal_(0, 1)
+        elif recorded_prologue is not None:
+            user = prologue
+            prologue = (lambda: (user() if user is not None else None, recorded_prologue()))
         self._capture(gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, prologue, single)
+        if self.native:
+            self._go_native()
         # the weight repacks issued during capture were recorded, not executed, yet the host-side change counters
         # now call the packed copies fresh: invalidate them so that an eager step after the capture repacks
         ops.weights_changed()
@@ -592,7 +645,9 @@ class GraphedStep(object):
         # per-phase graphs keep the ranking terms inside the generator-loss phase; the whole-step captures
         # (single=True, ReplayedStep) record the early branch
         early = gan.early_damsm
-        gan.early_damsm = early and single and not gan.distributed
+        # (native: phases replayed on different streams DO overlap -- the ranking terms get their own phase beside the
+        # discriminator updates, as in the whole-step captures, also in the data-parallel path)
+        gan.early_damsm = early and ((single and not gan.distributed) or self.native)
         try:
             self._capture_phases(gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, prologue, single)
         finally:
@@ -613,16 +668,22 @@ class GraphedStep(object):
                     prologue()
                 gan.step(imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise)
             torch.cuda.current_stream().wait_stream(stream)
-        eager_on(self.cap)                       # warm the capture stream (its split-K workspace)
+        if self.native and gan.early_damsm and not single:
+            gan._warm_e_stream = gan._e_stream()
+        try:
+            eager_on(self.cap)                   # warm the capture stream (its split-K workspace)
+        finally:
+            gan._warm_e_stream = None
         torch.cuda.synchronize()
         gan.finish()                             # (data-parallel: the warm-up step's generator update may be pending)
-        self.gA, self.gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        self.gD = [torch.cuda.CUDAGraph() for _ in range(nD)]
+        mk = self._mk
+        self.gA, self.gB = mk(), mk()
+        self.gD = [mk() for _ in range(nD)]
         self.gPre, self._pending = None, None
         if gan.distributed and gan.overlap_g:
             # the discriminators' forward passes on the real images: replayed BEFORE the generator's pending update
             # (and the prologue -- noise draw, frozen text encoder, trainer.py:248-252 -- which does not depend on it either)
-            self.gPre = torch.cuda.CUDAGraph()
+            self.gPre = mk()
             with torch.cuda.graph(self.gPre, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
                 if prologue is not None:
                     prologue()
@@ -632,16 +693,16 @@ class GraphedStep(object):
             with torch.cuda.graph(self.gA, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
                 if prologue is not None:
                     prologue()
-                self.out = gan.step(imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise)
+                self.out = gan.step(imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, eps=self.eps)
             torch.cuda.synchronize()
             return
         with torch.cuda.graph(self.gA, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
             if prologue is not None:
                 prologue()
-            gan.phase_a(sent_emb, words_embs, mask, noise)
+            gan.phase_a(sent_emb, words_embs, mask, noise, self.eps)
         self.gE = None
         if gan.early_damsm and not self.single:     # (kept for experiments: see _capture)
-            self.gE = torch.cuda.CUDAGraph()
+            self.gE = mk()
             self.estream = gan._e_stream()
             with torch.cuda.graph(self.gE, stream=self.estream, capture_error_mode=_CAPTURE_MODE):
                 gan.phase_e(sent_emb, words_embs, cap_lens, class_ids)
@@ -650,21 +711,23 @@ class GraphedStep(object):
             # backward and one for the Adam step, the all-reduce issued eagerly between them
             # (a bucketed discriminator: one graph down to the bucket boundary, one for the rest of its backward pass,
             # the tail bucket's all-reduce issued between them)
-            self.gDo = [torch.cuda.CUDAGraph() for _ in range(nD)]
+            self.gDo = [mk() for _ in range(nD)]
             self.gD2 = [None] * nD
-            self.gBo = torch.cuda.CUDAGraph()
+            self.gBo = mk()
             for i in range(nD):
                 with torch.cuda.graph(self.gD[i], stream=self.cap, capture_error_mode=_CAPTURE_MODE):
                     split = gan.phase_d_bwd_tail(i, imgs, sent_emb)
                     if not split:
                         gan.phase_d_bwd_join()
                 if split:
-                    self.gD2[i] = torch.cuda.CUDAGraph()
+                    self.gD2[i] = mk()
                     with torch.cuda.graph(self.gD2[i], stream=self.cap, capture_error_mode=_CAPTURE_MODE):
                         gan.phase_d_bwd_rest(i)
                         gan.phase_d_bwd_join()
                 with torch.cuda.graph(self.gDo[i], stream=self.cap, capture_error_mode=_CAPTURE_MODE):
                     gan.phase_d_opt(i)
+                    if gan.early_g_terms:       # its generator-loss term right behind the update (GANStep.phase_g_term)
+                        gan.phase_g_term(i, sent_emb)
             with torch.cuda.graph(self.gB, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
                 gan.phase_b_bwd(sent_emb, words_embs, cap_lens, class_ids)
             with torch.cuda.graph(self.gBo, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
@@ -674,9 +737,24 @@ class GraphedStep(object):
         for i in range(nD):
             with torch.cuda.graph(self.gD[i], stream=self.dstreams[i], capture_error_mode=_CAPTURE_MODE):
                 gan.phase_d(i, imgs, sent_emb, forked=False)
+                if gan.early_g_terms:
+                    gan.phase_g_term(i, sent_emb)
         with torch.cuda.graph(self.gB, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
             self.out = gan.phase_b(sent_emb, words_embs, cap_lens, class_ids)
         torch.cuda.synchronize()
+
+    def _mk(self):
+        return torch.cuda.CUDAGraph(keep_graph=True) if self.native else torch.cuda.CUDAGraph()
+
+    def _go_native(self):
+        """wrap every captured phase in a native replayer (same .replay() surface)"""
+        wrap = lambda g: None if g is None else _NativeGraph(g)
+        for name in ('gPre', 'gA', 'gB', 'gE', 'gBo'):
+            if getattr(self, name, None) is not None:
+                setattr(self, name, wrap(getattr(self, name)))
+        for name in ('gD', 'gD2', 'gDo'):
+            if getattr(self, name, None) is not None:
+                setattr(self, name, [wrap(g) for g in getattr(self, name)])
 
     def resync(self):
         """Bring the packed weight copies the graphs read in line with the f32 masters, eagerly.  Needed after
@@ -693,13 +771,36 @@ class GraphedStep(object):
         if self._pending is not None:
             h, self._pending = self._pending, None
             self.gan._allreduce_wait(h[0])
-            self.gBo.replay()
+            if self.native and not getattr(self, '_in_native', False):
+                cur = torch.cuda.current_stream()
+                self.cap.wait_stream(cur)
+                with torch.cuda.stream(self.cap):
+                    self.gBo.replay()
+                cur.wait_stream(self.cap)
+            else:
+                self.gBo.replay()
 
     def replay(self):
+        if self.native and not getattr(self, '_in_native', False):
+            # the phases' first chains run on the stream they are launched from: keep that off the NULL stream
+            cur = torch.cuda.current_stream()
+            self.cap.wait_stream(cur)
+            self._in_native = True
+            try:
+                with torch.cuda.stream(self.cap):
+                    out = self.replay()
+            finally:
+                self._in_native = False
+            cur.wait_stream(self.cap)
+            return out
         main = torch.cuda.current_stream()
         # the graphs repack the bf16 weight copies at the points where the capture did, without consulting the
         # host-side change counters; invalidate those so that an EAGER call after a replay repacks as well
         ops.weights_changed()
+        if self.native:
+            self.eps.normal_(0, 1)
+            if self._eager_prologue is not None:
+                self._eager_prologue()
         if self.gPre is not None:
             self.gPre.replay()      # netD_i(real_i): beside the generator's all-reduce of the previous replay
             self.finish()

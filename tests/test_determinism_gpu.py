@@ -119,6 +119,7 @@ def test_step_is_bit_reproducible_in_every_launch_mode(dev, det, encoder, dt):
         st.step(*args)
     whole = GraphedStep(st, *args, single=True)
     phases = GraphedStep(st, *args)
+    phases_native = GraphedStep(st, *args, native=True)      # the same per-phase captures through the native replayer
     rs = ReplayedStep(st, *args)
     rs.draw = False
     rs.eps.copy_(eps)
@@ -160,6 +161,9 @@ def test_step_is_bit_reproducible_in_every_launch_mode(dev, det, encoder, dt):
     for k in range(2):
         d = _diff(run(replay_of(phases)), l1, 'phases_' + tag)
         assert not d, ('per-phase hipGraphs, replay %d vs eager' % k, d[:8])
+    for k in range(2):      # (the natively replayed phases overlap for real, so they keep the early placement of the DAMSM terms)
+        d = _diff(run(replay_of(phases_native)), e1, 'phases_native_' + tag)
+        assert not d, ('per-phase captures through the native replayer, replay %d vs eager' % k, d[:8])
     # the two placements of the DAMSM terms give the same gradient by linearity, in a different summation order
     worst = max([r for _, r in _diff(e1, l1)] or [0.0])
     assert worst <= (2e-3 if dt == torch.float32 else 0.5), worst
