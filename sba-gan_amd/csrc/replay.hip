@@ -102,6 +102,10 @@ extern "C" int sba_replay_create(void* hip_graph, int max_streams, int flags, vo
     std::vector<char> stream_taken(n, 0);           // a successor already continues this node's stream
     std::vector<int> last_use(max_streams, -1);     // issue position of the last node each stream was given
     int used_streams = 0, undecodable = 0;
+    std::vector<int> load(max_streams, 0);
+    int rr = 0;
+    const char* pol = getenv("SBA_REPLAY_POLICY");
+    const int policy = pol ? atoi(pol) : 0;
     for (int u : order) {
         RNode r;
         memset(&r.kp, 0, sizeof(r.kp)); memset(&r.cp, 0, sizeof(r.cp)); memset(&r.ms, 0, sizeof(r.ms));
@@ -156,8 +160,15 @@ extern "C" int sba_replay_create(void* hip_graph, int max_streams, int flags, vo
             // a fork (or a root): the stream that has been quiet longest -- a finished branch's stream rather
             // than one a long chain is still being issued to
             s = 0;
-            for (int t = 1; t < max_streams; ++t) if (last_use[t] < last_use[s]) s = t;
+            if (policy == 1) {              // (A/B aid) the stream with the fewest nodes so far
+                for (int t = 1; t < max_streams; ++t) if (load[t] < load[s]) s = t;
+            } else if (policy == 2) {       // (A/B aid) round robin over the forks
+                s = (rr++) % max_streams;
+            } else {
+                for (int t = 1; t < max_streams; ++t) if (last_use[t] < last_use[s]) s = t;
+            }
         }
+        ++load[s];
         used_streams = std::max(used_streams, s + 1);
         stream_of[u] = s;
         r.stream = s;

@@ -511,7 +511,8 @@ SIDE_WGRAD = False
 HOME_STREAM = None       # raw handle of the stream whose companion join_wgrads() will join (set by the trainer at the start of
 #                          a backward pass): the dense layers use the companion only from there -- their backward may be
 #                          replayed on a side stream (the mapping network's), whose companion nobody would join
-_COMPANION, _KEEPALIVE = {}, {}
+_COMPANION, _KEEPALIVE, _COMP_NEXT = {}, {}, {}
+N_COMPANIONS = int(os.environ.get('SBA_WGRAD_COMPANIONS', '1'))      # companion streams per stream, used in turn
 
 
 def _companion(device, *keep):
@@ -519,10 +520,13 @@ def _companion(device, *keep):
     tensors the companion's launches read (held until the join)"""
     cur = torch.cuda.current_stream()
     key = cur.cuda_stream
-    comp = _COMPANION.get(key)
-    if comp is None:
-        comp = _COMPANION[key] = torch.cuda.Stream(device=device)
+    comps = _COMPANION.get(key)
+    if comps is None:
+        comps = _COMPANION[key] = [torch.cuda.Stream(device=device) for _ in range(N_COMPANIONS)]
         _KEEPALIVE[key] = []
+        _COMP_NEXT[key] = 0
+    comp = comps[_COMP_NEXT[key] % len(comps)]
+    _COMP_NEXT[key] += 1
     comp.wait_stream(cur)
     _KEEPALIVE[key].extend(keep)
     return comp
@@ -539,10 +543,12 @@ def conv_wgrad_overlapped(x, dy, param, kind):
 def join_wgrads():
     """Make the current stream wait for the weight gradients issued from it."""
     cur = torch.cuda.current_stream()
-    comp = _COMPANION.get(cur.cuda_stream)
-    if comp is not None:
-        cur.wait_stream(comp)
+    comps = _COMPANION.get(cur.cuda_stream)
+    if comps is not None:
+        for comp in comps:
+            cur.wait_stream(comp)
         _KEEPALIVE[cur.cuda_stream].clear()
+        _COMP_NEXT[cur.cuda_stream] = 0
 
 
 def wgrad_tail_stream():
@@ -553,11 +559,15 @@ def wgrad_tail_stream():
     trip, while one-way edges that only re-join the capture's origin stream are fine
     (tools/debug_nested.py)."""
     cur = torch.cuda.current_stream()
-    comp = _COMPANION.get(cur.cuda_stream)
-    if comp is None:
+    comps = _COMPANION.get(cur.cuda_stream)
+    if comps is None:
         return cur
+    comp = comps[0]
     comp.wait_stream(cur)
+    for other in comps[1:]:
+        comp.wait_stream(other)
     _KEEPALIVE[cur.cuda_stream].clear()
+    _COMP_NEXT[cur.cuda_stream] = 0
     return comp
 
 

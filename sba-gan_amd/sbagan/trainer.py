@@ -191,6 +191,7 @@ class GANStep(object):
         self._real_feats = [None] * len(netsD)
         self._g_terms = [None] * len(netsD)
         self._adam_early = [None] * len(netsD)
+        self._d_zeroed = [False] * len(netsD)
         self._forked_d = False
         self._g_pending = None
         self._d_buckets = {}
@@ -275,7 +276,10 @@ class GANStep(object):
         fake_imgs = self._ctx[0]
         netD = self.netsD[i]
         ops.SIDE_WGRAD = self.overlap_wgrad and self.overlap_wgrad_d
-        self.flatD[i].zero_grad()
+        if self._d_zeroed[i]:           # cleared at the start of the step, beside the generator's forward pass (step())
+            self._d_zeroed[i] = False
+        else:
+            self.flatD[i].zero_grad()
         rf = self._real_feats[i]
         self._real_feats[i] = None
         split = ((self.distributed and self.bucket_d) or self.force_overlap_layout or
@@ -456,6 +460,15 @@ class GANStep(object):
         main = torch.cuda.current_stream()
         nD = len(self.netsD)
         streams = self._d_streams()[:nD] if self.concurrent_d else [main] * nD
+        if self.early_zero and self.concurrent_d:
+            # the discriminators' gradient buffers (D_NET256: 287 MB, a 57 us fill at the head of the longest chain of the
+            # step) are cleared on their update streams NOW, beside the generator's forward pass
+            for i in range(nD):
+                if streams[i] is not main:
+                    streams[i].wait_stream(main)
+                    with torch.cuda.stream(streams[i]):
+                        self.flatD[i].zero_grad()
+                    self._d_zeroed[i] = True
         self.phase_pre(imgs, streams)         # (data-parallel: beside the generator's pending gradient exchange)
         self.finish()
         # discriminator i reads fake image i only: its update forks from the point where that image has been issued
@@ -520,6 +533,10 @@ class GANStep(object):
     #                                                                  against 11.29 ms -- the HBM-bound update competes with
     #                                                                  the trunk's weight gradients, and the split backward
     #                                                                  pass adds a graph boundary.  Off.
+    early_zero = os.environ.get('SBA_EARLY_ZERO', '0') == '1'      # clear the discriminators' gradients at the start of the step,
+    #                                                              beside the generator's forward pass.  Measured SLOWER (11.7
+    #                                                              against 11.0 ms): the earlier forks change the replayer's
+    #                                                              stream assignment.  Off.
     early_g_terms = os.environ.get('SBA_EARLY_G_TERMS', '1') == '1'      # each discriminator's generator-loss term right
     #                                                                  behind its own update (phase_g_term)
     early_damsm = True           # DAMSM terms + their image gradient beside the discriminator updates (phase_e)
