@@ -476,6 +476,200 @@ __global__ __launch_bounds__(AttnMma<T>::NW * 64) void word_attn_bwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// The backward on the matrix cores (bf16 activations, idf = 32: NEXT_STAGE_G of every stage), in the forward kernel's
+// formulation -- the QUERY axis is the MFMA's lane axis, nothing but the dsrc contraction touches LDS:
+//   S^T[l][q]  = sum_c src[c][l] h[q][c]        recomputed as in the forward (A = src^T hi + lo, B = h from HBM)
+//   dA^T[l][q] = sum_c src[c][l] dctx[q][c]     the SAME A operands, B = dctx (one 16-byte load per k-step)
+//   softmax and dS = a (dA - <a, dA>)           in-lane over the lane's 16 words + ONE exchange with lane ^ 32
+//   dh^T[c][q] = sum_l src[c][l] dS[q][l]       the forward's context contraction with dS in place of a (hi + lo)
+//   dsrc[c][l] += sum_q (h[q][c] dS[q][l] + dctx[q][c] a[q][l])   over the query axis: the wave's four [32 q][32] bf16
+//                                               tiles go to LDS and come back through ds_read_b64_tr_b16 (as before)
+// The VALU kernel above spends 3 x 32 x 32 FMAs per query on the vector pipe, each fed by an LDS read of src: 89 us at
+// 128 x 128 queries (0.7 TB/s); here 18 MFMAs per 32 queries.
+// ---------------------------------------------------------------------------
+template <int IDF>
+__global__ __launch_bounds__(256) void word_attn_bwd_mfma_kernel(
+    const bf16_t* __restrict__ h, const float* __restrict__ src, const uint8_t* __restrict__ mask,
+    const bf16_t* __restrict__ dctx, bf16_t* __restrict__ dh, float* __restrict__ dsrc, int B, int Q, int L,
+    int mask_mode, int dcs, int dco, int accumulate, int tiles_per_wave, float* __restrict__ det_part) {
+    static_assert(IDF == 32, "one 32-channel tile");
+    constexpr int KS = IDF / 16, NDEAD = 1024, TILE = 32 * 64;      // a [32 q][32] bf16 tile: 2 KB
+    __shared__ uint32_t s_dead[NDEAD];
+    __shared__ __attribute__((aligned(16))) unsigned char s_t[4 * 4 * TILE];     // per wave: h, dctx, dS, a
+    __shared__ float s_red[IDF * 32];
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ql = lane & 31, kg = lane >> 5;
+    const int nrows = mask_mode == 0 ? B : 1;
+    for (int i = tid; i < nrows && i < NDEAD; i += 256) s_dead[i] = dead_words(mask, mask_mode == 0 ? i : b, L);
+    const float* sb = src + (int64_t)b * IDF * L;
+    bf16x8_t st_hi[KS], st_lo[KS];          // score / dA contraction: row = word ql, k = channel 16 s + 8 kg + j
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        float v[8], lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = ql < L ? sb[(16 * s + 8 * kg + j) * L + ql] : 0.f;
+            lo[j] = v[j] - bf2f(f2bf(v[j]));
+        }
+        st_hi[s] = pack8_bf16(v);
+        st_lo[s] = pack8_bf16(lo);
+    }
+    bf16x8_t sc_hi[2], sc_lo[2];            // dh contraction: row = channel ql, k = word wmap(s, kg, j)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float v[8], lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int l = (j & 3) + 8 * (2 * s + (j >> 2)) + 4 * kg;
+            v[j] = l < L ? sb[ql * L + l] : 0.f;
+            lo[j] = v[j] - bf2f(f2bf(v[j]));
+        }
+        sc_hi[s] = pack8_bf16(v);
+        sc_lo[s] = pack8_bf16(lo);
+    }
+    __syncthreads();
+    unsigned char* XH = s_t + wid * 4 * TILE;
+    unsigned char* XD = XH + TILE;
+    unsigned char* YS = XD + TILE;
+    unsigned char* YA = YS + TILE;
+    f32x16_t wacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wacc[i] = 0.f;
+
+    const int tile0 = (blockIdx.x * 4 + wid) * tiles_per_wave;
+    for (int t = 0; t < tiles_per_wave; ++t) {
+        const int q0 = (tile0 + t) * 32;
+        if (q0 >= Q) break;                                   // (wave-uniform)
+        const int q = q0 + ql;
+        const bool live = q < Q;
+        const int64_t r = (int64_t)b * Q + (live ? q : 0);
+        bf16x8_t hb[KS], db[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            hb[s] = *reinterpret_cast<const bf16x8_t*>(h + r * IDF + 16 * s + 8 * kg);
+            db[s] = *reinterpret_cast<const bf16x8_t*>(dctx + r * dcs + dco + 16 * s + 8 * kg);
+            if (!live) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { hb[s][j] = 0; db[s][j] = 0; }
+            }
+        }
+        f32x16_t sa, da;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sa[i] = 0.f; da[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st_hi[s], hb[s], sa, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st_lo[s], hb[s], sa, 0, 0, 0);
+            da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st_hi[s], db[s], da, 0, 0, 0);
+            da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st_lo[s], db[s], da, 0, 0, 0);
+        }
+        // ---- softmax over the words (16 in this lane, 16 in lane ^ 32), then dS = a (dA - <a, dA>)
+        const int mrow = mask_mode == 0 ? (int)(r % B) : 0;
+        const uint32_t deadbits = (mask_mode == 0 && mrow >= NDEAD) ? dead_words(mask, mrow, L) : s_dead[mrow];
+        float a[16], ds[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int l = (i & 3) + 8 * (i >> 2) + 4 * kg;
+            a[i] = ((deadbits >> l) & 1u) ? -INFINITY : sa[i];
+            mx = fmaxf(mx, a[i]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a[i] = __expf(a[i] - mx); sum += a[i]; }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a[i] *= inv; dot += a[i] * da[i]; }
+        dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            ds[i] = live ? a[i] * (da[i] - dot) : 0.f;
+            if (!live) a[i] = 0.f;
+        }
+        // ---- dh
+        {
+            f32x16_t c;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) c[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float v[8], lo[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[j] = ds[8 * s + j]; lo[j] = v[j] - bf2f(f2bf(v[j])); }
+                const bf16x8_t ah = pack8_bf16(v), al = pack8_bf16(lo);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sc_hi[s], ah, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sc_hi[s], al, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sc_lo[s], ah, c, 0, 0, 0);
+            }
+            if (live) {
+                bf16_t* op = dh + r * IDF + 4 * kg;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {        // channels 8 g4 + 4 kg .. + 4
+                    float v[4] = {c[4 * g4], c[4 * g4 + 1], c[4 * g4 + 2], c[4 * g4 + 3]};
+                    if (accumulate) {
+                        const uint2 pr = *reinterpret_cast<const uint2*>(op + 8 * g4);
+                        v[0] += __uint_as_float(pr.x << 16); v[1] += __uint_as_float(pr.x & 0xffff0000u);
+                        v[2] += __uint_as_float(pr.y << 16); v[3] += __uint_as_float(pr.y & 0xffff0000u);
+                    }
+                    uint2 o;
+                    o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                    o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(op + 8 * g4) = o;
+                }
+            }
+        }
+        // ---- dsrc: rows of the four [32 q][32] tiles (a wave's LDS accesses complete in order: no barrier)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            *reinterpret_cast<bf16x8_t*>(XH + ql * 64 + (16 * s + 8 * kg) * 2) = hb[s];
+            *reinterpret_cast<bf16x8_t*>(XD + ql * 64 + (16 * s + 8 * kg) * 2) = db[s];
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {                // words 8 g4 + 4 kg .. + 4
+            uint2 o, p;
+            o.x = (uint32_t)f2bf(ds[4 * g4]) | ((uint32_t)f2bf(ds[4 * g4 + 1]) << 16);
+            o.y = (uint32_t)f2bf(ds[4 * g4 + 2]) | ((uint32_t)f2bf(ds[4 * g4 + 3]) << 16);
+            p.x = (uint32_t)f2bf(a[4 * g4]) | ((uint32_t)f2bf(a[4 * g4 + 1]) << 16);
+            p.y = (uint32_t)f2bf(a[4 * g4 + 2]) | ((uint32_t)f2bf(a[4 * g4 + 3]) << 16);
+            *reinterpret_cast<uint2*>(YS + ql * 64 + (8 * g4 + 4 * kg) * 2) = o;
+            *reinterpret_cast<uint2*>(YA + ql * 64 + (8 * g4 + 4 * kg) * 2) = p;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            wacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AttnMma<bf16_t>::frag(XH, ks, lane),
+                                                           AttnMma<bf16_t>::frag(YS, ks, lane), wacc, 0, 0, 0);
+            wacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AttnMma<bf16_t>::frag(XD, ks, lane),
+                                                           AttnMma<bf16_t>::frag(YA, ks, lane), wacc, 0, 0, 0);
+        }
+    }
+    // wacc: rows = channel (r&3)+8(r>>2)+4 kg, column = word ql; the waves' tiles are added in wave order
+#pragma unroll 1
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wid == wv) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = (i & 3) + 8 * (i >> 2) + 4 * kg;
+                float* qd = &s_red[c * 32 + ql];
+                *qd = wv == 0 ? wacc[i] : *qd + wacc[i];
+            }
+        }
+        __syncthreads();
+    }
+    if (det_part) {         // deterministic mode: this workgroup's own slot; sba_det_fold adds the slots in order
+        float* part = det_part + ((int64_t)b * gridDim.x + blockIdx.x) * IDF * L;
+        for (int o = tid; o < IDF * L; o += 256) part[o] = s_red[(o / L) * 32 + (o - (o / L) * L)];
+        return;
+    }
+    for (int o = tid; o < IDF * L; o += 256) {
+        const int c = o / L, l = o - c * L;
+        atomicAdd(&dsrc[((int64_t)b * IDF + c) * L + l], s_red[c * 32 + l]);
+    }
+}
+
 // SBA_ATTN_MFMA=0: the VALU kernel for bf16 as well (A/B aid)
 static int attn_mfma_enabled() {
     static int v = -1;
@@ -508,6 +702,20 @@ int launch_fwd(const void* h, const float* src, const uint8_t* mask, void* ctx, 
 template <typename T, int IDF>
 int launch_bwd(const void* h, const float* src, const uint8_t* mask, const void* dctx, void* dh, float* dsrc, int B,
                int Q, int L, int mode, int dcs, int dco, int acc, hipStream_t st) {
+    if (sizeof(T) == 2 && IDF == 32 && dcs % 8 == 0 && dco % 8 == 0 && attn_mfma_enabled()) {
+        const int tiles = cdiv(Q, 32);
+        const int tpw = tiles * B >= 16384 ? 4 : (tiles * B >= 4096 ? 2 : 1);
+        dim3 grid(cdiv(tiles, 4 * tpw), B);
+        float* part = nullptr;
+        if (sba_det_on()) {
+            part = sba_det_alloc((int64_t)B * grid.x * IDF * L);
+            if (!part) return SBA_E_ARG;
+        }
+        SBA_LAUNCH((word_attn_bwd_mfma_kernel<32>), grid, dim3(256), 0, st, (const bf16_t*)h, src, mask,
+                   (const bf16_t*)dctx, (bf16_t*)dh, dsrc, B, Q, L, mode, dcs, dco, acc, tpw, part);
+        if (part) sba_det_fold(part, B, (int)grid.x, (int64_t)IDF * L, dsrc, (int64_t)IDF * L, 0, st);
+        return SBA_CHECK_LAUNCH();
+    }
     constexpr int NT = AttnMma<T>::NW * 64;
     int chunks = Q >= 16384 ? 4 : (Q >= 4096 ? 2 : 1);           // NT-query chunks per workgroup
     dim3 grid(cdiv(Q, NT * chunks), B);

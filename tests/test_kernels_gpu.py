@@ -897,6 +897,44 @@ def test_attention_key_projection_fp8(dev):
     assert 0 < rel_l2(o8, o32) <= 1e-1, rel_l2(o8, o32)      # measured 5.9e-2 (the softmax sharpens the key error)
 
 
+@pytest.mark.parametrize('shape', [(3, 18, 12 * 12, 0, 0), (20, 18, 64 * 64, 0, 1), (5, 20, 1000, 1, 0), (2, 32, 33, 1, 1)])
+def test_word_attention_matrix_core_backward(dev, shape):
+    """The bf16 backward at idf = 32 (GlobalAttention.py:103-117 differentiated): scores and dA recomputed on the matrix
+    cores with hi + lo split keys, softmax backward in-lane, dh with hi + lo split dS, dsrc over the query axis through
+    LDS -- against torch autograd in f32 on the same bf16 inputs.  dh is a bf16 tensor (2^-9 per element); dsrc contracts
+    bf16-rounded dS / probabilities (as the VALU kernel does).  Ragged query counts, L up to 32, both mask modes, dctx
+    read from a channel slice, dh accumulated onto an existing gradient, several tiles per wave (20 x 4096 queries)."""
+    from sbagan._lib import call
+    B, L, Q, mode, accumulate = shape
+    idf = 32
+    g = torch.Generator().manual_seed(7)
+    h = torch.randn((B, Q, idf), generator=g).to(dev).bfloat16()
+    src = (torch.randn((B, idf, L), generator=g) * 0.5).to(dev)
+    mask = (torch.rand((B, L), generator=g) < 0.3).to(dev)
+    mask[:, 0] = False
+    m8 = mask.to(torch.uint8).contiguous()
+    dcs, dco = 2 * idf, idf
+    dfull = torch.randn((B, Q, dcs), generator=g).to(dev).bfloat16()
+    dctx = dfull[:, :, dco:dco + idf]
+    hf, sf = h.float().requires_grad_(True), src.clone().requires_grad_(True)
+    s = torch.bmm(hf, sf)
+    rows = torch.arange(B * Q, device=dev).view(B, Q)
+    mrow = (rows % B) if mode == 0 else torch.arange(B, device=dev).view(B, 1).expand(B, Q)
+    a = torch.softmax(s.masked_fill(mask[mrow], float('-inf')), 2)
+    ctx = torch.bmm(a, sf.transpose(1, 2))
+    gh, gs = torch.autograd.grad(ctx, [hf, sf], dctx.float())
+    prev = torch.randn((B, Q, idf), generator=g).to(dev).bfloat16()
+    dh = prev.clone() if accumulate else torch.empty_like(prev)
+    dsrc = torch.zeros((B, idf, L), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    call('sba_word_attn_bwd', 1, h.data_ptr(), src.data_ptr(), m8.data_ptr(), dfull.data_ptr(), dh.data_ptr(),
+         dsrc.data_ptr(), B, Q, idf, L, mode, dcs, dco, accumulate, st)
+    torch.cuda.synchronize()
+    want = gh + prev.float() if accumulate else gh
+    assert rel_l2(dh.float(), want) <= 4e-3, rel_l2(dh.float(), want)
+    assert rel_l2(dsrc, gs) <= 6e-3, rel_l2(dsrc, gs)
+
+
 @pytest.mark.parametrize('shape', [(3, 32, 7, 12 * 12, 0), (20, 32, 18, 64 * 64, 0), (5, 64, 20, 1000, 1), (2, 32, 32, 33, 1)])
 def test_word_attention_matrix_core_forward(dev, shape):
     """The bf16 forward runs both contractions (GlobalAttention.py:103,117) on v_mfma_f32_32x32x16_bf16 with the keys
