@@ -399,6 +399,25 @@ class GANStep(object):
         self.flatG.zero_grad()
         damsm = getattr(self, '_damsm', None) if self.early_damsm else None
         d_terms = self._g_terms if all(t is not None for t in self._g_terms) else None
+        if d_terms is not None and damsm is not None:
+            # every term but the KL one was evaluated ahead of time, gradients and all: the backward pass starts from the
+            # image gradients and the KL term at once; errG_total -- a VALUE now, summed in the reference's order from the
+            # same numbers -- is put together behind it (seven scalar launches off the head of the critical chain)
+            kl = KL_loss(mu, logvar)
+            grads = [t[1] for t in d_terms]
+            if not torch.cuda.is_current_stream_capturing():
+                for g in grads:             # produced on the discriminators' streams, consumed on this one
+                    g.record_stream(torch.cuda.current_stream())
+            grads[-1] = grads[-1] + damsm[2]
+            mark('g_loss_forward')
+            backward_with_image_grads(kl, fake_imgs, grads)
+            errG_total, logs = generator_loss(self.netsD, self.image_encoder, fake_imgs, self.real_labels, words_embs,
+                                              sent_emb, self.match_labels, cap_lens, class_ids, damsm=damsm,
+                                              d_terms=[t[0] for t in d_terms])
+            errG_total = errG_total + kl.detach()
+            self._damsm = None
+            self._g_terms = [None] * len(self.netsD)
+            return self._phase_b_bwd_end(errG_total, kl, logs, fake_imgs)
         errG_total, logs = generator_loss(self.netsD, self.image_encoder, fake_imgs, self.real_labels, words_embs,
                                           sent_emb, self.match_labels, cap_lens, class_ids,
                                           streams=self._d_streams() if self.concurrent_d else None, damsm=damsm,
@@ -422,8 +441,11 @@ class GANStep(object):
         else:
             errG_total.backward()
         self._g_terms = [None] * len(self.netsD)
+        return self._phase_b_bwd_end(errG_total, kl, logs, fake_imgs)
+
+    def _phase_b_bwd_end(self, errG_total, kl, logs, fake_imgs):
         ops.join_wgrads()
-        mark('g_backward')
+        self._mark('g_backward')
         for p in self._d_params:
             p.requires_grad_(True)
         out = self._out
