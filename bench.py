@@ -475,7 +475,20 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / n
 
-    if args.graph:
+    dp_replay = multi and os.environ.get('SBA_DP_REPLAY', '0') == '1'
+    if args.graph and dp_replay:
+        # opt-in data-parallel launch mode (sbagan.trainer.ReplayedStepDP): three recordings through the native replayer
+        # with the gradient exchange between them; every rank takes it (same environment), nothing else is probed
+        from sbagan.trainer import ReplayedStepDP
+        a = (b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'], b['class_ids'], noise)
+        graph = ReplayedStepDP(step, *a, recorded_prologue=encode,
+                               max_streams=int(os.environ.get('SBA_REPLAY_STREAMS', '4')))
+        for _ in range(2):
+            graph.replay()
+        torch.cuda.synchronize()
+        mode, out = 'replayer-dp', graph.out
+        sys.stderr.write('launch probe (ms per step): replayer-dp %.2f\n' % (probe(graph.replay) * 1e3))
+    elif args.graph:
         cands = {}
         a = (b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'], b['class_ids'], noise)
         if args.graph in (1, 2):

@@ -622,11 +622,11 @@ class _NativeGraph(object):
     runs on the CALLER's stream (phase graphs are single chains apart from the weight-gradient companion), so phases
     replayed on different streams really overlap -- hipGraph launches on different streams do not, on ROCm 7.2."""
 
-    def __init__(self, graph, max_streams=2):
+    def __init__(self, graph, max_streams=2, flags=2):
         self.graph = graph                       # keeps the hipGraph (and the kernel arguments in its nodes) alive
         self.handle = ctypes.c_void_p()
         from ._lib import lib
-        rc = lib.sba_replay_create(ctypes.c_void_p(int(graph.raw_cuda_graph())), int(max_streams), 2,
+        rc = lib.sba_replay_create(ctypes.c_void_p(int(graph.raw_cuda_graph())), int(max_streams), int(flags),
                                    ctypes.byref(self.handle))      # flags = 2: the first chain on the caller's stream
         if rc != 0:
             raise RuntimeError('sba_replay_create failed (%d)' % rc)
@@ -974,3 +974,132 @@ class ReplayedStep(object):
             except Exception:
                 pass
             self.handle = None
+
+
+class ReplayedStepDP(object):
+    """The DATA-PARALLEL step from three recordings re-issued by the native replayer, the gradient exchange between them:
+
+        R1  generator forward | the three discriminators' loss + backward passes, each on its own stream, forked where
+            its fake image is issued | the image encoder + DAMSM terms beside them
+        --  all-reduce of the three discriminators' flat gradient buffers (RCCL, eager, largest first)
+        R2  every discriminator's Adam step and its generator-loss term on its own stream | the generator's backward pass
+        --  all-reduce of the generator's gradients
+        R3  the generator's Adam + EMA step
+
+    GraphedStep's per-phase hipGraphs keep every RCCL call exactly where the eager data-parallel step has it (buckets
+    under the backward passes, the generator's exchange under the next step's prologue) but hipGraph launches do not overlap
+    each other on ROCm 7.2, so its phases run back to back: 15.5 ms with one rank against 11.1 ms for the single-GPU
+    replayer.  Here the phases overlap inside a recording as they do on one GPU and the price is an EXPOSED exchange of
+    the discriminators' gradients (382 MB) between R1 and R2.  One grouped real|fake pass and one bucket per discriminator
+    (`overlap_g` / `bucket_d` are switched off on the GANStep).  Opt-in (bench.py: SBA_DP_REPLAY=1): never run on more than
+    one GPU -- no multi-GPU node was available in rounds 1-3."""
+
+    def __init__(self, gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, prologue=None,
+                 recorded_prologue=None, max_streams=4):
+        if not gan.distributed:
+            raise RuntimeError('ReplayedStepDP is the data-parallel launch mode; use ReplayedStep on one GPU')
+        gan.finish()
+        gan.overlap_g = False
+        gan.bucket_d = False
+        self.gan, self.noise, self.prologue = gan, noise, prologue
+        dev = gan.device
+        self.eps = torch.empty((noise.shape[-2], cfg.GAN.CONDITION_DIM), dtype=torch.float32, device=dev)
+        self.cap = torch.cuda.Stream(device=dev)
+        self.draw = True
+        nD = len(gan.netsD)
+        streams = gan._d_streams()[:nD]
+        self.cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.cap):                   # warm the capture stream (workspaces, packed weights)
+            self._draw()
+            if recorded_prologue is not None:
+                recorded_prologue()
+            gan.step(imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, eps=self.eps)
+        torch.cuda.current_stream().wait_stream(self.cap)
+        torch.cuda.synchronize()
+
+        def seg1():
+            if recorded_prologue is not None:
+                recorded_prologue()
+            main = torch.cuda.current_stream()
+            ready = [None] * nD
+            if gan.early_d:
+                def on_image(i):
+                    if i < nD - 1:
+                        ready[i] = torch.cuda.Event()
+                        ready[i].record()
+                gan.netG.on_image = on_image
+            try:
+                gan.phase_a(sent_emb, words_embs, mask, noise, self.eps)
+            finally:
+                gan.netG.on_image = None
+            for i in range(nD):
+                st = streams[i]
+                if ready[i] is not None:
+                    st.wait_event(ready[i])
+                else:
+                    st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    if gan.phase_d_bwd_tail(i, imgs, sent_emb):
+                        gan.phase_d_bwd_rest(i)
+                    gan.phase_d_bwd_join()
+            if gan.early_damsm:
+                gan.phase_e(sent_emb, words_embs, cap_lens, class_ids)
+            for st in streams:
+                main.wait_stream(st)
+
+        def seg2():
+            main = torch.cuda.current_stream()
+            for i in range(nD):
+                st = streams[i]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    gan.phase_d_opt(i)
+                    if gan.early_g_terms:
+                        gan.phase_g_term(i, sent_emb)
+            for st in streams:
+                main.wait_stream(st)
+            gan.phase_b_bwd(sent_emb, words_embs, cap_lens, class_ids)
+
+        def seg3():
+            self.out = gan.phase_b_opt()
+
+        self.graphs, self.replayers = [], []
+        for fn, ns in ((seg1, max_streams), (seg2, max_streams), (seg3, 1)):
+            g = torch.cuda.CUDAGraph(keep_graph=True)
+            with torch.cuda.graph(g, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
+                fn()
+            torch.cuda.synchronize()
+            self.graphs.append(g)
+            self.replayers.append(_NativeGraph(g, max_streams=ns, flags=0))
+        ops.weights_changed()
+
+    def _draw(self):
+        if self.draw:
+            self.noise.normal_(0, 1)
+            self.eps.normal_(0, 1)
+        if self.prologue is not None:
+            self.prologue()
+
+    def resync(self):
+        GraphedStep.resync(self)
+
+    def finish(self):
+        pass                    # (the generator's update is applied inside replay(): nothing is deferred)
+
+    def replay(self):
+        gan = self.gan
+        ops.weights_changed()
+        self._draw()
+        cur = torch.cuda.current_stream()
+        self.cap.wait_stream(cur)
+        with torch.cuda.stream(self.cap):
+            self.replayers[0].replay()
+            order = sorted(range(len(gan.flatD)), key=lambda i: -gan.flatD[i].n)       # same order on every rank
+            handles = [gan.exchange.start(gan.flatD[i].grad) for i in order]
+            for h in handles:
+                gan._allreduce_wait(h)
+            self.replayers[1].replay()
+            gan._allreduce_wait(gan._allreduce_start(gan.flatG))
+            self.replayers[2].replay()
+        cur.wait_stream(self.cap)
+        return self.out

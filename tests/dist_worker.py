@@ -207,6 +207,35 @@ def main():
     bad_out = [(k, got_out[k], want_out[k]) for k in want_out if got_out[k] != want_out[k]]
     expect(not bad and not bad_out, 'hipGraph replay of the data-parallel step differs from the eager data-parallel step '
            'in %d tensors: %r; losses %r' % (len(bad), bad[:12], bad_out[:6]))
+    # ---- the data-parallel step from three native recordings with the exchange between them (ReplayedStepDP: one grouped
+    # pass and one bucket per discriminator, nothing deferred): two replays must leave every parameter, Adam moment and
+    # BatchNorm buffer bit-identical to two eager data-parallel steps with the same decomposition
+    from sbagan.trainer import ReplayedStepDP
+    dp.restore(snap_dp)
+    graph.resync()
+    dp.overlap_g = dp.bucket_d = False
+    for _ in range(2):
+        eager_out = dp.step(*gargs)
+    dp.finish()
+    torch.cuda.synchronize()
+    want = [t.clone() for t in state()]
+    want_out = {k: float(v) for k, v in eager_out.items()}
+    noise_keep = noise_in.clone()
+    rdp = ReplayedStepDP(dp, *gargs)        # (its warm-up step draws fresh noise into the static tensor)
+    rdp.draw = False
+    rdp.eps.copy_(eps)
+    noise_in.copy_(noise_keep)
+    dp.restore(snap_dp)
+    rdp.resync()
+    for _ in range(2):
+        rdp.replay()
+    torch.cuda.synchronize()
+    got = state()
+    bad = [(names[i], rel_l2(a.float(), b.float())) for i, (a, b) in enumerate(zip(got, want)) if not torch.equal(a, b)]
+    got_out = {k: float(v) for k, v in rdp.out.items()}
+    bad_out = [(k, got_out[k], want_out[k]) for k in want_out if got_out[k] != want_out[k]]
+    expect(not bad and not bad_out, 'ReplayedStepDP differs from the eager data-parallel step in %d tensors: %r; losses %r'
+           % (len(bad), bad[:12], bad_out[:6]))
     # generator: its local gradient is taken against the UPDATED (replica-identical) discriminators, so it
     # differs from the single-process run, whose discriminators moved by the local gradient only
     expect(bool(torch.isfinite(out_dp['errG_total'])), 'errG_total not finite')
