@@ -475,14 +475,15 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / n
 
-    dp_replay = multi and os.environ.get('SBA_DP_REPLAY', '0') == '1'
+    dp_replay = multi and os.environ.get('SBA_DP_REPLAY', '0') in ('1', '2')
     if args.graph and dp_replay:
         # opt-in data-parallel launch mode (sbagan.trainer.ReplayedStepDP): three recordings through the native replayer
         # with the gradient exchange between them; every rank takes it (same environment), nothing else is probed
         from sbagan.trainer import ReplayedStepDP
         a = (b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'], b['class_ids'], noise)
         graph = ReplayedStepDP(step, *a, recorded_prologue=encode,
-                               max_streams=int(os.environ.get('SBA_REPLAY_STREAMS', '4')))
+                               max_streams=int(os.environ.get('SBA_REPLAY_STREAMS', '4')),
+                               e_beside_exchange=os.environ.get('SBA_DP_REPLAY') == '2')
         for _ in range(2):
             graph.replay()
         torch.cuda.synchronize()

@@ -995,9 +995,14 @@ class ReplayedStepDP(object):
     one GPU -- no multi-GPU node was available in rounds 1-3."""
 
     def __init__(self, gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, prologue=None,
-                 recorded_prologue=None, max_streams=4):
+                 recorded_prologue=None, max_streams=4, e_beside_exchange=False):
+        """e_beside_exchange: the image encoder + DAMSM terms as a recording of their own, launched AFTER the
+        discriminators' all-reduces have been started -- they run while the exchange is in flight (hides up to their
+        3.3 ms of it) instead of beside the discriminators' backward passes (one rank: 13.5 against 12.1 ms; pays
+        once the exposed exchange exceeds ~1.4 ms)."""
         if not gan.distributed:
             raise RuntimeError('ReplayedStepDP is the data-parallel launch mode; use ReplayedStep on one GPU')
+        self.e_beside_exchange = bool(e_beside_exchange) and gan.early_damsm
         gan.finish()
         gan.overlap_g = False
         gan.bucket_d = False
@@ -1042,10 +1047,13 @@ class ReplayedStepDP(object):
                     if gan.phase_d_bwd_tail(i, imgs, sent_emb):
                         gan.phase_d_bwd_rest(i)
                     gan.phase_d_bwd_join()
-            if gan.early_damsm:
+            if gan.early_damsm and not self.e_beside_exchange:
                 gan.phase_e(sent_emb, words_embs, cap_lens, class_ids)
             for st in streams:
                 main.wait_stream(st)
+
+        def seg_e():
+            gan.phase_e(sent_emb, words_embs, cap_lens, class_ids)
 
         def seg2():
             main = torch.cuda.current_stream()
@@ -1064,7 +1072,10 @@ class ReplayedStepDP(object):
             self.out = gan.phase_b_opt()
 
         self.graphs, self.replayers = [], []
-        for fn, ns in ((seg1, max_streams), (seg2, max_streams), (seg3, 1)):
+        segs = [(seg1, max_streams), (seg2, max_streams), (seg3, 1)]
+        if self.e_beside_exchange:
+            segs.insert(1, (seg_e, 2))
+        for fn, ns in segs:
             g = torch.cuda.CUDAGraph(keep_graph=True)
             with torch.cuda.graph(g, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
                 fn()
@@ -1093,13 +1104,16 @@ class ReplayedStepDP(object):
         cur = torch.cuda.current_stream()
         self.cap.wait_stream(cur)
         with torch.cuda.stream(self.cap):
-            self.replayers[0].replay()
+            reps = list(self.replayers)
+            reps.pop(0).replay()
             order = sorted(range(len(gan.flatD)), key=lambda i: -gan.flatD[i].n)       # same order on every rank
             handles = [gan.exchange.start(gan.flatD[i].grad) for i in order]
+            if self.e_beside_exchange:
+                reps.pop(0).replay()        # image encoder + DAMSM terms, while the exchange is in flight
             for h in handles:
                 gan._allreduce_wait(h)
-            self.replayers[1].replay()
+            reps.pop(0).replay()
             gan._allreduce_wait(gan._allreduce_start(gan.flatG))
-            self.replayers[2].replay()
+            reps.pop(0).replay()
         cur.wait_stream(self.cap)
         return self.out

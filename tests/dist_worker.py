@@ -236,6 +236,20 @@ def main():
     bad_out = [(k, got_out[k], want_out[k]) for k in want_out if got_out[k] != want_out[k]]
     expect(not bad and not bad_out, 'ReplayedStepDP differs from the eager data-parallel step in %d tensors: %r; losses %r'
            % (len(bad), bad[:12], bad_out[:6]))
+    # ... and with the image encoder + DAMSM terms recorded on their own, launched while the exchange is in flight
+    rdp2 = ReplayedStepDP(dp, *gargs, e_beside_exchange=True)
+    rdp2.draw = False
+    rdp2.eps.copy_(eps)
+    noise_in.copy_(noise_keep)
+    dp.restore(snap_dp)
+    rdp2.resync()
+    for _ in range(2):
+        rdp2.replay()
+    torch.cuda.synchronize()
+    got = state()
+    bad = [(names[i], rel_l2(a.float(), b.float())) for i, (a, b) in enumerate(zip(got, want)) if not torch.equal(a, b)]
+    expect(not bad, 'ReplayedStepDP(e_beside_exchange) differs from the eager data-parallel step in %d tensors: %r'
+           % (len(bad), bad[:12]))
     # generator: its local gradient is taken against the UPDATED (replica-identical) discriminators, so it
     # differs from the single-process run, whose discriminators moved by the local gradient only
     expect(bool(torch.isfinite(out_dp['errG_total'])), 'errG_total not finite')
