@@ -475,20 +475,37 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / n
 
-    dp_replay = multi and os.environ.get('SBA_DP_REPLAY', '0') in ('1', '2')
-    if args.graph and dp_replay:
-        # opt-in data-parallel launch mode (sbagan.trainer.ReplayedStepDP): three recordings through the native replayer
-        # with the gradient exchange between them; every rank takes it (same environment), nothing else is probed
-        from sbagan.trainer import ReplayedStepDP
+    # Data-parallel launch mode (N > 1): sbagan.trainer.ReplayedStepDP -- three recordings through the native replayer with the
+    # gradient exchange between them.  SBA_DP_REPLAY: 2 (default) = image encoder + DAMSM terms
+    # launched while the discriminators' all-reduces are in flight; 1 = beside the discriminators' backward passes (the
+    # exchange fully exposed); 0 = the per-phase hipGraphs (GraphedStep).  Every rank reads the same environment; a rank
+    # whose capture fails makes ALL ranks fall back to the per-phase graphs.
+    dp_mode = os.environ.get('SBA_DP_REPLAY', '2')
+    dp_graph = None
+    if args.graph and multi and dp_mode in ('1', '2'):
+        flags = (step.overlap_g, step.bucket_d)
         a = (b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'], b['class_ids'], noise)
-        graph = ReplayedStepDP(step, *a, recorded_prologue=encode,
-                               max_streams=int(os.environ.get('SBA_REPLAY_STREAMS', '4')),
-                               e_beside_exchange=os.environ.get('SBA_DP_REPLAY') == '2')
+        try:
+            from sbagan.trainer import ReplayedStepDP
+            dp_graph = ReplayedStepDP(step, *a, recorded_prologue=encode,
+                                      max_streams=int(os.environ.get('SBA_REPLAY_STREAMS', '4')),
+                                      e_beside_exchange=dp_mode == '2')
+        except Exception as e:
+            sys.stderr.write('data-parallel launch replayer unavailable (%s: %s)\n' % (type(e).__name__, e))
+            dp_graph = None
+            torch.cuda.synchronize()
+        ok = torch.tensor([1 if dp_graph is not None else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok) == 0:
+            dp_graph = None
+            step.overlap_g, step.bucket_d = flags
+    if dp_graph is not None:
+        graph = dp_graph
         for _ in range(2):
             graph.replay()
         torch.cuda.synchronize()
-        mode, out = 'replayer-dp', graph.out
-        sys.stderr.write('launch probe (ms per step): replayer-dp %.2f\n' % (probe(graph.replay) * 1e3))
+        mode, out = 'replayer-dp%s' % dp_mode, graph.out
+        sys.stderr.write('launch probe (ms per step): %s %.2f\n' % (mode, probe(graph.replay) * 1e3))
     elif args.graph:
         cands = {}
         a = (b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'], b['class_ids'], noise)
