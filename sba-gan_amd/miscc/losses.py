@@ -54,6 +54,7 @@ class LossLogs(dict):
 _MASK_CACHE = {}
 BATCH_REAL_FAKE = True
 FUSED_HEADS = os.environ.get('SBA_FUSED_HEADS', '1') != '0'   # ops.DHeadsFn: one autograd node per discriminator term
+DIRECT_DAMSM = os.environ.get('SBA_DIRECT_DAMSM', '1') != '0'  # damsm_image_terms: loss heads + gradients without autograd
 
 
 def class_mask(class_ids, batch_size, device):
@@ -161,6 +162,17 @@ def damsm_image_terms(image_encoder, fake_img, words_embs, sent_emb, match_label
     batch_size = fake_img.size(0)
     leaf = fake_img.detach().requires_grad_(True)
     region_features, cnn_code = image_encoder(leaf)
+    if DIRECT_DAMSM and match_labels is not None and region_features.is_cuda:
+        # the loss heads and their gradients as ten back-to-back launches (ops.damsm_terms_direct), then ONLY the encoder's
+        # backward pass through autograd -- bit-identical to the Function path below
+        s = cfg.TRAIN.SMOOTH
+        mask = class_mask(class_ids, batch_size, region_features.device)
+        w_loss, s_loss, dfeat, dcnn = ops.damsm_terms_direct(
+            region_features, cnn_code, words_embs, sent_emb, cap_lens, mask,
+            (float(s.GAMMA1), float(s.GAMMA2), float(s.GAMMA3)), float(s.LAMBDA))
+        (grad,) = torch.autograd.grad([region_features, cnn_code],
+                                      leaf, [dfeat.to(region_features.dtype), dcnn.to(cnn_code.dtype)])
+        return w_loss, s_loss, grad
     w_loss0, w_loss1, _ = words_loss(region_features, words_embs, match_labels, cap_lens, class_ids, batch_size)
     w_loss = (w_loss0 + w_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
     s_loss0, s_loss1 = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size)

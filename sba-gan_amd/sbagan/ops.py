@@ -1500,6 +1500,61 @@ class SentLossFn(torch.autograd.Function):
         return dcnn, drnn, None, None, None
 
 
+_LAMBDA_CELL = {}
+
+
+def damsm_terms_direct(region_features, cnn_code, words_embs, sent_emb, cap_lens, mask, gammas, lam, eps=1e-8):
+    """w_loss = LAMBDA (loss0 + loss1) of words_loss, s_loss likewise of sent_loss (losses.py:187-204), TOGETHER WITH
+    their gradients w.r.t. the image-side inputs (region features, global code) -- the kernels of WordsLossFn / SentLossFn
+    called back to back, no autograd in between.  For a frozen text side the upstream gradient of the four cross-entropy
+    terms is the constant LAMBDA, so the ~20 scalar launches autograd issues around the two Functions (adds, the LAMBDA
+    multiplications and their backward, ones / zeros fills) -- half a millisecond of launch gaps on the image encoder's
+    chain, the critical one of the step -- reduce to two `combine2` launches; the loss VALUES are put together after the
+    gradient kernels have been issued.  Same kernels, same operands: bit-identical to the autograd path.
+    Returns (w_loss, s_loss, d region_features, d cnn_code)."""
+    g1, g2, g3 = gammas
+    feat = region_features.detach().float().contiguous()
+    cnn = cnn_code.detach().float().contiguous()
+    words = words_embs.detach().float().contiguous()
+    rnn = sent_emb.detach().float().contiguous()
+    B, nef = feat.shape[0], feat.shape[1]
+    R = feat.shape[2] * feat.shape[3]
+    L = words.shape[2]
+    dev = feat.device
+    cap_lens = cap_lens.to(device=dev, dtype=torch.int64).contiguous()
+    key = (dev, float(lam))
+    lamt = _LAMBDA_CELL.get(key)
+    if lamt is None:
+        lamt = _LAMBDA_CELL[key] = torch.full((1,), float(lam), dtype=torch.float32, device=dev)
+    st = _stream()
+    sim = torch.empty((B, B), dtype=torch.float32, device=dev)
+    attn = torch.empty((B * B, L, R), dtype=torch.float32, device=dev)
+    attn1 = torch.empty((B * B, L, R), dtype=torch.float32, device=dev)
+    wctx = torch.empty((B * B, L, nef), dtype=torch.float32, device=dev)
+    call('sba_damsm_words_fwd', _p(feat), _p(words), _p(cap_lens), _p(sim), _p(attn), _p(attn1), _p(wctx), B, nef, R, L,
+         g1, g2, st)
+    wl = torch.empty(2, dtype=torch.float32, device=dev)
+    d0, d1 = torch.empty_like(sim), torch.empty_like(sim)
+    call('sba_ce_pair', _p(sim), _p(mask), g3, _p(wl), _p(d0), _p(d1), B, st)
+    dsim = torch.empty_like(sim)
+    call('sba_combine2', _p(dsim), _p(d0), _p(lamt), _p(d1), _p(lamt), B * B, st)
+    dfeat = torch.zeros_like(feat)
+    call('sba_damsm_words_bwd', _p(feat), _p(words), _p(cap_lens), _p(sim), _p(attn), _p(attn1), _p(wctx), _p(dsim),
+         _p(dfeat), None, B, nef, R, L, g1, g2, st)
+    s = torch.empty((B, B), dtype=torch.float32, device=dev)
+    call('sba_damsm_sent_fwd', _p(cnn), _p(rnn), _p(s), B, nef, g3, eps, st)
+    sl = torch.empty(2, dtype=torch.float32, device=dev)
+    e0, e1 = torch.empty_like(s), torch.empty_like(s)
+    call('sba_ce_pair', _p(s), _p(mask), 1.0, _p(sl), _p(e0), _p(e1), B, st)
+    ds = torch.empty_like(s)
+    call('sba_combine2', _p(ds), _p(e0), _p(lamt), _p(e1), _p(lamt), B * B, st)
+    dcnn = torch.zeros_like(cnn)
+    call('sba_damsm_sent_bwd', _p(cnn), _p(rnn), _p(ds), _p(dcnn), None, B, nef, g3, eps, st)
+    w_loss = (wl[0] + wl[1]) * lam          # (values only: behind the gradient kernels)
+    s_loss = (sl[0] + sl[1]) * lam
+    return w_loss, s_loss, dfeat, dcnn
+
+
 # ----------------------------------------------------------------------------
 # text encoder (SURVEY.md 8f-2)
 def lstm_bidir_forward(captions, cap_lens, emb_weight, w_ih, w_hh, b_ih, b_hh, hidden=None, max_len=None, out=None):

@@ -178,7 +178,8 @@ def test_dependency_relaxations_do_not_change_a_bit(dev, det, encoder, dt):
     forked from the point their fake image is issued, MAPPING_NET on a side stream) only reorder launches: one step from
     the same state with all of them OFF -- the reference's order, trainer.py:261-299 -- and with all of them ON must
     agree bit for bit in every loss, gradient, parameter, Adam-updated weight, EMA value, BatchNorm buffer and image;
-    so must the Adam update issued in two pieces (FusedAdam.step_range) and the bucketed discriminator update."""
+    so must the Adam update issued in two pieces (FusedAdam.step_range), the bucketed discriminator update, and the DAMSM
+    loss heads called directly (ops.damsm_terms_direct) instead of through their autograd Functions."""
     from sbagan import nets, ops
     from sbagan.synth import synthetic_batch
     ops.set_compute_dtype(dt)
@@ -199,11 +200,14 @@ def test_dependency_relaxations_do_not_change_a_bit(dev, det, encoder, dt):
     torch.cuda.synchronize()
     snap = st.snapshot()
 
-    def run(relaxed, bucket=False):
+    from miscc import losses
+
+    def run(relaxed, bucket=False, direct=True):
         st.restore(snap)
         st.early_g_terms = st.early_d = relaxed
         st.bucket_adam = bucket
         nets._GBase.fork_mapping = relaxed
+        losses.DIRECT_DAMSM = direct
         try:
             out = st.step(*args)
             torch.cuda.synchronize()
@@ -212,9 +216,10 @@ def test_dependency_relaxations_do_not_change_a_bit(dev, det, encoder, dt):
             st.early_g_terms = st.early_d = True
             st.bucket_adam = False
             nets._GBase.fork_mapping = True
+            losses.DIRECT_DAMSM = True
 
     tag = '%s_%s' % (encoder, str(dt).split('.')[-1])
-    ref = run(False)
+    ref = run(False, direct=False)      # the DAMSM terms through WordsLossFn / SentLossFn and autograd, too
     d = _diff(run(True), ref, 'relaxed_' + tag)
     assert not d, ('relaxed dependencies vs the reference order', d[:8])
     d = _diff(run(True, bucket=True), ref, 'bucket_adam_' + tag)
