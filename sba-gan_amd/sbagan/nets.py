@@ -359,8 +359,12 @@ class _GBase(nn.Module):
     # The style codes w = MAPPING_NET(z) are first read by stage 2 (AdaIN): the mapping network -- a chain of 6 / 8 dense
     # layers of ~13 us each, pure latency -- runs on a side stream beside CA_NET and the whole first stage, and autograd
     # replays its backward pass (another ~160 us chain) on that stream too, beside the first stage's backward pass
-    # instead of at the very end of the generator's.  Same kernels, same operands: results are unchanged.
-    fork_mapping = os.environ.get('SBA_FORK_MAPPING', '1') == '1'
+    # instead of at the very end of the generator's.  Same kernels, same operands -- worth 0.2 ms of the 11 ms step -- but
+    # OFF by default: with two mapping calls (G_NET_MIX) `tools/stress_generator_test.py` shows a RACE in eager mode, 4 of
+    # 30 runs with one wrong weight gradient (h_net2.adain2.style.weight, the same wrong value every time), 0 of 30 without
+    # the fork; the mechanism (autograd replaying the mapping network's backward on the side stream while the main
+    # stream's allocator reuses a block) is not pinned down, so no variant gets the fork until it is.
+    fork_mapping = os.environ.get('SBA_FORK_MAPPING', '0') == '1'
     on_image = None          # callable(i): called right after fake image i has been issued (the trainer forks the
     #                          update of discriminator i from that point instead of from the end of the forward pass)
 

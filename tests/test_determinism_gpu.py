@@ -175,7 +175,7 @@ def test_step_is_bit_reproducible_in_every_launch_mode(dev, det, encoder, dt):
 def test_dependency_relaxations_do_not_change_a_bit(dev, det, encoder, dt):
     """The step's fine-grained dependencies (every discriminator's generator-loss term right behind
     its own update with the image gradients handed to the generator's single backward pass, the 64 / 128 px updates
-    forked from the point their fake image is issued, MAPPING_NET on a side stream) only reorder launches: one step from
+    forked from the point their fake image is issued) only reorder launches: one step from
     the same state with all of them OFF -- the reference's order, trainer.py:261-299 -- and with all of them ON must
     agree bit for bit in every loss, gradient, parameter, Adam-updated weight, EMA value, BatchNorm buffer and image;
     so must the Adam update issued in two pieces (FusedAdam.step_range), the bucketed discriminator update, and the DAMSM
@@ -201,12 +201,14 @@ def test_dependency_relaxations_do_not_change_a_bit(dev, det, encoder, dt):
     snap = st.snapshot()
 
     from miscc import losses
+    fork_default = nets._GBase.fork_mapping
 
     def run(relaxed, bucket=False, direct=True):
         st.restore(snap)
         st.early_g_terms = st.early_d = relaxed
         st.bucket_adam = bucket
-        nets._GBase.fork_mapping = relaxed
+        # (MAPPING_NET on a side stream is NOT part of the set: it is off by default -- a race with two mapping calls,
+        # tools/stress_generator_test.py -- and stays out of the gating tests until that is understood)
         losses.DIRECT_DAMSM = direct
         try:
             out = st.step(*args)
@@ -215,7 +217,7 @@ def test_dependency_relaxations_do_not_change_a_bit(dev, det, encoder, dt):
         finally:
             st.early_g_terms = st.early_d = True
             st.bucket_adam = False
-            nets._GBase.fork_mapping = True
+            nets._GBase.fork_mapping = fork_default
             losses.DIRECT_DAMSM = True
 
     tag = '%s_%s' % (encoder, str(dt).split('.')[-1])
