@@ -333,6 +333,25 @@ class GET_IMAGE_G(nn.Module):
 _MAP_STREAMS = {}        # device -> the side stream of the mapping network (module level: modules stay deep-copyable)
 
 
+class _CrossStream(torch.autograd.Function):
+    """Identity at the boundary between the mapping network's side stream and the main stream (experiment,
+    SBA_FORK_MAPPING=2): tells the caching allocator about the cross-stream use in BOTH directions -- the forward value
+    (allocated on the side stream, read on the main stream) and the gradient (allocated on the main stream, read by the
+    mapping network's backward pass on the side stream)."""
+
+    @staticmethod
+    def forward(ctx, w, main, side):
+        ctx.side = side
+        w.record_stream(main)
+        return w.view_as(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        g.record_stream(ctx.side)
+        return g, None, None
+
+
 class _GBase(nn.Module):
     def _build(self, n_map, cond_only, adain_name):
         ngf, nef, ncf = cfg.GAN.GF_DIM, cfg.TEXT.EMBEDDING_DIM, cfg.GAN.CONDITION_DIM
@@ -362,9 +381,11 @@ class _GBase(nn.Module):
     # instead of at the very end of the generator's.  Same kernels, same operands -- worth 0.2 ms of the 11 ms step -- but
     # OFF by default: with two mapping calls (G_NET_MIX) `tools/stress_generator_test.py` shows a RACE in eager mode, 4 of
     # 30 runs with one wrong weight gradient (h_net2.adain2.style.weight, the same wrong value every time), 0 of 30 without
-    # the fork; the mechanism (autograd replaying the mapping network's backward on the side stream while the main
-    # stream's allocator reuses a block) is not pinned down, so no variant gets the fork until it is.
-    fork_mapping = os.environ.get('SBA_FORK_MAPPING', '0') == '1'
+    # the fork.  SBA_FORK_MAPPING=2 adds `_CrossStream` (record_stream in both directions at the boundary): 0 of 40 in the
+    # same stress run -- an allocator cross-stream reuse hazard -- but that variant has not been through the full GPU
+    # suite yet (the round's GPU budget ended there), so no variant gets the fork by default.
+    fork_mapping = os.environ.get('SBA_FORK_MAPPING', '0') in ('1', '2')
+    _fork_guard = os.environ.get('SBA_FORK_MAPPING', '0') == '2'
     on_image = None          # callable(i): called right after fake image i has been issued (the trainer forks the
     #                          update of discriminator i from that point instead of from the end of the forward pass)
 
@@ -394,6 +415,9 @@ class _GBase(nn.Module):
             self._emit(fake_imgs, self.img_net1(h))
         if join is not None:
             join[0].wait_stream(join[1])
+            if self._fork_guard:
+                ws = [_CrossStream.apply(w, join[0], join[1]) for w in ws]
+                w2, w3 = ws[0], ws[-1]
         if self.branch_num > 1:
             h, att1 = self.h_net2(h, c_code, w2, word_embs, mask)
             self._emit(fake_imgs, self.img_net2(h))
