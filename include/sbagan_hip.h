@@ -95,8 +95,9 @@ const char* sba_version(void);
  * meant for parity tests and debugging, not for the benchmark.
  *   scratch: device memory, 256-byte aligned, >= 1 MiB; size it for the partial sums of one whole step (the
  *   B = 20 step uses about 0.6 GiB; sba_det_high_water() reports the largest amount handed out between two resets).
- *   An allocation that does not fit before the end of the ring wraps to its start; one that exceeds the ring
- *   fails (SBA_E_ARG from the launching entry point).  sba_det_reset() rewinds the ring (call it at the start of a
+ *   The ring never wraps: an allocation that does not fit in what is left since the last sba_det_reset() fails
+ *   (SBA_E_ARG from the launching entry point, one line on stderr) -- slots handed out earlier may still be waiting for
+ *   their fold.  sba_det_reset() rewinds the ring (call it at the start of a
  *   step, before capture: the addresses are baked into captured graphs).  Switch the mode only while the device is
  *   idle. */
 int sba_set_deterministic(int on, void* scratch, int64_t scratch_bytes);
@@ -108,7 +109,12 @@ int64_t sba_det_high_water(void);
  * gradients) then store per-workgroup partial sums into the ring and a second small launch folds them into the
  * destination; without a ring they use f32 atomics (correct, ~30 us slower per launch at 256 px).  Device memory,
  * 256-byte aligned, >= 1 MiB; a launch takes at most a quarter of it (larger requests fall back to atomics); regions
- * are handed out round-robin, so size it for the launches of one whole step (64 MiB covers the B = 20 step). */
+ * are handed out round-robin at host-issue time, so size it for the launches of one whole step (64 MiB covers the B = 20
+ * step, which uses ~33 MB).  REUSE-DISTANCE ASSUMPTION: a region is handed out again after `scratch_bytes` of later
+ * requests; the caller guarantees that the fold of its previous user has completed by then -- true when every step
+ * joins its streams before the next one starts (GANStep.step does; a captured step re-uses the SAME regions every replay,
+ * ordered by that join).  ONE ring per process = one device per process (the launch model of this library: one process
+ * per GPU); the host refuses a second device (sbagan.ops.reduce_scratch). */
 int sba_set_reduce_scratch(void* scratch, int64_t scratch_bytes);
 /* SBA_BN_STAT_SLOTS the library was compiled with (the host sizes its statistics buffers with it) */
 int sba_bn_stat_slots(void);
@@ -148,6 +154,14 @@ typedef struct sba_conv_group_item {
     const sba_conv_geom* g;
 } sba_conv_group_item;
 int sba_conv_igemm_group(int dtype, int n, const sba_conv_group_item* items, int tile, void* stream);
+/* The same with split-K: every item's K range (ntaps * Cin) is cut into `ksplit` slices (grid.z), partial sums meet in
+ * f32 atomics in the item's own [M][Cout] slice of `workspace` (zero-filled when handed in, left zero-filled; needs
+ * sum_i 4 * M_i * Cout_i bytes, 16-byte aligned) and ONE finishing launch for the whole group applies the epilogues.
+ * Falls back to ksplit = 1 when the workspace is too small, some Cin % 64 != 0, or in the deterministic mode.
+ * Used for the four parity classes of the data gradient of the 4x4 stride-2 conv (model.py:552 downBlock backward):
+ * they read the same dy, write disjoint pixels of dx, and were four launches of 80..640 workgroups each. */
+int sba_conv_igemm_group_splitk(int dtype, int n, const sba_conv_group_item* items, int tile, int ksplit,
+                                void* workspace, int64_t workspace_bytes, void* stream);
 /* dw[co][t][ci] += sum_pixel dy[pixel][co] * x[gather(pixel,t)][ci]   (f32 accumulate/output).
  * ksplit > 1 splits the pixel range over that many workgroups (atomic accumulation). */
 int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* dw, const sba_conv_geom* g,

@@ -3,6 +3,7 @@
 // The reference is PyTorch on cuDNN, whose default algorithms are not run-to-run reproducible either; this mode
 // exists so that the parity tests can tell a race from floating-point reassociation: with it on, two runs of the
 // same step from the same state are bit-identical in every launch mode (tests/test_step_gpu.py).
+#include <cstdio>
 #include <mutex>
 
 #include "common.h"
@@ -70,7 +71,18 @@ float* sba_det_alloc(int64_t nfloats) {
     std::lock_guard<std::mutex> lk(g_mu);
     const int64_t bytes = ((nfloats * 4 + 255) / 256) * 256;
     if (!g_ring || bytes > g_bytes) return nullptr;
-    if (g_off + bytes > g_bytes) g_off = 0;             // wrap: callers size the ring for more than one step
+    if (g_off + bytes > g_bytes) {
+        // NO wrap: slots handed out since the last sba_det_reset() may still be waiting for their fold, and this is the
+        // mode that exists to prove bit equality -- fail loudly (SBA_E_ARG from the launching entry point) instead
+        static bool said = false;
+        if (!said) {
+            said = true;
+            fprintf(stderr, "sbagan_hip: deterministic scratch ring exhausted (%lld of %lld bytes used since the last "
+                            "sba_det_reset): reset it at the start of every step or enlarge it (SBA_DET_SCRATCH_MB)\n",
+                    (long long)g_used_since_reset, (long long)g_bytes);
+        }
+        return nullptr;
+    }
     float* p = reinterpret_cast<float*>(g_ring + g_off);
     g_off += bytes;
     g_used_since_reset += bytes;

@@ -1152,8 +1152,9 @@ struct GroupItem {
     const bf16_t* x; const bf16_t* w; bf16_t* y; const bf16_t* addend; const float* bias; const void* mask;
     sba_conv_geom g;
     int M, gx, gy, tile_begin, nmajor, pad;
+    float* ws;              // split-K partial sums of this item ([M][Cout] f32, zero-filled), or NULL
 };
-struct GroupArgs { int n; int pad; GroupItem it[SBA_GROUP_MAX]; };
+struct GroupArgs { int n; int sps; GroupItem it[SBA_GROUP_MAX]; };      // sps: 64-channel slabs per K split (0 = no split)
 
 template <int BM, int BN, int WM, int WN, int D>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma2_group_kernel(const GroupArgs A DMA_TRACE_PARAM) {
@@ -1163,9 +1164,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_dma2_group_k
         if (k < A.n && (int)blockIdx.x >= A.it[k].tile_begin) i = k;
     const GroupItem& it = A.it[i];
     const sba_conv_geom g = it.g;
-    igemm_dma2_body<BM, BN, WM, WN, D>(it.x, it.w, it.y, it.addend, nullptr, g, it.M, nullptr, nullptr,
-                                       g.ntaps * (g.Cin / 64), EpiX{it.bias, it.mask, 0}, it.gx, it.gy,
-                                       (int)blockIdx.x - it.tile_begin, 0, it.nmajor DMA_TRACE_ARG_FWD);
+    // A.sps != 0: grid.z K splits, partial sums added into the item's f32 workspace, finished by splitk_finish_group_kernel
+    igemm_dma2_body<BM, BN, WM, WN, D>(it.x, it.w, it.y, it.addend, nullptr, g, it.M, A.sps ? it.ws : nullptr, nullptr,
+                                       A.sps ? A.sps : g.ntaps * (g.Cin / 64), EpiX{it.bias, it.mask, 0}, it.gx, it.gy,
+                                       (int)blockIdx.x - it.tile_begin, (int)blockIdx.z, it.nmajor DMA_TRACE_ARG_FWD);
 }
 
 // the same for members whose Cin is a multiple of 32 only (32-channel slabs, first-generation body)
@@ -2349,16 +2351,17 @@ __global__ void pool2x2_kernel(const T* __restrict__ up, T* __restrict__ dx, int
 
 // split-K finish: y[pix(m)][co] = ws[m][co] (+ addend), per-channel stats; thread = 4 channels x 8 rows
 template <typename T>
-__global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ ws, T* __restrict__ y,
-                                                            const T* __restrict__ addend,
-                                                            float* __restrict__ stats, const sba_conv_geom g,
-                                                            const int M, const EpiX ex) {
+__device__ __forceinline__ void splitk_finish_body(float* __restrict__ ws, T* __restrict__ y,
+                                                   const T* __restrict__ addend,
+                                                   float* __restrict__ stats, const sba_conv_geom& g,
+                                                   const int M, const EpiX ex) {
     const int ycs = g.y_cstride ? g.y_cstride : g.Cout;
     const int cq = g.Cout / 4;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= cq) return;
     const int c = t * 4;
     const int m0 = blockIdx.y * 8, m1 = min(m0 + 8, M);
+    if (m0 >= M) return;
     const int sub = g.OHs * g.OWs;
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
     float4 rows[8];
@@ -2408,6 +2411,21 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ 
             atomicAdd(&slot[g.Cout + c + k], s1[k]);
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ ws, T* __restrict__ y,
+                                                            const T* __restrict__ addend,
+                                                            float* __restrict__ stats, const sba_conv_geom g,
+                                                            const int M, const EpiX ex) {
+    splitk_finish_body<T>(ws, y, addend, stats, g, M, ex);
+}
+
+// the finishing pass of a grouped split-K launch: blockIdx.z = item
+__global__ __launch_bounds__(256) void splitk_finish_group_kernel(const GroupArgs A) {
+    const GroupItem& it = A.it[blockIdx.z];
+    const sba_conv_geom g = it.g;
+    splitk_finish_body<bf16_t>(it.ws, it.y, it.addend, nullptr, g, it.M, EpiX{it.bias, it.mask, 0});
 }
 
 // ---- tile configurations and their selection --------------------------------------------
@@ -2785,11 +2803,11 @@ extern "C" int sba_conv_igemm_plan(int dtype, const sba_conv_geom* g, int64_t wo
 }
 
 template <int BM, int BN, int WM, int WN, int D, int KS = 0>
-static int launch_group(const sba_conv_group_item* items, int n, hipStream_t st) {
+static int launch_group(const sba_conv_group_item* items, int n, hipStream_t st, int split = 1, float* ws = nullptr) {
     GroupArgs A;
     A.n = n;
-    A.pad = 0;
-    int tiles = 0;
+    A.sps = 0;
+    int tiles = 0, max_m = 0, max_co = 0, ns64 = 0;
     for (int i = 0; i < n; ++i) {
         const sba_conv_geom& g = *items[i].g;
         GroupItem& it = A.it[i];
@@ -2801,30 +2819,56 @@ static int launch_group(const sba_conv_group_item* items, int n, hipStream_t st)
         it.gy = cdiv(g.Cout, BN);
         it.nmajor = nmajor_for(g);
         it.pad = 0;
+        it.ws = nullptr;
         it.tile_begin = tiles;
         tiles += it.nmajor ? 8 * cdiv(it.gy, 8) * it.gx : 8 * cdiv(it.gx, 8) * it.gy;
+        if (it.M > max_m) max_m = it.M;
+        if (g.Cout > max_co) max_co = g.Cout;
+        const int k = g.ntaps * (g.Cin / 64);
+        if (k > ns64) ns64 = k;
+    }
+    if (split > 1 && KS == 0 && ws) {
+        // every item is cut into the same number of K splits (slabs per split from the longest K); item i adds its
+        // partial sums into its own [M][Cout] f32 slice of the zero-filled workspace
+        A.sps = cdiv(ns64, split);
+        split = cdiv(ns64, A.sps);
+        float* p = ws;
+        for (int i = 0; i < n; ++i) { A.it[i].ws = p; p += (int64_t)A.it[i].M * A.it[i].g.Cout; }
+        if (split <= 1) { A.sps = 0; split = 1; }
+    } else {
+        split = 1;
     }
     for (int i = n; i < SBA_GROUP_MAX; ++i) A.it[i] = A.it[0];
     constexpr int NT = (BM / WM) * (BN / WN) * 64;
-    if (KS == 0) SBA_LAUNCH((igemm_dma2_group_kernel<BM, BN, WM, WN, D>), dim3(tiles), dim3(NT), 0, st, A DMA_TRACE_ARG);
+    if (KS == 0) SBA_LAUNCH((igemm_dma2_group_kernel<BM, BN, WM, WN, D>), dim3(tiles, 1, split), dim3(NT), 0, st, A DMA_TRACE_ARG);
     else SBA_LAUNCH((igemm_dma_group_kernel<BM, BN, WM, WN, (KS ? KS : 1), D>), dim3(tiles), dim3(NT), 0, st, A DMA_TRACE_ARG);
+    if (A.sps) {
+        dim3 fgrid(cdiv(max_co / 4, 256), cdiv(max_m, 8), n);
+        SBA_LAUNCH(splitk_finish_group_kernel, fgrid, dim3(256), 0, st, A);
+    }
     return SBA_CHECK_LAUNCH();
 }
 
-extern "C" int sba_conv_igemm_group(int dtype, int n, const sba_conv_group_item* items, int tile, void* stream) {
+static int group_dispatch(int dtype, int n, const sba_conv_group_item* items, int tile, int ksplit, void* workspace,
+                          int64_t ws_bytes, hipStream_t st) {
     if (dtype != SBA_BF16 || !items || n < 1 || n > SBA_GROUP_MAX) return SBA_E_ARG;
     bool all64 = true;
+    int64_t need = 0;
     for (int i = 0; i < n; ++i) {
         const sba_conv_group_item& it = items[i];
         if (!it.x || !it.w || !it.y || !geom_ok(it.g, dtype)) return SBA_E_ARG;     // (geom_ok: Cin % 32 == 0)
         all64 = all64 && it.g->Cin % 64 == 0;
+        need += (int64_t)it.g->N * it.g->OHs * it.g->OWs * it.g->Cout * 4;
+        if (ksplit > 1 && it.g->Cout % 4) ksplit = 1;
     }
-    hipStream_t st = (hipStream_t)stream;
+    if (ksplit > 1 && (!workspace || need > ws_bytes || ((uintptr_t)workspace & 15) || !all64 || sba_det_on())) ksplit = 1;
+    if (ksplit < 1) ksplit = 1;
+    float* ws = (float*)workspace;
     if (all64) {        // 64-channel slabs, second-generation body
         switch (tile) {
-            case 0: case 1: return launch_group<64, 64, 32, 32, 4>(items, n, st);
-            case 3: return launch_group<96, 64, 32, 64, 3>(items, n, st);
-            case 5: return launch_group<128, 64, 32, 64, 3>(items, n, st);
+            case 0: case 1: return launch_group<64, 64, 32, 32, 4>(items, n, st, ksplit, ws);
+            case 3: return launch_group<96, 64, 32, 64, 3>(items, n, st, ksplit, ws);
+            case 5: return launch_group<128, 64, 32, 64, 3>(items, n, st, ksplit, ws);
             default: return SBA_E_ARG;
         }
     }
@@ -2834,6 +2878,15 @@ extern "C" int sba_conv_igemm_group(int dtype, int n, const sba_conv_group_item*
         case 5: return launch_group<128, 64, 32, 64, 4, 1>(items, n, st);
         default: return SBA_E_ARG;
     }
+}
+
+extern "C" int sba_conv_igemm_group(int dtype, int n, const sba_conv_group_item* items, int tile, void* stream) {
+    return group_dispatch(dtype, n, items, tile, 1, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int sba_conv_igemm_group_splitk(int dtype, int n, const sba_conv_group_item* items, int tile, int ksplit,
+                                           void* workspace, int64_t workspace_bytes, void* stream) {
+    return group_dispatch(dtype, n, items, tile, ksplit, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* dw, const sba_conv_geom* g,

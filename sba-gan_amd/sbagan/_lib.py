@@ -55,6 +55,7 @@ SIGNATURES = {
     'sba_conv_igemm_bias': [I, P, P, P, P, P, P, P, G, P, L, P],
     'sba_conv_igemm_plan': [I, G, L, POINTER(c_int)],
     'sba_conv_igemm_group': [I, I, POINTER(ConvGroupItem), I, P],
+    'sba_conv_igemm_group_splitk': [I, I, POINTER(ConvGroupItem), I, I, P, L, P],
     'sba_conv_wgrad': [I, P, P, P, G, I, P],
     'sba_pack_weight': [I, P, P, I, I, I, I, I, P],
     'sba_pack_weights_multi': [I, P, I, I, P],

@@ -366,6 +366,10 @@ def reduce_scratch(device):
     """The ring for the default mode's two-stage reductions (include/sbagan_hip.h: sba_set_reduce_scratch), handed to
     the library the first time an operator that uses it runs on `device` (SBA_REDUCE_SCRATCH_MB=0: none, atomics)."""
     if device not in _REDUCE_SCRATCH:
+        if _REDUCE_SCRATCH and REDUCE_SCRATCH_BYTES:
+            # the library keeps ONE ring (include/sbagan_hip.h): a second device would silently re-point it
+            raise RuntimeError('sbagan runs one process per GPU: the reduction scratch ring already belongs to %s'
+                               % next(iter(_REDUCE_SCRATCH)))
         buf = None
         if REDUCE_SCRATCH_BYTES:
             with torch.cuda.stream(torch.cuda.default_stream(device)):
@@ -387,15 +391,25 @@ def geom_key(g):
     return '%d_%dx%d_%d_%dx%d_%d_t%d_s%d_u%d' % (g.N, g.IH, g.IW, g.Cin, g.OHs, g.OWs, g.Cout, g.ntaps, g.sy, g.ups)
 
 
-def _igemm_table():
-    global _IGEMM_TABLE
-    if _IGEMM_TABLE is None:
-        _IGEMM_TABLE = {}
+_TABLE_FILE = None
+
+
+def _table_section(name):
+    global _TABLE_FILE
+    if _TABLE_FILE is None:
+        _TABLE_FILE = {}
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'igemm_table.json')
         if os.environ.get('SBA_IGEMM_TABLE', '1') != '0' and os.path.exists(path):
             import json
             with open(path) as f:
-                _IGEMM_TABLE = json.load(f).get('bf16', {})
+                _TABLE_FILE = json.load(f)
+    return _TABLE_FILE.get(name, {})
+
+
+def _igemm_table():
+    global _IGEMM_TABLE
+    if _IGEMM_TABLE is None:
+        _IGEMM_TABLE = _table_section('bf16')
     return _IGEMM_TABLE
 
 
@@ -458,12 +472,51 @@ def conv_dgrad(dy, pw, kind, in_hw, addend=None):
     if kind == '4x4s2':
         dx = empty_act(N, I, H, W, dy)
         esz = dy.element_size()
+        gs = [_geom(('4x4s2_dgrad', N, OH, OW, O, I, (cls // 2, cls % 2))) for cls in range(4)]
+        if DGRAD4_GROUP and dy.dtype == torch.bfloat16 and O % 64 == 0:
+            # the four parity classes read the same dy and write disjoint pixels of dx: ONE grid (4x the workgroups of a
+            # class, one launch floor, one tail) instead of four launches of 80..640 workgroups
+            arr = (_lib.ConvGroupItem * 4)()
+            for cls, (a, g) in enumerate(zip(arr, gs)):
+                a.x, a.w, a.y, a.addend = _p(dy), wd.data_ptr() + cls * I * 4 * O * esz, _p(dx), _p(addend)
+                a.bias = a.relu_mask = None
+                a.g = ctypes.pointer(g)
+            tile, split = dgrad4_plan(gs[0])
+            ws = workspace(dy.device)
+            call('sba_conv_igemm_group_splitk', _lib.SBA_BF16, 4, arr, tile, split, ws.data_ptr(), WORKSPACE_BYTES, _stream())
+            if IGEMM_LOG is not None:
+                IGEMM_LOG.append(('group', tile, gs))
+            return dx
         for cls in range(4):
-            g = _geom(('4x4s2_dgrad', N, OH, OW, O, I, (cls // 2, cls % 2)))
             wptr = wd.data_ptr() + cls * I * 4 * O * esz
-            _igemm(_dt(dy), _p(dy), wptr, _p(dx), _p(addend), None, g, dy.device)
+            _igemm(_dt(dy), _p(dy), wptr, _p(dx), _p(addend), None, gs[cls], dy.device)
         return dx
     raise ValueError(kind)
+
+
+DGRAD4_GROUP = os.environ.get('SBA_DGRAD4_GROUP', '1') != '0'
+_DGRAD4_FORCE = os.environ.get('SBA_DGRAD4_PLAN')          # tuning aid: "tile,split"
+
+
+def dgrad4_plan(g):
+    """(tile id, K splits) of the grouped launch of the four parity classes of a 4x4/s2 data gradient: from the measured
+    table (igemm_table.json, section 'dgrad4'; tools/tune_dgrad4.py) or by rule -- the biggest tile that still gives
+    two workgroups per CU, then K splits up to that occupancy while a split keeps >= 8 slabs of 64 channels."""
+    if _DGRAD4_FORCE:
+        t, s = _DGRAD4_FORCE.split(',')
+        return int(t), int(s)
+    ent = _table_section('dgrad4').get(geom_key(g))
+    if ent:
+        return int(ent[0]), int(ent[1])
+    M = g.N * g.OHs * g.OWs
+    ny = (g.Cout + 63) // 64
+    for tile, bm in ((5, 128), (3, 96), (1, 64)):
+        tiles = 4 * ((M + bm - 1) // bm) * ny
+        if tiles >= 512 or tile == 1:
+            break
+    ns64 = g.ntaps * (g.Cin // 64)
+    split = max(1, min(512 // max(tiles, 1), ns64 // 8))
+    return tile, split
 
 
 _KSPLIT_TARGET = int(os.environ.get('SBA_WGRAD_WGS', '640'))

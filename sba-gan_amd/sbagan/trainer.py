@@ -192,6 +192,7 @@ class GANStep(object):
         self._g_terms = [None] * len(netsD)
         self._adam_early = [None] * len(netsD)
         self._d_zeroed = [False] * len(netsD)
+        self._d_frozen = [False] * len(netsD)
         self._forked_d = False
         self._g_pending = None
         self._d_buckets = {}
@@ -245,6 +246,14 @@ class GANStep(object):
             self._allreduce_wait(h[0])
             self.optG.step(1.0 / self.world)
 
+    def drop_pending(self):
+        """Wait for a pending generator exchange and DISCARD it without applying the update: the parameters are about to
+        be overwritten (restore(), a checkpoint load), and the gradient in flight belongs to the weights being replaced --
+        applying it later would run Adam on the new weights with a stale gradient and bump its step counter."""
+        if self._g_pending is not None:
+            h, self._g_pending = self._g_pending, None
+            self._allreduce_wait(h[0])
+
     def _allreduce_wait(self, h):
         self.exchange.wait(h)
 
@@ -275,6 +284,10 @@ class GANStep(object):
         network exchanges one bucket); returns True when phase_d_bwd_rest has work left"""
         fake_imgs = self._ctx[0]
         netD = self.netsD[i]
+        if self._d_frozen[i]:           # left frozen by a phase_g_term whose phase_b_bwd never ran
+            for p in netD.parameters():
+                p.requires_grad_(True)
+            self._d_frozen[i] = False
         ops.SIDE_WGRAD = self.overlap_wgrad and self.overlap_wgrad_d
         if self._d_zeroed[i]:           # cleared at the start of the step, beside the generator's forward pass (step())
             self._d_zeroed[i] = False
@@ -385,7 +398,9 @@ class GANStep(object):
         behind the slowest of them (losses.py:168-186 evaluates the terms inside generator_loss, after all updates)."""
         netD = self.netsD[i]
         for p in netD.parameters():
-            p.requires_grad_(False)         # (phase_b_bwd restores them after the generator's backward pass)
+            p.requires_grad_(False)         # (phase_b_bwd restores them after the generator's backward pass; if that never
+        self._d_frozen[i] = True            #  runs -- an exception, a caller driving the phases by hand -- the next
+        #                                      phase_d_bwd_tail of this discriminator does)
         value, grad = generator_d_term(netD, self._ctx[0][i], sent_emb)
         self._g_terms[i] = (value, grad)
 
@@ -448,6 +463,7 @@ class GANStep(object):
         self._mark('g_backward')
         for p in self._d_params:
             p.requires_grad_(True)
+        self._d_frozen = [False] * len(self.netsD)
         out = self._out
         out['errG_total'] = errG_total.detach()
         out['kl_loss'] = kl.detach()
@@ -597,7 +613,10 @@ class GANStep(object):
 
     def restore(self, snap):
         """Write a snapshot() back in place (pointers are unchanged, so captured graphs stay valid; call
-        GraphedStep.resync() before the next replay: the graphs read packed bf16 copies of the weights)."""
+        GraphedStep.resync() before the next replay: the graphs read packed bf16 copies of the weights).  A generator
+        update still pending from the last data-parallel step is dropped, not applied (drop_pending); a launch-mode wrapper
+        that defers the update itself (GraphedStep) drops its own in resync()."""
+        self.drop_pending()
         for (net, flat, opt), s in zip(self._trained(), snap):
             flat.data.copy_(s['data'])
             flat.m.copy_(s['m'])
@@ -798,7 +817,14 @@ class GraphedStep(object):
     def resync(self):
         """Bring the packed weight copies the graphs read in line with the f32 masters, eagerly.  Needed after
         parameters changed behind the graphs' back (GANStep.restore, load_state_dict, a checkpoint): the graphs
-        repack a network only where the capture did, right after its own Adam step."""
+        repack a network only where the capture did, right after its own Adam step.  Contract: a generator update this
+        wrapper still holds back (data-parallel, overlapped exchange) is waited for and DROPPED here -- it was computed
+        for the weights that have just been replaced; call finish() BEFORE changing parameters to apply it instead."""
+        pend = getattr(self, '_pending', None)
+        if pend is not None:
+            self._pending = None
+            self.gan._allreduce_wait(pend[0])
+        self.gan.drop_pending()
         dt = ops.compute_dtype()
         for flat in [self.gan.flatG] + list(self.gan.flatD):
             if flat.packs is not None:
@@ -906,9 +932,10 @@ class ReplayedStep(object):
     Same contract as GraphedStep for parameters changed behind its back (resync())."""
 
     def __init__(self, gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, prologue=None,
-                 recorded_prologue=None, max_streams=4, verbose=False):
+                 recorded_prologue=None, max_streams=None, verbose=False):
         """prologue: called eagerly before every replay (after the random draws); recorded_prologue: deterministic
-        launches recorded in front of the step (e.g. the frozen text encoder's forward, trainer.py:248-252)."""
+        launches recorded in front of the step (e.g. the frozen text encoder's forward, trainer.py:248-252).
+        max_streams: replay streams; None = SBA_REPLAY_STREAMS from the environment, else 4."""
         if gan.distributed:
             raise RuntimeError('ReplayedStep records the whole step; the data-parallel path replays per phase '
                                '(GraphedStep)')
@@ -939,7 +966,8 @@ class ReplayedStep(object):
         # More streams share queues in an order the runtime picks (two independent chains on one queue run back to
         # back): 8 streams 11.31 ms, 6: 11.18, 5: 11.15, **4: 11.05**, 3: 11.7, 2: 12.5; raising GPU_MAX_HW_QUEUES instead
         # is far worse (5: 13.2 ms, 6: 19.8, 8: 20.7) -- profiles/r03_ab_replay_streams.txt
-        max_streams = int(os.environ.get('SBA_REPLAY_STREAMS', max_streams))
+        if max_streams is None:
+            max_streams = int(os.environ.get('SBA_REPLAY_STREAMS', '4'))
         rc = lib.sba_replay_create(ctypes.c_void_p(int(raw)), int(max_streams), 1 if verbose else 0,
                                    ctypes.byref(self.handle))
         if rc != 0:

@@ -158,6 +158,41 @@ def test_conv_addend_epilogue(dev, dt):
     close(dx, ref, dt, 'dgrad+addend')
 
 
+@pytest.mark.parametrize('case', [(2, 64, 128, 16, 16), (3, 128, 320, 8, 8), (20, 512, 1024, 8, 8), (5, 64, 64, 6, 10)])
+def test_dgrad4_grouped_plans(dev, case):
+    """the four parity classes of the 4x4 / stride-2 data gradient as ONE grouped launch (sba_conv_igemm_group_splitk):
+    every tile and K split the host may plan, with and without an addend, against conv_transpose2d and against the
+    four single launches"""
+    from sbagan import ops
+    dt = torch.bfloat16
+    N, Cin, Cout, H, W = case
+    w = fill.unit((Cout, Cin, 4, 4), 2) / np.sqrt(Cin * 16)
+    dy = fill.unit((N, Cout, H // 2, W // 2), 3)
+    add = fill.unit((N, Cin, H, W), 4)
+    wp = torch.nn.Parameter(w.to(dev).contiguous(memory_format=torch.channels_last))
+    pw = ops.PackedWeight(wp)
+    ref = F.conv_transpose2d(rounded(dy, dt), rounded(w, dt), None, 2, 1)
+    dya, adda = act(dy, dt, dev), act(add, dt, dev)
+    old = (ops.DGRAD4_GROUP, ops._DGRAD4_FORCE)
+    try:
+        ops.DGRAD4_GROUP = False
+        single = ops.conv_dgrad(dya, pw, '4x4s2', (H, W)).float().cpu()
+        ops.DGRAD4_GROUP = True
+        for plan in [None, '1,1', '3,1', '5,1', '1,2', '3,3', '5,4', '1,8']:
+            ops._DGRAD4_FORCE = plan
+            dx = ops.conv_dgrad(dya, pw, '4x4s2', (H, W))
+            close(dx, ref, dt, 'dx plan %s' % plan)
+            if plan in ('1,1', '3,1', '5,1'):       # no K split: the same sums in the same order as a single launch
+                assert torch.equal(dx.float().cpu(), single) or (dx.float().cpu() - single).abs().max() < 1e-2
+            dxa = ops.conv_dgrad(dya, pw, '4x4s2', (H, W), addend=adda)
+            close(dxa, ref + rounded(add, dt), dt, 'dx + addend plan %s' % plan)
+        # the split-K workspace is left zero-filled
+        torch.cuda.synchronize()
+        assert int(ops.workspace(dev).count_nonzero()) == 0
+    finally:
+        ops.DGRAD4_GROUP, ops._DGRAD4_FORCE = old
+
+
 def test_conv_addend_epilogue_persistent_halo(dev):
     """the persistent halo-tile kernel with the residual-add epilogue (ResBlock skip gradient) and statistics"""
     from sbagan import ops
