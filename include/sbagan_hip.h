@@ -394,6 +394,26 @@ int sba_damsm_words_bwd(const float* feat, const float* words, const int64_t* ca
                         const float* dsim, float* dfeat, float* dwords, int B, int nef, int R, int L,
                         float gamma1, float gamma2, void* stream);
 /* sentence similarity matrix (losses.py:41-47): s[j][i] = cos(cnn[j], rnn[i]) * g3. */
+/* The same loss on the bf16 MATRIX CORES (csrc/damsm_mfma.hip; nef % 64 == 0, R <= 384, L <= 32 -- sba_damsm_prep_bytes
+ * returns -1 otherwise and the callers keep the f32 kernels above).  Every product is formed from bf16 hi + lo parts of its
+ * f32 factors (xh yh + xl yh + xh yl, f32 sums): results agree with the f32 kernels to ~1e-5 relative.
+ *   sba_damsm_prep: features / words -> hi + lo operands in `prep` (caller-owned scratch of sba_damsm_prep_bytes bytes,
+ *     16-byte aligned; read by the forward AND the backward of the same inputs).
+ *   forward: one workgroup per (caption, image) pair; same outputs as sba_damsm_words_fwd.
+ *   backward: dwbuf [B*B][L][nef] and dsbuf [B*B][L][R] are f32 scratch (caller-owned, any contents); pass 1 (per pair)
+ *     fills them with d(context) and d(scores), pass 2 forms dfeat[j] += sum over (caption, word) of
+ *     A x dcontext + dS x q as ONE contraction per image -- every element of dfeat has one owner: no atomics, the same
+ *     bits in every run.  dwords (may be NULL) is accumulated with f32 atomics (deterministic mode: ordered fold). */
+int64_t sba_damsm_prep_bytes(int B, int nef, int R, int L);
+int sba_damsm_prep(const float* feat, const float* words, const int64_t* cap_lens, void* prep, int64_t prep_bytes,
+                   int B, int nef, int R, int L, void* stream);
+int sba_damsm_words_fwd_mfma(const void* prep, const float* words, const int64_t* cap_lens, float* sim, float* attn,
+                             float* attn1, float* wctx, int B, int nef, int R, int L, float gamma1, float gamma2,
+                             void* stream);
+int sba_damsm_words_bwd_mfma(const void* prep, const float* words, const int64_t* cap_lens, const float* sim,
+                             const float* attn, const float* attn1, const float* wctx, const float* dsim,
+                             float* dwbuf, float* dsbuf, float* dfeat, float* dwords, int B, int nef, int R, int L,
+                             float gamma1, float gamma2, void* stream);
 int sba_damsm_sent_fwd(const float* cnn, const float* rnn, float* s, int B, int nef, float gamma3,
                        float eps, void* stream);
 int sba_damsm_sent_bwd(const float* cnn, const float* rnn, const float* ds, float* dcnn, float* drnn,

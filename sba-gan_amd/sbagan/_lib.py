@@ -105,6 +105,9 @@ SIGNATURES = {
     'sba_kl_loss': [P, P, P, P, P, I, P],
     'sba_damsm_words_fwd': [P, P, P, P, P, P, P, I, I, I, I, F, F, P],
     'sba_damsm_words_bwd': [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, P],
+    'sba_damsm_prep': [P, P, P, P, L, I, I, I, I, P],
+    'sba_damsm_words_fwd_mfma': [P, P, P, P, P, P, P, I, I, I, I, F, F, P],
+    'sba_damsm_words_bwd_mfma': [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, P],
     'sba_damsm_sent_fwd': [P, P, P, I, I, F, F, P],
     'sba_damsm_sent_bwd': [P, P, P, P, P, I, I, F, F, P],
     'sba_ce_pair': [P, P, F, P, P, P, I, P],
@@ -139,6 +142,8 @@ lib.sba_version.restype = c_char_p
 lib.sba_version.argtypes = []
 lib.sba_det_high_water.restype = c_int64
 lib.sba_det_high_water.argtypes = []
+lib.sba_damsm_prep_bytes.restype = c_int64
+lib.sba_damsm_prep_bytes.argtypes = [I, I, I, I]
 
 _ERR = {-1: 'SBA_E_ARG (unsupported shape/alignment/enum)', -2: 'SBA_E_LAUNCH (HIP launch failed)',
         -3: 'SBA_E_UNSUPPORTED (graph node kind the replayer cannot re-issue)'}

@@ -1471,6 +1471,43 @@ class KLFn(torch.autograd.Function):
         return dmu * g, dlv * g
 
 
+DAMSM_MFMA = os.environ.get('SBA_DAMSM_MFMA', '1') != '0'
+
+
+def _damsm_prep(feat, words, cap_lens, B, nef, R, L):
+    """bf16 hi + lo operand copies for the matrix-core words loss (include/sbagan_hip.h: sba_damsm_prep), or None when the
+    shape is outside that path (the f32 kernels then run)"""
+    if not DAMSM_MFMA:
+        return None
+    nbytes = int(_lib.lib.sba_damsm_prep_bytes(B, nef, R, L))
+    if nbytes <= 0:
+        return None
+    prep = torch.empty(nbytes, dtype=torch.uint8, device=feat.device)
+    call('sba_damsm_prep', _p(feat), _p(words), _p(cap_lens), _p(prep), nbytes, B, nef, R, L, _stream())
+    return prep
+
+
+def _damsm_words_fwd(prep, feat, words, cap_lens, sim, attn, attn1, wctx, B, nef, R, L, g1, g2, st):
+    if prep is not None:
+        call('sba_damsm_words_fwd_mfma', _p(prep), _p(words), _p(cap_lens), _p(sim), _p(attn), _p(attn1), _p(wctx), B, nef,
+             R, L, g1, g2, st)
+    else:
+        call('sba_damsm_words_fwd', _p(feat), _p(words), _p(cap_lens), _p(sim), _p(attn), _p(attn1), _p(wctx), B, nef, R,
+             L, g1, g2, st)
+
+
+def _damsm_words_bwd(prep, feat, words, cap_lens, sim, attn, attn1, wctx, dsim, dfeat, dwords, B, nef, R, L, g1, g2, st):
+    """dfeat must be zero-filled (both paths accumulate into it)"""
+    if prep is not None:
+        dwbuf = torch.empty((B * B, L, nef), dtype=torch.float32, device=feat.device)
+        dsbuf = torch.empty((B * B, L, R), dtype=torch.float32, device=feat.device)
+        call('sba_damsm_words_bwd_mfma', _p(prep), _p(words), _p(cap_lens), _p(sim), _p(attn), _p(attn1), _p(wctx),
+             _p(dsim), _p(dwbuf), _p(dsbuf), _p(dfeat), _p(dwords), B, nef, R, L, g1, g2, st)
+    else:
+        call('sba_damsm_words_bwd', _p(feat), _p(words), _p(cap_lens), _p(sim), _p(attn), _p(attn1), _p(wctx), _p(dsim),
+             _p(dfeat), _p(dwords), B, nef, R, L, g1, g2, st)
+
+
 class WordsLossFn(torch.autograd.Function):
     """words_loss (losses.py:62-132): returns (loss0, loss1)."""
 
@@ -1489,13 +1526,14 @@ class WordsLossFn(torch.autograd.Function):
         attn = torch.empty((B * B, L, R), dtype=torch.float32, device=dev)
         attn1 = torch.empty((B * B, L, R), dtype=torch.float32, device=dev)
         wctx = torch.empty((B * B, L, nef), dtype=torch.float32, device=dev)
-        call('sba_damsm_words_fwd', _p(feat), _p(words), _p(cap_lens), _p(sim), _p(attn), _p(attn1), _p(wctx), B,
-             nef, R, L, g1, g2, _stream())
+        prep = _damsm_prep(feat, words, cap_lens, B, nef, R, L)
+        _damsm_words_fwd(prep, feat, words, cap_lens, sim, attn, attn1, wctx, B, nef, R, L, g1, g2, _stream())
         loss = torch.empty(2, dtype=torch.float32, device=dev)
         d0, d1 = torch.empty_like(sim), torch.empty_like(sim)
         call('sba_ce_pair', _p(sim), _p(mask), g3, _p(loss), _p(d0), _p(d1), B, _stream())
         ctx.save_for_backward(feat, words, cap_lens, sim, attn, attn1, wctx, d0, d1)
         ctx.g = (g1, g2)
+        ctx.prep = prep
         ctx.fshape = None
         return loss[0], loss[1]
 
@@ -1513,8 +1551,8 @@ class WordsLossFn(torch.autograd.Function):
         call('sba_combine2', _p(dsim), _p(d0), _p(gl0), _p(d1), _p(gl1), B * B, _stream())
         dfeat = torch.zeros_like(feat)
         dwords = torch.zeros_like(words) if ctx.needs_input_grad[1] else None
-        call('sba_damsm_words_bwd', _p(feat), _p(words), _p(cap_lens), _p(sim), _p(attn), _p(attn1), _p(wctx),
-             _p(dsim), _p(dfeat), _p(dwords), B, nef, R, L, ctx.g[0], ctx.g[1], _stream())
+        _damsm_words_bwd(ctx.prep, feat, words, cap_lens, sim, attn, attn1, wctx, dsim, dfeat, dwords, B, nef, R, L,
+                         ctx.g[0], ctx.g[1], _stream())
         return dfeat, dwords, None, None, None
 
 
@@ -1584,16 +1622,15 @@ def damsm_terms_direct(region_features, cnn_code, words_embs, sent_emb, cap_lens
     attn = torch.empty((B * B, L, R), dtype=torch.float32, device=dev)
     attn1 = torch.empty((B * B, L, R), dtype=torch.float32, device=dev)
     wctx = torch.empty((B * B, L, nef), dtype=torch.float32, device=dev)
-    call('sba_damsm_words_fwd', _p(feat), _p(words), _p(cap_lens), _p(sim), _p(attn), _p(attn1), _p(wctx), B, nef, R, L,
-         g1, g2, st)
+    prep = _damsm_prep(feat, words, cap_lens, B, nef, R, L)
+    _damsm_words_fwd(prep, feat, words, cap_lens, sim, attn, attn1, wctx, B, nef, R, L, g1, g2, st)
     wl = torch.empty(2, dtype=torch.float32, device=dev)
     d0, d1 = torch.empty_like(sim), torch.empty_like(sim)
     call('sba_ce_pair', _p(sim), _p(mask), g3, _p(wl), _p(d0), _p(d1), B, st)
     dsim = torch.empty_like(sim)
     call('sba_combine2', _p(dsim), _p(d0), _p(lamt), _p(d1), _p(lamt), B * B, st)
     dfeat = torch.zeros_like(feat)
-    call('sba_damsm_words_bwd', _p(feat), _p(words), _p(cap_lens), _p(sim), _p(attn), _p(attn1), _p(wctx), _p(dsim),
-         _p(dfeat), None, B, nef, R, L, g1, g2, st)
+    _damsm_words_bwd(prep, feat, words, cap_lens, sim, attn, attn1, wctx, dsim, dfeat, None, B, nef, R, L, g1, g2, st)
     s = torch.empty((B, B), dtype=torch.float32, device=dev)
     call('sba_damsm_sent_fwd', _p(cnn), _p(rnn), _p(s), B, nef, g3, eps, st)
     sl = torch.empty(2, dtype=torch.float32, device=dev)

@@ -204,14 +204,27 @@ class condGANTrainer(object):
         self.save_model(netG, gan.flatG.ema_params(), netsD, self.max_epoch)
 
     # ------------------------------------------------------------------ inference (trainer.py:348-518)
+    # Written from the OUTPUT-FILE contract of the reference's three inference entry points (what a user of its eval
+    # scripts finds on disk), not from their statements:
+    #   save_singleimages  <save_dir>/single_samples/<split_dir>/<filename>_<sentenceID>.jpg
+    #   sampling           <NET_G without .pth>/<split>/single/<key>_s-1.png          (last stage only; 'test' -> 'valid')
+    #   gen_example        <NET_G without .pth>/<key>/0_s_<original caption index>_g<stage>.png
+    @staticmethod
+    def _write_image(tensor_chw, path, made=None):
+        """one CHW image in [-1, 1] to `path`, creating its directory the first time it is seen"""
+        parent = os.path.dirname(path)
+        if made is None or parent not in made:
+            if not os.path.isdir(parent):
+                mkdir_p(parent)
+            if made is not None:
+                made.add(parent)
+        Image.fromarray(_to_uint8(tensor_chw)).save(path)
+
     def save_singleimages(self, images, filenames, save_dir, split_dir, sentenceID=0):
-        for i in range(images.size(0)):
-            s_tmp = '%s/single_samples/%s/%s' % (save_dir, split_dir, filenames[i])
-            folder = s_tmp[:s_tmp.rfind('/')]
-            if not os.path.isdir(folder):
-                print('Make a new folder: ', folder)
-                mkdir_p(folder)
-            Image.fromarray(_to_uint8(images[i])).save('%s_%d.jpg' % (s_tmp, sentenceID))
+        root = os.path.join(save_dir, 'single_samples', split_dir)
+        made = set()
+        for img, name in zip(images, filenames):
+            self._write_image(img, '%s_%d.jpg' % (os.path.join(root, name), sentenceID), made)
 
     def _load_inference_models(self):
         dev = self.device
@@ -227,64 +240,59 @@ class condGANTrainer(object):
         print('Load G from: ', cfg.TRAIN.NET_G)
         return netG.to(dev).eval(), text_encoder.to(dev).eval()
 
+    @staticmethod
+    def _output_root():
+        """the directory named after the generator checkpoint (its path without the .pth suffix), or None"""
+        ckpt = cfg.TRAIN.NET_G
+        if not ckpt:
+            print('cfg.TRAIN.NET_G is empty: inference needs a generator checkpoint')
+            return None
+        cut = ckpt.rfind('.pth')
+        return ckpt[:cut] if cut >= 0 else ckpt
+
+    def _generate(self, netG, text_encoder, captions, cap_lens, noise):
+        """fake images of every stage for one caption batch (noise is refilled in place)"""
+        words_embs, sent_emb = self._encode(text_encoder, captions, cap_lens)
+        noise.normal_(0, 1)
+        with torch.no_grad():
+            fake_imgs, _, _, _ = netG(noise, sent_emb, words_embs, build_mask(captions, words_embs.size(2)))
+        return fake_imgs
+
     def sampling(self, split_dir):
-        """trainer.py:363-433: one image per caption of the split, <NET_G minus .pth>/<split>/single/<key>_s-1.png."""
-        if cfg.TRAIN.NET_G == '':
-            print('Error: the path for morels is not found!')
-            return
-        if split_dir == 'test':
-            split_dir = 'valid'
+        """trainer.py:363-433: one image (the last stage's) per caption of the split."""
+        root = self._output_root()
+        if root is None:
+            return None
+        out_dir = os.path.join(root, 'valid' if split_dir == 'test' else split_dir)
+        mkdir_p(out_dir)
         netG, text_encoder = self._load_inference_models()
-        batch_size, nz = self.batch_size, cfg.GAN.Z_DIM
-        noise = torch.empty((batch_size, nz), device=self.device)
-        model_dir = cfg.TRAIN.NET_G
-        save_dir = '%s/%s' % (model_dir[:model_dir.rfind('.pth')], split_dir)
-        mkdir_p(save_dir)
-        cnt = 0
-        for step, data in enumerate(self.data_loader, 0):
-            cnt += batch_size
-            if step % 100 == 0:
-                print('step: ', step)
-            imgs, captions, cap_lens, class_ids, keys = prepare_data(data)
-            words_embs, sent_emb = self._encode(text_encoder, captions, cap_lens)
-            mask = build_mask(captions, words_embs.size(2))
-            noise.normal_(0, 1)
-            with torch.no_grad():
-                fake_imgs, _, _, _ = netG(noise, sent_emb, words_embs, mask)
-            for j in range(batch_size):
-                s_tmp = '%s/single/%s' % (save_dir, keys[j])
-                folder = s_tmp[:s_tmp.rfind('/')]
-                if not os.path.isdir(folder):
-                    print('Make a new folder: ', folder)
-                    mkdir_p(folder)
-                k = -1
-                Image.fromarray(_to_uint8(fake_imgs[k][j])).save('%s_s%d.png' % (s_tmp, k))
-        return save_dir
+        noise = torch.empty((self.batch_size, cfg.GAN.Z_DIM), device=self.device)
+        made = set()
+        for nbatch, data in enumerate(self.data_loader):
+            if nbatch % 100 == 0:
+                print('step: ', nbatch)
+            _, captions, cap_lens, _, keys = prepare_data(data)
+            last = self._generate(netG, text_encoder, captions, cap_lens, noise)[-1]
+            for img, key in zip(last, keys):
+                self._write_image(img, os.path.join(out_dir, 'single', key) + '_s-1.png', made)
+        return out_dir
 
     def gen_example(self, data_dic):
         """trainer.py:435-518: data_dic[key] = [captions (n x Lmax int64, sorted by length), cap_lens, sorted_indices];
-        writes <NET_G minus .pth>/<key>/0_s_<index>_g<scale>.png (attention overlays: out of scope)."""
-        if cfg.TRAIN.NET_G == '':
-            print('Error: the path for morels is not found!')
-            return
+        every stage's image per caption, named by the caption's ORIGINAL position (attention overlays: out of scope)."""
+        root = self._output_root()
+        if root is None:
+            return None
         netG, text_encoder = self._load_inference_models()
-        s_tmp = cfg.TRAIN.NET_G[:cfg.TRAIN.NET_G.rfind('.pth')]
-        for key in data_dic:
-            save_dir = '%s/%s' % (s_tmp, key)
-            print(save_dir)
-            mkdir_p(save_dir)
-            captions, cap_lens, sorted_indices = data_dic[key]
-            batch_size = captions.shape[0]
+        for key, (captions, cap_lens, order) in data_dic.items():
+            out_dir = os.path.join(root, key)
+            print(out_dir)
+            mkdir_p(out_dir)
             captions = torch.from_numpy(np.ascontiguousarray(captions)).to(self.device)
             cap_lens = torch.from_numpy(np.ascontiguousarray(cap_lens)).to(self.device)
-            for i in range(1):
-                noise = torch.randn((batch_size, cfg.GAN.Z_DIM), device=self.device)
-                words_embs, sent_emb = self._encode(text_encoder, captions, cap_lens)
-                mask = build_mask(captions, words_embs.size(2))
-                with torch.no_grad():
-                    fake_imgs, attention_maps, _, _ = netG(noise, sent_emb, words_embs, mask)
-                for j in range(batch_size):
-                    save_name = '%s/%d_s_%d' % (save_dir, i, sorted_indices[j])
-                    for k in range(len(fake_imgs)):
-                        Image.fromarray(_to_uint8(fake_imgs[k][j])).save('%s_g%d.png' % (save_name, k))
-        return s_tmp
+            noise = torch.empty((captions.shape[0], cfg.GAN.Z_DIM), device=self.device)
+            stages = self._generate(netG, text_encoder, captions, cap_lens, noise)
+            for stage, batch in enumerate(stages):
+                for img, src in zip(batch, order):
+                    self._write_image(img, os.path.join(out_dir, '0_s_%d_g%d.png' % (int(src), stage)))
+        return root

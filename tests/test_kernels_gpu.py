@@ -686,6 +686,48 @@ def test_damsm_losses(dev):
         close(ca.grad, cr.grad, torch.float32, 'dcnn', scale=10); close(sa.grad, sr.grad, torch.float32, 'drnn', scale=10)
 
 
+@pytest.mark.parametrize('shape', [(20, 256, 17, 18), (3, 64, 17, 32), (4, 128, 10, 5), (2, 256, 17, 1)])
+def test_damsm_words_matrix_cores(dev, shape):
+    """words_loss on the bf16 matrix cores (csrc/damsm_mfma.hip: hi + lo operands, one contraction per image for
+    d(features)) against the oracle (losses.py:62-132) and against the f32 kernels it replaces: losses, d(features),
+    d(words); d(features) is bit-reproducible run to run (no atomics)."""
+    from miscc import losses
+    from sbagan import ops
+    B, nef, S, L = shape
+    feat = fill.unit((B, nef, S, S), 11)
+    words = fill.unit((B, nef, L), 12)
+    lens = torch.tensor([max(1, L - (k * 3) % L) for k in range(B)])
+    labels = torch.arange(B)
+    cids = np.arange(B)
+    fr, wr = feat.clone().requires_grad_(True), words.clone().requires_grad_(True)
+    w0, w1 = O.words_loss(fr, wr, labels, lens, cids, B, 4.0, 5.0, 10.0)
+    (w0 * 1.5 + w1 * 0.7).backward()
+
+    def run():
+        fa, wa = feat.to(dev).requires_grad_(True), words.to(dev).requires_grad_(True)
+        g0, g1, _ = losses.words_loss(fa, wa, labels.to(dev), lens.to(dev), cids, B)
+        (g0 * 1.5 + g1 * 0.7).backward()
+        torch.cuda.synchronize()
+        return float(g0), float(g1), fa.grad.cpu(), wa.grad.cpu()
+    old = ops.DAMSM_MFMA
+    try:
+        ops.DAMSM_MFMA = True
+        assert ops._damsm_prep(feat.to(dev), words.to(dev), lens.to(dev), B, nef, S * S, L) is not None
+        m0, m1, mf, mw = run()
+        _, _, mf2, _ = run()
+        ops.DAMSM_MFMA = False
+        v0, v1, vf, vw = run()
+    finally:
+        ops.DAMSM_MFMA = old
+    for got, ref in ((m0, float(w0)), (m1, float(w1)), (m0, v0), (m1, v1)):
+        assert abs(got - ref) < 2e-4 * max(1, abs(ref)), (got, ref)
+    close(mf, fr.grad, torch.float32, 'dfeat vs oracle', scale=20)
+    close(mw, wr.grad, torch.float32, 'dwords vs oracle', scale=20)
+    close(mf, vf, torch.float32, 'dfeat vs f32 kernels', scale=20)
+    close(mw, vw, torch.float32, 'dwords vs f32 kernels', scale=20)
+    assert torch.equal(mf, mf2), 'd(features) of the matrix-core path is not reproducible'
+
+
 def test_public_func_attention_vs_reference_golden(dev, golden_dir):
     """GlobalAttention.func_attention (GlobalAttention.py:31-69) as exported by the drop-in package, on the GPU,
     against the output of the reference's own function (tests/golden/units_tiny.npz, tools/make_golden.py)."""

@@ -233,6 +233,8 @@ GOLDEN_STEPS = {
     'mix_b4': ('step_full_mix_b4.npz', 'mix', 4, 3, False),              # config 5 generator (G_NET_MIX)
     'stage1_b4': ('step_full_model_b4_branch1.npz', 'model', 4, 1, False),   # config 1 (64 px only)
     'model_b20': ('step_full_model_b20.npz', 'model', 20, 3, True),      # config 2 at its own batch size
+    'bert_b20': ('step_full_bert_b20.npz', 'bert', 20, 3, True),         # config 3 at the benched batch size
+    'mix_b20': ('step_full_mix_b20.npz', 'mix', 20, 3, True),            # config 5 at the benched batch size
 }
 # stated tolerances on the losses / gradient norms of step 0 (x10 after an Adam update, x3 for discriminator
 # gradient norms): f32 1e-3 = the north star's bar.  bf16 (bf16 storage of activations and packed weights, f32

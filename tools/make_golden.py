@@ -400,6 +400,10 @@ def main():
         gen_step(ref, 'step_full_model_b4_branch1.npz', FULL, 4, 2, 'model', branch=1)
     if 'step_full_b20' in what:         # BASELINE config 2 at its own batch size (losses, grad norms, slices)
         gen_step(ref, 'step_full_model_b20.npz', FULL, 20, 2, 'model', slim=True)
+    if 'step_full_bert_b20' in what:    # BASELINE config 3 at the benched batch size
+        gen_step(ref, 'step_full_bert_b20.npz', FULL, 20, 2, 'bert', slim=True)
+    if 'step_full_mix_b20' in what:     # BASELINE config 5 at the benched batch size
+        gen_step(ref, 'step_full_mix_b20.npz', FULL, 20, 2, 'mix', slim=True)
 
 
 if __name__ == '__main__':
