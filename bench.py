@@ -475,21 +475,35 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / n
 
-    # Data-parallel launch mode (N > 1): sbagan.trainer.ReplayedStepDP -- three recordings through the native replayer with the
-    # gradient exchange between them.  SBA_DP_REPLAY: 2 (default) = image encoder + DAMSM terms
-    # launched while the discriminators' all-reduces are in flight; 1 = beside the discriminators' backward passes (the
-    # exchange fully exposed); 0 = the per-phase hipGraphs (GraphedStep).  Every rank reads the same environment; a rank
+    # Data-parallel launch mode (N > 1), SBA_DP_REPLAY:
+    #   4 (default) the WHOLE data-parallel step as ONE recording through the native replayer, the gradient exchanges and the
+    #     deferred generator update as host-call nodes (sbagan.trainer.ReplayedStep + ExchangeRecorder): every collective
+    #     where the eager data-parallel step has it -- D_NET128 / D_NET256 in two buckets under their backward passes, the
+    #     generator's exchange behind the next step's text encoder + real-image forwards -- and the phases overlapping as on
+    #     one GPU;
+    #   3 / 2 / 1 sbagan.trainer.ReplayedStepDP: several recordings with the exchange between them (3: deferred generator
+    #     update + image encoder beside the discriminators' exchange, 2: no deferral, 1: the exchange fully exposed);
+    #   0 the per-phase hipGraphs (GraphedStep).
+    # Every rank reads the same environment; the collective-bearing warm-up step runs OUTSIDE the try block (a rank that
+    # threw inside it would leave its peers blocked in the step's all-reduces); the captures issue no collective, and a rank
     # whose capture fails makes ALL ranks fall back to the per-phase graphs.
-    dp_mode = os.environ.get('SBA_DP_REPLAY', '2')
+    dp_mode = os.environ.get('SBA_DP_REPLAY', '4')
     dp_graph = None
-    if args.graph and multi and dp_mode in ('1', '2'):
+    if args.graph and multi and dp_mode in ('1', '2', '3', '4'):
+        from sbagan.trainer import ReplayedStep, ReplayedStepDP
         flags = (step.overlap_g, step.bucket_d)
         a = (b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'], b['class_ids'], noise)
+        nstreams = int(os.environ.get('SBA_REPLAY_STREAMS', '4'))
+        if dp_mode == '4':
+            warm = ReplayedStep.warm_up(step, *a, recorded_prologue=encode)
+        else:
+            warm = ReplayedStepDP.warm_up(step, *a, recorded_prologue=encode, defer_g=dp_mode == '3')
         try:
-            from sbagan.trainer import ReplayedStepDP
-            dp_graph = ReplayedStepDP(step, *a, recorded_prologue=encode,
-                                      max_streams=int(os.environ.get('SBA_REPLAY_STREAMS', '4')),
-                                      e_beside_exchange=dp_mode == '2')
+            if dp_mode == '4':
+                dp_graph = ReplayedStep(step, *a, recorded_prologue=encode, max_streams=nstreams, verbose=True, warm=warm)
+            else:
+                dp_graph = ReplayedStepDP(step, *a, recorded_prologue=encode, max_streams=nstreams,
+                                          e_beside_exchange=dp_mode in ('2', '3'), defer_g=dp_mode == '3', warm=warm)
         except Exception as e:
             sys.stderr.write('data-parallel launch replayer unavailable (%s: %s)\n' % (type(e).__name__, e))
             dp_graph = None
@@ -498,6 +512,7 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok) == 0:
             dp_graph = None
+            step.finish()
             step.overlap_g, step.bucket_d = flags
     if dp_graph is not None:
         graph = dp_graph

@@ -400,11 +400,13 @@ int sba_damsm_words_bwd(const float* feat, const float* words, const int64_t* ca
  *   sba_damsm_prep: features / words -> hi + lo operands in `prep` (caller-owned scratch of sba_damsm_prep_bytes bytes,
  *     16-byte aligned; read by the forward AND the backward of the same inputs).
  *   forward: one workgroup per (caption, image) pair; same outputs as sba_damsm_words_fwd.
- *   backward: dwbuf [B*B][L][nef] and dsbuf [B*B][L][R] are f32 scratch (caller-owned, any contents); pass 1 (per pair)
- *     fills them with d(context) and d(scores), pass 2 forms dfeat[j] += sum over (caption, word) of
- *     A x dcontext + dS x q as ONE contraction per image -- every element of dfeat has one owner: no atomics, the same
- *     bits in every run.  dwords (may be NULL) is accumulated with f32 atomics (deterministic mode: ordered fold). */
+ *   backward: `scratch` (caller-owned, sba_damsm_bwd_bytes bytes, 16-byte aligned, any contents): pass 1 (per pair)
+ *     fills it with d(context), the attention and d(scores) as bf16 hi + lo MFMA fragments, pass 2 forms
+ *     dfeat[j] (= or +=, `accumulate`) sum over (caption, word) of A x dcontext + dS x q as ONE contraction per image --
+ *     every element of dfeat has one owner: no atomics, the same bits in every run.  dwords (may be NULL) is accumulated
+ *     with f32 atomics (deterministic mode: ordered fold). */
 int64_t sba_damsm_prep_bytes(int B, int nef, int R, int L);
+int64_t sba_damsm_bwd_bytes(int B, int nef, int R, int L);
 int sba_damsm_prep(const float* feat, const float* words, const int64_t* cap_lens, void* prep, int64_t prep_bytes,
                    int B, int nef, int R, int L, void* stream);
 int sba_damsm_words_fwd_mfma(const void* prep, const float* words, const int64_t* cap_lens, float* sim, float* attn,
@@ -412,8 +414,19 @@ int sba_damsm_words_fwd_mfma(const void* prep, const float* words, const int64_t
                              void* stream);
 int sba_damsm_words_bwd_mfma(const void* prep, const float* words, const int64_t* cap_lens, const float* sim,
                              const float* attn, const float* attn1, const float* wctx, const float* dsim,
-                             float* dwbuf, float* dsbuf, float* dfeat, float* dwords, int B, int nef, int R, int L,
-                             float gamma1, float gamma2, void* stream);
+                             void* scratch, int64_t scratch_bytes, float* dfeat, int accumulate, float* dwords,
+                             int B, int nef, int R, int L, float gamma1, float gamma2, void* stream);
+/* The loss heads of the generator step with a FROZEN text side (losses.py:187-204: the upstream gradient of the four
+ * cross-entropy terms is the constant LAMBDA), each as ONE launch instead of ce_pair + combine2 + scalar arithmetic:
+ *   sba_ce_pair_direct: loss_out[0] = lam (loss0 + loss1) of the two cross entropies over the B x B scores (x scale,
+ *     masked), dscore = d(that) / d(score);
+ *   sba_damsm_sent_direct: the whole sentence loss -- cosine scores x gamma3, both cross entropies,
+ *     loss_out[0] = lam (loss0 + loss1), dcnn = d(that) / d(cnn) (STORED; may be NULL); one workgroup, B <= 96,
+ *     deterministic (partners walked in order). */
+int sba_ce_pair_direct(const float* score, const uint8_t* mask, float scale, float lam, float* loss_out,
+                       float* dscore, int B, void* stream);
+int sba_damsm_sent_direct(const float* cnn, const float* rnn, const uint8_t* mask, float gamma3, float eps, float lam,
+                          float* loss_out, float* dcnn, int B, int nef, void* stream);
 int sba_damsm_sent_fwd(const float* cnn, const float* rnn, float* s, int B, int nef, float gamma3,
                        float eps, void* stream);
 int sba_damsm_sent_bwd(const float* cnn, const float* rnn, const float* ds, float* dcnn, float* drnn,
@@ -470,6 +483,16 @@ int sba_lstm_bidir_fwd(const int64_t* captions, const int64_t* cap_lens, const f
 int sba_replay_create(void* hip_graph, int max_streams, int flags, void** out_handle);
 int sba_replay_launch(void* handle, void* stream);
 int sba_replay_info(void* handle, int* info8);
+/* HOST-CALL nodes.  sba_replay_marker launches a no-op kernel carrying `tag` (>= 0) on `stream`; captured into the graph it
+ * becomes a node with the dependencies of its stream position.  A replay does not launch that node: it calls the callback
+ * registered with sba_replay_set_callback -- void fn(int tag, void* stream, void* user) -- with the stream the node was
+ * assigned to, after everything the node depends on has been issued.  The host issues there what cannot be recorded: an
+ * RCCL collective (on its own stream, ordered behind `stream`), the wait for one (make `stream` wait for it), launches
+ * that depend on host state.  This is how the DATA-PARALLEL step is one recording: the gradient exchanges sit between
+ * its launches exactly where the eager step has them.  Without a callback the node is skipped.  info8[7] of
+ * sba_replay_info = the number of such nodes. */
+int sba_replay_marker(int tag, void* stream);
+int sba_replay_set_callback(void* handle, void* fn, void* user);
 int sba_replay_destroy(void* handle);
 /* Training path of the same encoder (DAMSM pre-training, pretrain_DAMSM.py:49-130).
  *   sba_lstm_recur_train: the packed bidirectional recurrence on pre-computed input projections

@@ -39,7 +39,17 @@ struct RNode {
     int record;                   // event index recorded after this node, or -1
     std::vector<int> waits;       // event indices this node's stream waits for first
     bool sink;                    // no successors: the caller's stream must wait for it
+    int marker;                   // >= 0: a host-call node (sba_replay_marker): its tag; the callback runs instead of a launch
 };
+
+// A marker: a no-op kernel whose captured node stands for "call the host here".  Stream capture records it like any
+// launch (with the dependencies of its stream position); a replay calls the registered callback with the node's tag and
+// the stream the node was assigned to -- the host then issues whatever belongs at that point of the step and cannot be
+// recorded: an RCCL collective on the exchange stream (torch.distributed call), the wait for one, an eager launch
+// sequence that depends on host state.  Eagerly (outside capture / replay) the marker is a no-op launch.
+__global__ void sba_replay_marker_kernel(int tag) { (void)tag; }
+
+typedef void (*sba_replay_cb)(int tag, void* stream, void* user);
 
 struct Replayer {
     std::vector<RNode> nodes;     // in issue order (topological)
@@ -48,7 +58,9 @@ struct Replayer {
     hipEvent_t start = nullptr;
     std::vector<int> sink_events; // events recorded after the last node of every stream that ends in a sink
     std::vector<int> tail_event;  // per stream: event recorded at the end of a replay (for the caller to wait on)
-    int n_kernels = 0, n_copies = 0, n_memsets = 0, n_waits = 0;
+    int n_kernels = 0, n_copies = 0, n_memsets = 0, n_waits = 0, n_markers = 0;
+    sba_replay_cb cb = nullptr;
+    void* cb_user = nullptr;
 };
 
 #define RCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
@@ -109,7 +121,7 @@ extern "C" int sba_replay_create(void* hip_graph, int max_streams, int flags, vo
     for (int u : order) {
         RNode r;
         memset(&r.kp, 0, sizeof(r.kp)); memset(&r.cp, 0, sizeof(r.cp)); memset(&r.ms, 0, sizeof(r.ms));
-        r.hfunc = nullptr; r.record = -1; r.sink = succ[u].empty();
+        r.hfunc = nullptr; r.record = -1; r.sink = succ[u].empty(); r.marker = -1;
         if (hipGraphNodeGetType(gn[u], &r.type) != hipSuccess) { delete R; return SBA_E_LAUNCH; }
         if (r.type == hipGraphNodeTypeKernel) {
             if (hipGraphKernelNodeGetParams(gn[u], &r.kp) != hipSuccess) { delete R; return SBA_E_LAUNCH; }
@@ -117,6 +129,10 @@ extern "C" int sba_replay_create(void* hip_graph, int max_streams, int flags, vo
             if (hipGetFuncBySymbol(&f, r.kp.func) != hipSuccess) {      // not a host-side kernel symbol:
                 (void)hipGetLastError();
                 r.hfunc = (hipFunction_t)r.kp.func;                      // the node holds a module function
+            }
+            if (r.kp.func == (void*)sba_replay_marker_kernel && r.kp.kernelParams && r.kp.kernelParams[0]) {
+                r.marker = *reinterpret_cast<int*>(r.kp.kernelParams[0]);
+                ++R->n_markers;
             }
             ++R->n_kernels;
         } else if (r.type == hipGraphNodeTypeMemcpy) {
@@ -236,6 +252,12 @@ extern "C" int sba_replay_launch(void* handle, void* stream) {
         for (int e : r.waits) RCHECK(hipStreamWaitEvent(s, R->events[e], 0));
         switch (r.type) {
             case hipGraphNodeTypeKernel:
+                if (r.marker >= 0) {
+                    // host-call node: everything it depends on has been ISSUED (stream-ordered before s's current
+                    // position); the callback may enqueue on s and make s wait for other streams
+                    if (R->cb) R->cb(r.marker, (void*)s, R->cb_user);
+                    break;
+                }
                 if (r.hfunc)
                     RCHECK(hipModuleLaunchKernel(r.hfunc, r.kp.gridDim.x, r.kp.gridDim.y, r.kp.gridDim.z, r.kp.blockDim.x,
                                                  r.kp.blockDim.y, r.kp.blockDim.z, r.kp.sharedMemBytes, s,
@@ -279,7 +301,22 @@ extern "C" int sba_replay_info(void* handle, int* info8) {
     if (!handle || !info8) return SBA_E_ARG;
     Replayer* R = (Replayer*)handle;
     info8[0] = (int)R->nodes.size(); info8[1] = R->n_kernels; info8[2] = R->n_copies; info8[3] = R->n_memsets;
-    info8[4] = (int)R->streams.size(); info8[5] = R->n_waits; info8[6] = (int)R->events.size(); info8[7] = 0;
+    info8[4] = (int)R->streams.size(); info8[5] = R->n_waits; info8[6] = (int)R->events.size(); info8[7] = R->n_markers;
+    return SBA_OK;
+}
+
+extern "C" int sba_replay_marker(int tag, void* stream) {
+    if (tag < 0) return SBA_E_ARG;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(sba_replay_marker_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, tag);
+    return hipGetLastError() == hipSuccess ? SBA_OK : SBA_E_LAUNCH;
+}
+
+extern "C" int sba_replay_set_callback(void* handle, void* fn, void* user) {
+    if (!handle) return SBA_E_ARG;
+    Replayer* R = (Replayer*)handle;
+    R->cb = (sba_replay_cb)fn;
+    R->cb_user = user;
     return SBA_OK;
 }
 

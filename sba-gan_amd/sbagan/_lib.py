@@ -107,7 +107,9 @@ SIGNATURES = {
     'sba_damsm_words_bwd': [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, P],
     'sba_damsm_prep': [P, P, P, P, L, I, I, I, I, P],
     'sba_damsm_words_fwd_mfma': [P, P, P, P, P, P, P, I, I, I, I, F, F, P],
-    'sba_damsm_words_bwd_mfma': [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, P],
+    'sba_damsm_words_bwd_mfma': [P, P, P, P, P, P, P, P, P, L, P, I, P, I, I, I, I, F, F, P],
+    'sba_ce_pair_direct': [P, P, F, F, P, P, I, P],
+    'sba_damsm_sent_direct': [P, P, P, F, F, F, P, P, I, I, P],
     'sba_damsm_sent_fwd': [P, P, P, I, I, F, F, P],
     'sba_damsm_sent_bwd': [P, P, P, P, P, I, I, F, F, P],
     'sba_ce_pair': [P, P, F, P, P, P, I, P],
@@ -131,6 +133,8 @@ SIGNATURES = {
     'sba_replay_create': [P, I, I, POINTER(c_void_p)],
     'sba_replay_launch': [P, P],
     'sba_replay_info': [P, POINTER(c_int)],
+    'sba_replay_marker': [I, P],
+    'sba_replay_set_callback': [P, P, P],
     'sba_replay_destroy': [P],
 }
 
@@ -144,14 +148,21 @@ lib.sba_det_high_water.restype = c_int64
 lib.sba_det_high_water.argtypes = []
 lib.sba_damsm_prep_bytes.restype = c_int64
 lib.sba_damsm_prep_bytes.argtypes = [I, I, I, I]
+lib.sba_damsm_bwd_bytes.restype = c_int64
+lib.sba_damsm_bwd_bytes.argtypes = [I, I, I, I]
 
 _ERR = {-1: 'SBA_E_ARG (unsupported shape/alignment/enum)', -2: 'SBA_E_LAUNCH (HIP launch failed)',
         -3: 'SBA_E_UNSUPPORTED (graph node kind the replayer cannot re-issue)'}
 
 
+AUDIT_HOOK = None        # sbagan.stream_audit: called with (name, args) before every launch while an audit records
+
+
 def call(name, *args):
     """Invoke a C-ABI entry point; non-zero status becomes RuntimeError (the
     reference surfaces errors as Python exceptions)."""
+    if AUDIT_HOOK is not None:
+        AUDIT_HOOK(name, args)
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError('%s failed: %s' % (name, _ERR.get(rc, rc)))

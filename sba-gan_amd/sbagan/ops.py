@@ -1496,16 +1496,19 @@ def _damsm_words_fwd(prep, feat, words, cap_lens, sim, attn, attn1, wctx, B, nef
              L, g1, g2, st)
 
 
-def _damsm_words_bwd(prep, feat, words, cap_lens, sim, attn, attn1, wctx, dsim, dfeat, dwords, B, nef, R, L, g1, g2, st):
-    """dfeat must be zero-filled (both paths accumulate into it)"""
+def _damsm_words_bwd(prep, feat, words, cap_lens, sim, attn, attn1, wctx, dsim, dwords, B, nef, R, L, g1, g2, st):
+    """returns dfeat (f32, feat's shape); dwords (zero-filled or None) is accumulated into"""
     if prep is not None:
-        dwbuf = torch.empty((B * B, L, nef), dtype=torch.float32, device=feat.device)
-        dsbuf = torch.empty((B * B, L, R), dtype=torch.float32, device=feat.device)
+        nbytes = int(_lib.lib.sba_damsm_bwd_bytes(B, nef, R, L))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=feat.device)
+        dfeat = torch.empty_like(feat)              # (the matrix-core path STORES every element)
         call('sba_damsm_words_bwd_mfma', _p(prep), _p(words), _p(cap_lens), _p(sim), _p(attn), _p(attn1), _p(wctx),
-             _p(dsim), _p(dwbuf), _p(dsbuf), _p(dfeat), _p(dwords), B, nef, R, L, g1, g2, st)
+             _p(dsim), _p(scratch), nbytes, _p(dfeat), 0, _p(dwords), B, nef, R, L, g1, g2, st)
     else:
+        dfeat = torch.zeros_like(feat)
         call('sba_damsm_words_bwd', _p(feat), _p(words), _p(cap_lens), _p(sim), _p(attn), _p(attn1), _p(wctx), _p(dsim),
              _p(dfeat), _p(dwords), B, nef, R, L, g1, g2, st)
+    return dfeat
 
 
 class WordsLossFn(torch.autograd.Function):
@@ -1549,10 +1552,9 @@ class WordsLossFn(torch.autograd.Function):
         gl1 = z if gl1 is None else gl1.reshape(1).float()
         dsim = torch.empty_like(sim)
         call('sba_combine2', _p(dsim), _p(d0), _p(gl0), _p(d1), _p(gl1), B * B, _stream())
-        dfeat = torch.zeros_like(feat)
         dwords = torch.zeros_like(words) if ctx.needs_input_grad[1] else None
-        _damsm_words_bwd(ctx.prep, feat, words, cap_lens, sim, attn, attn1, wctx, dsim, dfeat, dwords, B, nef, R, L,
-                         ctx.g[0], ctx.g[1], _stream())
+        dfeat = _damsm_words_bwd(ctx.prep, feat, words, cap_lens, sim, attn, attn1, wctx, dsim, dwords, B, nef, R, L,
+                                 ctx.g[0], ctx.g[1], _stream())
         return dfeat, dwords, None, None, None
 
 
@@ -1596,12 +1598,11 @@ _LAMBDA_CELL = {}
 
 def damsm_terms_direct(region_features, cnn_code, words_embs, sent_emb, cap_lens, mask, gammas, lam, eps=1e-8):
     """w_loss = LAMBDA (loss0 + loss1) of words_loss, s_loss likewise of sent_loss (losses.py:187-204), TOGETHER WITH
-    their gradients w.r.t. the image-side inputs (region features, global code) -- the kernels of WordsLossFn / SentLossFn
-    called back to back, no autograd in between.  For a frozen text side the upstream gradient of the four cross-entropy
-    terms is the constant LAMBDA, so the ~20 scalar launches autograd issues around the two Functions (adds, the LAMBDA
-    multiplications and their backward, ones / zeros fills) -- half a millisecond of launch gaps on the image encoder's
-    chain, the critical one of the step -- reduce to two `combine2` launches; the loss VALUES are put together after the
-    gradient kernels have been issued.  Same kernels, same operands: bit-identical to the autograd path.
+    their gradients w.r.t. the image-side inputs (region features, global code), no autograd in between.  For a frozen
+    text side the upstream gradient of the four cross-entropy terms is the constant LAMBDA, so the words head is
+    prep (2 launches) -> forward -> cross entropies + their gradient (sba_ce_pair_direct) -> backward (2 launches), the
+    sentence loss ONE launch (sba_damsm_sent_direct): 7 launches on the image encoder's chain -- the critical one of the
+    step -- where the autograd path issues ~35 (scalar adds, LAMBDA multiplications, fills).  B <= 96.
     Returns (w_loss, s_loss, d region_features, d cnn_code)."""
     g1, g2, g3 = gammas
     feat = region_features.detach().float().contiguous()
@@ -1613,10 +1614,6 @@ def damsm_terms_direct(region_features, cnn_code, words_embs, sent_emb, cap_lens
     L = words.shape[2]
     dev = feat.device
     cap_lens = cap_lens.to(device=dev, dtype=torch.int64).contiguous()
-    key = (dev, float(lam))
-    lamt = _LAMBDA_CELL.get(key)
-    if lamt is None:
-        lamt = _LAMBDA_CELL[key] = torch.full((1,), float(lam), dtype=torch.float32, device=dev)
     st = _stream()
     sim = torch.empty((B, B), dtype=torch.float32, device=dev)
     attn = torch.empty((B * B, L, R), dtype=torch.float32, device=dev)
@@ -1624,24 +1621,13 @@ def damsm_terms_direct(region_features, cnn_code, words_embs, sent_emb, cap_lens
     wctx = torch.empty((B * B, L, nef), dtype=torch.float32, device=dev)
     prep = _damsm_prep(feat, words, cap_lens, B, nef, R, L)
     _damsm_words_fwd(prep, feat, words, cap_lens, sim, attn, attn1, wctx, B, nef, R, L, g1, g2, st)
-    wl = torch.empty(2, dtype=torch.float32, device=dev)
-    d0, d1 = torch.empty_like(sim), torch.empty_like(sim)
-    call('sba_ce_pair', _p(sim), _p(mask), g3, _p(wl), _p(d0), _p(d1), B, st)
+    losses = torch.empty(2, dtype=torch.float32, device=dev)        # [w_loss, s_loss], written by the two head kernels
     dsim = torch.empty_like(sim)
-    call('sba_combine2', _p(dsim), _p(d0), _p(lamt), _p(d1), _p(lamt), B * B, st)
-    dfeat = torch.zeros_like(feat)
-    _damsm_words_bwd(prep, feat, words, cap_lens, sim, attn, attn1, wctx, dsim, dfeat, None, B, nef, R, L, g1, g2, st)
-    s = torch.empty((B, B), dtype=torch.float32, device=dev)
-    call('sba_damsm_sent_fwd', _p(cnn), _p(rnn), _p(s), B, nef, g3, eps, st)
-    sl = torch.empty(2, dtype=torch.float32, device=dev)
-    e0, e1 = torch.empty_like(s), torch.empty_like(s)
-    call('sba_ce_pair', _p(s), _p(mask), 1.0, _p(sl), _p(e0), _p(e1), B, st)
-    ds = torch.empty_like(s)
-    call('sba_combine2', _p(ds), _p(e0), _p(lamt), _p(e1), _p(lamt), B * B, st)
-    dcnn = torch.zeros_like(cnn)
-    call('sba_damsm_sent_bwd', _p(cnn), _p(rnn), _p(ds), _p(dcnn), None, B, nef, g3, eps, st)
-    w_loss = (wl[0] + wl[1]) * lam          # (values only: behind the gradient kernels)
-    s_loss = (sl[0] + sl[1]) * lam
+    call('sba_ce_pair_direct', _p(sim), _p(mask), g3, float(lam), _p(losses[0:1]), _p(dsim), B, st)
+    dfeat = _damsm_words_bwd(prep, feat, words, cap_lens, sim, attn, attn1, wctx, dsim, None, B, nef, R, L, g1, g2, st)
+    dcnn = torch.empty_like(cnn)
+    call('sba_damsm_sent_direct', _p(cnn), _p(rnn), _p(mask), g3, eps, float(lam), _p(losses[1:2]), _p(dcnn), B, nef, st)
+    w_loss, s_loss = losses[0], losses[1]
     return w_loss, s_loss, dfeat, dcnn
 
 

@@ -127,6 +127,54 @@ def sort_by_caption_length(captions_lens):
     return torch.sort(captions_lens, 0, True)
 
 
+class _RecordedHandle(object):
+    """what GradExchange.start returns while a step is being RECORDED: the tag of the host-call node that will start
+    the exchange at that point of every replay"""
+    __slots__ = ('tag',)
+
+    def __init__(self, tag):
+        self.tag = tag
+
+
+class ExchangeRecorder(object):
+    """Capture-time stand-in for everything of the data-parallel step that cannot be recorded into the launch replayer's
+    graph -- torch.distributed calls (RCCL collectives are host API calls on their own stream) and launches that depend
+    on host state (the deferred generator update).  While it is installed (GradExchange.recorder), start() / wait() /
+    host() emit a HOST-CALL node (include/sbagan_hip.h: sba_replay_marker) on the current stream and remember what to
+    do there; dispatch() is the replay-time callback: it runs the remembered action on the stream the replayer gave the
+    node, so the exchange sits between the recorded launches exactly where the eager step has it."""
+
+    def __init__(self, exchange):
+        self.exchange = exchange
+        self.calls = []                 # tag -> ('start', tensor) | ('wait', start tag) | ('host', callable)
+        self.live = {}                  # start tag -> handle of the exchange started by the current replay
+
+    def _mark(self, entry):
+        tag = len(self.calls)
+        self.calls.append(entry)
+        call('sba_replay_marker', tag, torch.cuda.current_stream().cuda_stream)
+        return tag
+
+    def start(self, flat_grad):
+        return _RecordedHandle(self._mark(('start', flat_grad)))
+
+    def wait(self, handle):
+        self._mark(('wait', handle.tag))
+
+    def host(self, fn):
+        self._mark(('host', fn))
+
+    def dispatch(self, tag, stream_ptr, device):
+        kind, arg = self.calls[tag]
+        with torch.cuda.stream(torch.cuda.ExternalStream(int(stream_ptr or 0), device=device)):
+            if kind == 'start':
+                self.live[tag] = self.exchange.start(arg)
+            elif kind == 'wait':
+                self.exchange.wait(self.live.pop(arg, None))
+            else:
+                arg()
+
+
 class GradExchange(object):
     """Data-parallel gradient exchange (new functionality; the reference is single-GPU, SURVEY.md
     8e): ONE sum all-reduce per network over its flat f32 gradient buffer, issued on a side
@@ -139,10 +187,13 @@ class GradExchange(object):
         self.world = dist.get_world_size() if self.enabled else 1
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device) if (self.enabled and self.device.type == 'cuda') else None
+        self.recorder = None            # an ExchangeRecorder while a step is being recorded (ReplayedStep)
 
     def start(self, flat_grad):
         if not self.enabled:
             return None
+        if self.recorder is not None:
+            return self.recorder.start(flat_grad)
         if self.stream is None:
             return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=True)
         if dist.get_backend() == 'gloo':
@@ -158,6 +209,9 @@ class GradExchange(object):
 
     def wait(self, handle):
         if handle is None:
+            return
+        if isinstance(handle, _RecordedHandle):
+            self.recorder.wait(handle)
             return
         if isinstance(handle, torch.cuda.Stream):
             torch.cuda.current_stream().wait_stream(handle)
@@ -240,11 +294,32 @@ class GANStep(object):
     def finish(self):
         """Apply a pending generator update (overlapped data-parallel mode: the last step's all-reduce may still be in
         flight and its Adam + EMA step not applied).  Call before reading the generator: checkpoints, sampling,
-        snapshot(); the next step() does it by itself."""
+        snapshot(); the next step() does it by itself.  While the step is being RECORDED (ReplayedStep) this point becomes
+        a host-call node: whether an update is pending is host state, so every replay applies it from the host, here."""
+        rec = self.exchange.recorder
+        if rec is not None:
+            rec.host(self._finish_now)
+            return
+        self._finish_now()
+
+    def _finish_now(self):
         if self._g_pending is not None:
             h, self._g_pending = self._g_pending, None
             self._allreduce_wait(h[0])
             self.optG.step(1.0 / self.world)
+            if self.flatG.packs is not None:        # (eagerly: a recorded generator forward holds no repack of its own)
+                self.flatG.packs.refresh(ops.compute_dtype())
+
+    def _start_g_exchange(self):
+        """start the generator's all-reduce and leave its update pending (host state: under recording a host-call node)"""
+        rec = self.exchange.recorder
+        if rec is not None:
+            rec.host(self._start_g_exchange_now)
+            return
+        self._start_g_exchange_now()
+
+    def _start_g_exchange_now(self):
+        self._g_pending = (self._allreduce_start(self.flatG),)
 
     def drop_pending(self):
         """Wait for a pending generator exchange and DISCARD it without applying the update: the parameters are about to
@@ -483,7 +558,7 @@ class GANStep(object):
         if self.distributed and self.overlap_g:
             # the exchange runs behind this step; the update is applied by the next step (after its text encoder and
             # real-image forwards have been issued) or by finish()
-            self._g_pending = (self._allreduce_start(self.flatG),)
+            self._start_g_exchange()
             self._mark('g_adam')
             ops.ARENA.end()
             ops.SIDE_WGRAD = False
@@ -931,33 +1006,54 @@ class ReplayedStep(object):
     offset that only torch's own graph replay advances): `noise` and `eps` are drawn eagerly by replay().
     Same contract as GraphedStep for parameters changed behind its back (resync())."""
 
+    @staticmethod
+    def warm_up(gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, recorded_prologue=None):
+        """One eager step on a fresh capture stream (per-stream workspaces, packed weights).  Data-parallel: this is the
+        COLLECTIVE-BEARING part of the construction -- callers that fall back when a capture fails run it outside
+        their try block (a rank that threw in here would leave its peers blocked in the step's all-reduces) and pass
+        the result as `warm`."""
+        dev = gan.device
+        eps = torch.empty((noise.shape[-2], cfg.GAN.CONDITION_DIM), dtype=torch.float32, device=dev)
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            noise.normal_(0, 1)
+            eps.normal_(0, 1)
+            if recorded_prologue is not None:
+                recorded_prologue()
+            gan.step(imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, eps=eps)
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        return {'cap': cap, 'eps': eps}
+
     def __init__(self, gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, prologue=None,
-                 recorded_prologue=None, max_streams=None, verbose=False):
+                 recorded_prologue=None, max_streams=None, verbose=False, warm=None):
         """prologue: called eagerly before every replay (after the random draws); recorded_prologue: deterministic
         launches recorded in front of the step (e.g. the frozen text encoder's forward, trainer.py:248-252).
-        max_streams: replay streams; None = SBA_REPLAY_STREAMS from the environment, else 4."""
-        if gan.distributed:
-            raise RuntimeError('ReplayedStep records the whole step; the data-parallel path replays per phase '
-                               '(GraphedStep)')
+        max_streams: replay streams; None = SBA_REPLAY_STREAMS from the environment, else 4.  warm: the result of
+        warm_up() when the caller has run it already."""
+        # Data-parallel (gan.distributed): the SAME single recording -- the gradient exchanges and the deferred generator
+        # update become host-call nodes (ExchangeRecorder): every collective sits between the recorded launches where the
+        # eager data-parallel step has it (buckets under the backward passes, the generator's exchange behind the next
+        # step's real-image forwards), and the phases overlap as on one GPU.  The warm-up step below issues collectives:
+        # every rank must construct the ReplayedStep at the same point.
         self.gan, self.noise, self.prologue = gan, noise, prologue
         dev = gan.device
-        self.eps = torch.empty((noise.shape[-2], cfg.GAN.CONDITION_DIM), dtype=torch.float32, device=dev)
-        self.cap = torch.cuda.Stream(device=dev)
-        self.draw = True
         args = (imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise)
-        self.cap.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.cap):                   # warm the capture stream (workspaces, packed weights)
-            self._draw()
-            if recorded_prologue is not None:
-                recorded_prologue()
-            gan.step(*args, eps=self.eps)
-        torch.cuda.current_stream().wait_stream(self.cap)
-        torch.cuda.synchronize()
+        if warm is None:
+            warm = self.warm_up(gan, *args, recorded_prologue=recorded_prologue)
+        self.eps, self.cap = warm['eps'], warm['cap']
+        self.draw = True
         self.graph = torch.cuda.CUDAGraph(keep_graph=True)
-        with torch.cuda.graph(self.graph, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
-            if recorded_prologue is not None:
-                recorded_prologue()
-            self.out = gan.step(*args, eps=self.eps)
+        self._rec = ExchangeRecorder(gan.exchange) if gan.distributed else None
+        gan.exchange.recorder = self._rec
+        try:
+            with torch.cuda.graph(self.graph, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
+                if recorded_prologue is not None:
+                    recorded_prologue()
+                self.out = gan.step(*args, eps=self.eps)
+        finally:
+            gan.exchange.recorder = None
         torch.cuda.synchronize()
         raw = self.graph.raw_cuda_graph()
         self.handle = ctypes.c_void_p()
@@ -975,7 +1071,21 @@ class ReplayedStep(object):
                                'cannot re-issue' % rc)
         info = (ctypes.c_int * 8)()
         call('sba_replay_info', self.handle, info)
-        self.info = dict(zip(('nodes', 'kernels', 'copies', 'memsets', 'streams', 'waits', 'events'), list(info)))
+        self.info = dict(zip(('nodes', 'kernels', 'copies', 'memsets', 'streams', 'waits', 'events', 'host_calls'),
+                             list(info)))
+        self._cb = self._cb_error = None
+        if self._rec is not None:
+            assert self.info['host_calls'] == len(self._rec.calls), (self.info, len(self._rec.calls))
+            rec, dev_ = self._rec, dev
+
+            def on_marker(tag, stream_ptr, _user):
+                try:
+                    rec.dispatch(tag, stream_ptr, dev_)
+                except BaseException as e:      # (an exception cannot cross the C frame: re-raised by replay())
+                    if self._cb_error is None:
+                        self._cb_error = e
+            self._cb = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)(on_marker)
+            call('sba_replay_set_callback', self.handle, ctypes.cast(self._cb, ctypes.c_void_p), None)
         ops.weights_changed()
 
     def _draw(self):
@@ -988,10 +1098,17 @@ class ReplayedStep(object):
     def resync(self):
         GraphedStep.resync(self)
 
+    def finish(self):
+        """data-parallel: apply the generator update the last replay left pending (GANStep.finish)"""
+        self.gan.finish()
+
     def replay(self):
         ops.weights_changed()
         self._draw()
         call('sba_replay_launch', self.handle, torch.cuda.current_stream().cuda_stream)
+        if self._cb_error is not None:
+            e, self._cb_error = self._cb_error, None
+            raise e
         return self.out
 
     def __del__(self):
@@ -1005,53 +1122,85 @@ class ReplayedStep(object):
 
 
 class ReplayedStepDP(object):
-    """The DATA-PARALLEL step from three recordings re-issued by the native replayer, the gradient exchange between them:
+    """The DATA-PARALLEL step from recordings re-issued by the native replayer, the gradient exchange between them:
 
+        R0  (defer_g) the frozen text encoder + the three discriminators' forward passes on the REAL images, each on its
+            discriminator's stream -- nothing here depends on the generator: it runs while the generator's all-reduce of
+            the PREVIOUS step is still in flight (trainer.py:248-252, losses.py:139)
+        --  (defer_g) wait for that all-reduce; R3 of the previous step: the generator's Adam + EMA step
         R1  generator forward | the three discriminators' loss + backward passes, each on its own stream, forked where
-            its fake image is issued | the image encoder + DAMSM terms beside them
+            its fake image is issued | (unless e_beside_exchange) the image encoder + DAMSM terms beside them
         --  all-reduce of the three discriminators' flat gradient buffers (RCCL, eager, largest first)
+        RE  (e_beside_exchange) image encoder + DAMSM terms, launched while that exchange is in flight
         R2  every discriminator's Adam step and its generator-loss term on its own stream | the generator's backward pass
-        --  all-reduce of the generator's gradients
+        --  all-reduce of the generator's gradients: started, and (defer_g) NOT waited for -- the next replay() or
+            finish() applies the update
         R3  the generator's Adam + EMA step
 
     GraphedStep's per-phase hipGraphs keep every RCCL call exactly where the eager data-parallel step has it (buckets
-    under the backward passes, the generator's exchange under the next step's prologue) but hipGraph launches do not overlap
-    each other on ROCm 7.2, so its phases run back to back: 15.5 ms with one rank against 11.1 ms for the single-GPU
-    replayer.  Here the phases overlap inside a recording as they do on one GPU and the price is an EXPOSED exchange of
-    the discriminators' gradients (382 MB) between R1 and R2.  One grouped real|fake pass and one bucket per discriminator
-    (`overlap_g` / `bucket_d` are switched off on the GANStep).  Opt-in (bench.py: SBA_DP_REPLAY=1): never run on more than
-    one GPU -- no multi-GPU node was available in rounds 1-3."""
+    under the backward passes) but hipGraph launches do not overlap each other on ROCm 7.2, so its phases run back to
+    back: 15.5 ms with one rank against 11.1 ms for the single-GPU replayer.  Here the phases overlap inside a recording
+    as they do on one GPU; the discriminators exchange one bucket each (`bucket_d` off), hidden behind the image encoder
+    with e_beside_exchange.  defer_g = the generator exchange overlapped with the next step's forward work, as the
+    eager data-parallel step (GANStep.overlap_g) and the per-phase graphs do it: the discriminator loss then runs its real
+    and fake halves as two passes.  No multi-GPU node was available in rounds 1-4: RCCL has only ever run with one rank;
+    the two-rank tests (tests/dist_worker.py: gloo, one card) hold every variant bit-identical to the eager step."""
+
+    @classmethod
+    def warm_up(cls, gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, recorded_prologue=None,
+                defer_g=False):
+        """The COLLECTIVE-BEARING part of the construction: set the step's decomposition, run one eager data-parallel step
+        on the capture stream (per-stream workspaces, packed weights).  Every rank must call it; callers that want to fall
+        back when a capture fails call it OUTSIDE their try block and pass the result as `warm` -- an exception in here
+        would leave the peers blocked in the step's all-reduces (the captures themselves issue no collective)."""
+        if not gan.distributed:
+            raise RuntimeError('ReplayedStepDP is the data-parallel launch mode; use ReplayedStep on one GPU')
+        gan.finish()
+        gan.overlap_g = bool(defer_g)
+        gan.bucket_d = False
+        dev = gan.device
+        eps = torch.empty((noise.shape[-2], cfg.GAN.CONDITION_DIM), dtype=torch.float32, device=dev)
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            noise.normal_(0, 1)
+            eps.normal_(0, 1)
+            if recorded_prologue is not None:
+                recorded_prologue()
+            gan.step(imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, eps=eps)
+            gan.finish()
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        return {'cap': cap, 'eps': eps, 'defer_g': bool(defer_g)}
 
     def __init__(self, gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, prologue=None,
-                 recorded_prologue=None, max_streams=4, e_beside_exchange=False):
+                 recorded_prologue=None, max_streams=4, e_beside_exchange=False, defer_g=False, warm=None):
         """e_beside_exchange: the image encoder + DAMSM terms as a recording of their own, launched AFTER the
         discriminators' all-reduces have been started -- they run while the exchange is in flight (hides up to their
         3.3 ms of it) instead of beside the discriminators' backward passes (one rank: 13.5 against 12.1 ms; pays
-        once the exposed exchange exceeds ~1.4 ms)."""
-        if not gan.distributed:
-            raise RuntimeError('ReplayedStepDP is the data-parallel launch mode; use ReplayedStep on one GPU')
+        once the exposed exchange exceeds ~1.4 ms).  defer_g: see the class docstring.  warm: the result of warm_up()."""
+        if warm is None:
+            warm = self.warm_up(gan, imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise,
+                                recorded_prologue=recorded_prologue, defer_g=defer_g)
+        self.defer_g = warm['defer_g']
         self.e_beside_exchange = bool(e_beside_exchange) and gan.early_damsm
-        gan.finish()
-        gan.overlap_g = False
-        gan.bucket_d = False
         self.gan, self.noise, self.prologue = gan, noise, prologue
-        dev = gan.device
-        self.eps = torch.empty((noise.shape[-2], cfg.GAN.CONDITION_DIM), dtype=torch.float32, device=dev)
-        self.cap = torch.cuda.Stream(device=dev)
+        self.eps, self.cap = warm['eps'], warm['cap']
         self.draw = True
+        self._pending = None
         nD = len(gan.netsD)
         streams = gan._d_streams()[:nD]
-        self.cap.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.cap):                   # warm the capture stream (workspaces, packed weights)
-            self._draw()
+
+        def seg0():
             if recorded_prologue is not None:
                 recorded_prologue()
-            gan.step(imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise, eps=self.eps)
-        torch.cuda.current_stream().wait_stream(self.cap)
-        torch.cuda.synchronize()
+            main = torch.cuda.current_stream()
+            gan.phase_pre(imgs, streams)
+            for st in streams:
+                main.wait_stream(st)
 
         def seg1():
-            if recorded_prologue is not None:
+            if recorded_prologue is not None and not self.defer_g:
                 recorded_prologue()
             main = torch.cuda.current_stream()
             ready = [None] * nD
@@ -1103,6 +1252,8 @@ class ReplayedStepDP(object):
         segs = [(seg1, max_streams), (seg2, max_streams), (seg3, 1)]
         if self.e_beside_exchange:
             segs.insert(1, (seg_e, 2))
+        if self.defer_g:
+            segs.insert(0, (seg0, max_streams))
         for fn, ns in segs:
             g = torch.cuda.CUDAGraph(keep_graph=True)
             with torch.cuda.graph(g, stream=self.cap, capture_error_mode=_CAPTURE_MODE):
@@ -1120,10 +1271,23 @@ class ReplayedStepDP(object):
             self.prologue()
 
     def resync(self):
-        GraphedStep.resync(self)
+        GraphedStep.resync(self)        # (drops a pending generator update: see its contract)
+
+    def _apply_pending(self):
+        """on the CURRENT stream: wait for the generator's exchange of the previous replay, then its Adam + EMA step (R3)"""
+        if self._pending is not None:
+            h, self._pending = self._pending, None
+            self.gan._allreduce_wait(h[0])
+            self.replayers[-1].replay()
 
     def finish(self):
-        pass                    # (the generator's update is applied inside replay(): nothing is deferred)
+        """apply a pending generator update (defer_g); a no-op otherwise"""
+        if self._pending is not None:
+            cur = torch.cuda.current_stream()
+            self.cap.wait_stream(cur)
+            with torch.cuda.stream(self.cap):
+                self._apply_pending()
+            cur.wait_stream(self.cap)
 
     def replay(self):
         gan = self.gan
@@ -1132,7 +1296,10 @@ class ReplayedStepDP(object):
         cur = torch.cuda.current_stream()
         self.cap.wait_stream(cur)
         with torch.cuda.stream(self.cap):
-            reps = list(self.replayers)
+            reps = list(self.replayers[:-1])
+            if self.defer_g:
+                reps.pop(0).replay()        # text encoder + netD_i(real_i): beside the generator's exchange in flight
+                self._apply_pending()
             reps.pop(0).replay()
             order = sorted(range(len(gan.flatD)), key=lambda i: -gan.flatD[i].n)       # same order on every rank
             handles = [gan.exchange.start(gan.flatD[i].grad) for i in order]
@@ -1141,7 +1308,11 @@ class ReplayedStepDP(object):
             for h in handles:
                 gan._allreduce_wait(h)
             reps.pop(0).replay()
-            gan._allreduce_wait(gan._allreduce_start(gan.flatG))
-            reps.pop(0).replay()
+            h = gan._allreduce_start(gan.flatG)
+            if self.defer_g:
+                self._pending = (h,)        # applied by the next replay() / finish()
+            else:
+                gan._allreduce_wait(h)
+                self.replayers[-1].replay()
         cur.wait_stream(self.cap)
         return self.out

@@ -250,6 +250,86 @@ def main():
     bad = [(names[i], rel_l2(a.float(), b.float())) for i, (a, b) in enumerate(zip(got, want)) if not torch.equal(a, b)]
     expect(not bad, 'ReplayedStepDP(e_beside_exchange) differs from the eager data-parallel step in %d tensors: %r'
            % (len(bad), bad[:12]))
+    # ---- bench.py's DEFAULT for N > 1: the WHOLE data-parallel step as ONE recording, the exchanges and the deferred generator
+    # update as host-call nodes of the replayer (same decomposition as the eager data-parallel step: two-pass discriminator
+    # loss, D_NET128 / D_NET256 in two buckets): two replays + finish() bit-identical to two eager steps from the same state
+    from sbagan.trainer import ReplayedStep
+    dp.restore(snap_dp)
+    rdp2.resync()
+    dp.overlap_g, dp.bucket_d = True, True
+    for _ in range(2):
+        eager_out = dp.step(*gargs)
+    dp.finish()
+    torch.cuda.synchronize()
+    want = [t.clone() for t in state()]
+    want_out = {k: float(v) for k, v in eager_out.items()}
+    rs = ReplayedStep(dp, *gargs)
+    expect(rs.info['host_calls'] >= 10, 'the recording holds %d host-call nodes' % rs.info['host_calls'])
+    rs.draw = False
+    rs.eps.copy_(eps)
+    noise_in.copy_(noise_keep)
+    dp.restore(snap_dp)
+    rs.resync()
+    rs.replay()
+    expect(dp._g_pending is not None, 'single recording: the generator update was not left pending')
+    rs.replay()
+    rs.finish()
+    torch.cuda.synchronize()
+    got = state()
+    bad = [(names[i], rel_l2(a.float(), b.float())) for i, (a, b) in enumerate(zip(got, want)) if not torch.equal(a, b)]
+    got_out = {k: float(v) for k, v in rs.out.items()}
+    bad_out = [(k, got_out[k], want_out[k]) for k in want_out if got_out[k] != want_out[k]]
+    expect(not bad and not bad_out, 'ReplayedStep (one recording, host-call exchanges) differs from the eager data-parallel '
+           'step in %d tensors: %r; losses %r' % (len(bad), bad[:12], bad_out[:6]))
+    # ---- ReplayedStepDP with the generator's exchange deferred behind the next step's text encoder + real-image
+    # forwards (recording R0), image encoder + DAMSM terms beside the discriminators' exchange.  Same bits as two eager
+    # data-parallel steps with the same decomposition (two-pass discriminator loss, one bucket), and the ORDER north_star
+    # asks for: in the second replay the real-image forwards are issued BEFORE the pending all-reduce is waited for.
+    dp.restore(snap_dp)
+    rdp2.resync()
+    dp.overlap_g, dp.bucket_d = True, False
+    for _ in range(2):
+        eager_out = dp.step(*gargs)
+    dp.finish()
+    torch.cuda.synchronize()
+    want = [t.clone() for t in state()]
+    rdp3 = ReplayedStepDP(dp, *gargs, e_beside_exchange=True, defer_g=True)
+    expect(dp.overlap_g and not dp.bucket_d and len(rdp3.replayers) == 5, 'deferred-update recordings were not captured')
+    rdp3.draw = False
+    rdp3.eps.copy_(eps)
+    noise_in.copy_(noise_keep)
+    dp.restore(snap_dp)
+    rdp3.resync()
+    log = []
+    r0 = rdp3.replayers[0]
+    orig_r0, orig_wait = r0.replay, dp._allreduce_wait
+    r0.replay = lambda: (log.append('real_forwards'), orig_r0())[1]
+
+    def logged_wait(h):
+        log.append('wait')
+        return orig_wait(h)
+    dp._allreduce_wait = logged_wait
+    rdp3.replay()
+    expect(rdp3._pending is not None, 'the generator update of a deferred replay was applied inside replay()')
+    del log[:]
+    rdp3.replay()
+    rdp3.finish()
+    dp._allreduce_wait = orig_wait
+    expect(log[:2] == ['real_forwards', 'wait'], 'the real-image forwards were not issued ahead of the wait for the '
+           'generator exchange in flight: %r' % (log[:6],))
+    torch.cuda.synchronize()
+    got = state()
+    bad = [(names[i], rel_l2(a.float(), b.float())) for i, (a, b) in enumerate(zip(got, want)) if not torch.equal(a, b)]
+    expect(not bad, 'ReplayedStepDP(defer_g) differs from the eager data-parallel step in %d tensors: %r' % (len(bad), bad[:12]))
+    # restore()/resync() DROP a pending update instead of applying it to the restored weights
+    rdp3.replay()
+    expect(rdp3._pending is not None, 'no pending update after a deferred replay')
+    dp.restore(snap_dp)
+    rdp3.resync()
+    expect(rdp3._pending is None and dp._g_pending is None, 'restore / resync left a stale generator update pending')
+    torch.cuda.synchronize()
+    expect(torch.equal(flats_dp[0].data, snap_dp[0]['data']) and torch.equal(dp.optG.state, snap_dp[0]['state']),
+           'the generator changed after restore(): a stale update was applied')
     # generator: its local gradient is taken against the UPDATED (replica-identical) discriminators, so it
     # differs from the single-process run, whose discriminators moved by the local gradient only
     expect(bool(torch.isfinite(out_dp['errG_total'])), 'errG_total not finite')
