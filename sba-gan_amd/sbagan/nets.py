@@ -378,14 +378,16 @@ class _GBase(nn.Module):
     # The style codes w = MAPPING_NET(z) are first read by stage 2 (AdaIN): the mapping network -- a chain of 6 / 8 dense
     # layers of ~13 us each, pure latency -- runs on a side stream beside CA_NET and the whole first stage, and autograd
     # replays its backward pass (another ~160 us chain) on that stream too, beside the first stage's backward pass
-    # instead of at the very end of the generator's.  Same kernels, same operands -- worth 0.2 ms of the 11 ms step -- but
-    # OFF by default: with two mapping calls (G_NET_MIX) `tools/stress_generator_test.py` shows a RACE in eager mode, 4 of
-    # 30 runs with one wrong weight gradient (h_net2.adain2.style.weight, the same wrong value every time), 0 of 30 without
-    # the fork.  SBA_FORK_MAPPING=2 adds `_CrossStream` (record_stream in both directions at the boundary): 0 of 40 in the
-    # same stress run -- an allocator cross-stream reuse hazard -- but that variant has not been through the full GPU
-    # suite yet (the round's GPU budget ended there), so no variant gets the fork by default.
-    fork_mapping = os.environ.get('SBA_FORK_MAPPING', '0') in ('1', '2')
-    _fork_guard = os.environ.get('SBA_FORK_MAPPING', '0') == '2'
+    # instead of at the very end of the generator's.  Same kernels, same operands, worth 0.2-0.4 ms of the 11 ms step.
+    # Round 3 found a RACE in the unguarded fork (SBA_FORK_MAPPING=1: with two mapping calls, G_NET_MIX, 4 of 30 eager
+    # runs produced one wrong weight gradient): the caching allocator re-using a block across the two streams.  The
+    # fork is GUARDED (`_CrossStream`: record_stream in both directions at the stream boundary) and, since round 4, ON by
+    # default: sbagan/stream_audit.py reports the unguarded fork's unjoined cross-stream frees and none for the guarded one
+    # (tests/test_stream_audit_gpu.py::test_audit_flags_the_unguarded_mapping_fork), the whole eager step audits clean for
+    # all three variants, and 40 eager passes per variant are bit-equal to the single-stream pass in the deterministic mode
+    # (::test_mapping_fork_stress_bit_equal).  SBA_FORK_MAPPING=0 turns it off.
+    fork_mapping = os.environ.get('SBA_FORK_MAPPING', '2') in ('1', '2')
+    _fork_guard = os.environ.get('SBA_FORK_MAPPING', '2') == '2'
     on_image = None          # callable(i): called right after fake image i has been issued (the trainer forks the
     #                          update of discriminator i from that point instead of from the end of the forward pass)
 

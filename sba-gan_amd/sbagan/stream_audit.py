@@ -15,9 +15,9 @@ What is recorded (all on the host, in issue order -- no clocks):
     outputs on the current stream; pure view ops are skipped);
   * every torch.cuda.Event.record / Event.wait (Stream.wait_stream / wait_event / record_event are built from these),
     and torch.cuda.synchronize / Stream.synchronize;
-  * the allocator's own trace (torch.cuda.memory._record_memory_history): alloc / free_requested / free_completed with
-    address, size and pool stream.  A block whose free completes LATER than it was requested had stream uses recorded
-    (by Python or by the autograd engine's own record_stream calls): the allocator protects it.
+  * every Tensor.record_stream call (any thread), and the allocator's own trace
+    (torch.cuda.memory._record_memory_history): alloc / free_requested / free_completed with address, size and pool
+    stream.  A block whose free completes LATER than it was requested had stream uses recorded: the allocator protects it.
 The two logs are interleaved exactly by MARKER allocations: after every recorded host event a 1-byte tensor is allocated
 and dropped on a private stream; its trace entries separate the allocator events that happened before the host event
 from those after it.
@@ -38,10 +38,10 @@ _MARK_BYTES = 1
 
 
 class _Block(object):
-    __slots__ = ('addr', 'size', 'stream', 'uses')
+    __slots__ = ('addr', 'size', 'stream', 'uses', 'recorded')
 
     def __init__(self, addr, size, stream):
-        self.addr, self.size, self.stream, self.uses = addr, size, stream, {}
+        self.addr, self.size, self.stream, self.uses, self.recorded = addr, size, stream, {}, set()
 
 
 class StreamAudit(object):
@@ -131,11 +131,19 @@ class StreamAudit(object):
 
         def ssync(st):
             r = o_ssync(st)
-            audit._event(('sync',))         # (conservative the other way would be per-stream; a full sync follows anyway)
+            audit._event(('ssync', st.cuda_stream))
+            return r
+        o_rs = torch.Tensor.record_stream
+
+        def record_stream(t, stream):
+            r = o_rs(t, stream)
+            if t.is_cuda and t.numel() > 0:
+                audit._event(('record_stream', t.data_ptr(), stream.cuda_stream))
             return r
         E.record, E.wait, torch.cuda.synchronize, S.synchronize = record, wait, sync, ssync
+        torch.Tensor.record_stream = record_stream
         self._patched = [(E, 'record', o_rec), (E, 'wait', o_wait), (torch.cuda, 'synchronize', o_sync),
-                         (S, 'synchronize', o_ssync)]
+                         (S, 'synchronize', o_ssync), (torch.Tensor, 'record_stream', o_rs)]
         _lib.AUDIT_HOOK = self._on_call
         if self.torch_ops:
             from torch.utils._python_dispatch import TorchDispatchMode
@@ -149,7 +157,7 @@ class StreamAudit(object):
                             view = any(r.alias_info is not None and not r.alias_info.is_write for r in func._schema.returns)
                         except Exception:
                             view = False
-                        if not view:
+                        if not view and 'record_stream' not in str(func):
                             ptrs = [t.data_ptr() for t in tree_leaves((args, kwargs, out))
                                     if isinstance(t, torch.Tensor) and t.is_cuda and t.numel() > 0]
                             if ptrs:
@@ -231,6 +239,10 @@ class StreamAudit(object):
                         b.uses[s] = (count[s], name)
                         if s != b.stream:
                             stats['foreign_uses'] += 1
+            elif kind == 'record_stream':
+                b = find(ev[1])
+                if b is not None:
+                    b.recorded.add(ev[2])
             elif kind == 'record':
                 c = dict(clock(ev[2]))
                 c[ev[2]] = count.get(ev[2], 0)
@@ -239,6 +251,9 @@ class StreamAudit(object):
                 c = events.get(ev[1])
                 if c is not None:
                     merge(clock(ev[2]), c)
+            elif kind == 'ssync':           # the host waited for ONE stream: everything issued to it so far is done
+                for s in list(count) + [ev[1]]:
+                    clock(s)[ev[1]] = count.get(ev[1], 0)
             elif kind == 'sync':
                 for s in list(count):
                     for s2, n in count.items():
@@ -291,7 +306,8 @@ class StreamAudit(object):
                         stats['deferred_frees'] += 1
                     else:
                         own = clock(b.stream)
-                        foreign = [(s, t, kn) for s, (t, kn) in b.uses.items() if s != b.stream and own.get(s, 0) < t]
+                        foreign = [(s, t, kn) for s, (t, kn) in b.uses.items()
+                                   if s != b.stream and s not in b.recorded and own.get(s, 0) < t]
                         if foreign:
                             stats['frees_with_unjoined_foreign_use'] += 1
                             tainted.append((b.addr, b.addr + b.size, b.stream, foreign, hi))

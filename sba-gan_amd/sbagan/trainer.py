@@ -298,7 +298,7 @@ class GANStep(object):
         a host-call node: whether an update is pending is host state, so every replay applies it from the host, here."""
         rec = self.exchange.recorder
         if rec is not None:
-            rec.host(self._finish_now)
+            rec.host(self._finish_replayed)
             return
         self._finish_now()
 
@@ -307,8 +307,14 @@ class GANStep(object):
             h, self._g_pending = self._g_pending, None
             self._allreduce_wait(h[0])
             self.optG.step(1.0 / self.world)
-            if self.flatG.packs is not None:        # (eagerly: a recorded generator forward holds no repack of its own)
-                self.flatG.packs.refresh(ops.compute_dtype())
+            return True
+        return False
+
+    def _finish_replayed(self):
+        """the host-call node of a recorded step: apply the pending update AND repack the generator's bf16 weight copies --
+        the recorded generator forward holds no repack of its own (at capture time the copies were fresh)"""
+        if self._finish_now() and self.flatG.packs is not None:
+            self.flatG.packs.refresh(ops.compute_dtype())
 
     def _start_g_exchange(self):
         """start the generator's all-reduce and leave its update pending (host state: under recording a host-call node)"""

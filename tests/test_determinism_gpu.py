@@ -207,8 +207,8 @@ def test_dependency_relaxations_do_not_change_a_bit(dev, det, encoder, dt):
         st.restore(snap)
         st.early_g_terms = st.early_d = relaxed
         st.bucket_adam = bucket
-        # (MAPPING_NET on a side stream is NOT part of the set: it is off by default -- a race with two mapping calls,
-        # tools/stress_generator_test.py -- and stays out of the gating tests until that is understood)
+        # MAPPING_NET on its (guarded) side stream belongs to the set since round 4: off in the reference order
+        nets._GBase.fork_mapping = bool(relaxed) and fork_default
         losses.DIRECT_DAMSM = direct
         try:
             out = st.step(*args)

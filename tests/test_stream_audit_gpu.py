@@ -65,7 +65,7 @@ def test_audit_controls(dev):
     else:
         assert stats['frees_with_unjoined_foreign_use'] >= 1, stats
     hz, _, stats = _planted(dev, 'record_stream')
-    assert not hz and stats['deferred_frees'] >= 1, (hz, stats)
+    assert not hz and stats['frees_with_unjoined_foreign_use'] == 0, (hz, stats)
     hz, _, stats = _planted(dev, 'join')
     assert not hz and stats['frees_with_unjoined_foreign_use'] == 0, (hz, stats)
 
