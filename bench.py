@@ -258,14 +258,15 @@ def measure_igemm_kernels(args, dev, step, one_step, dump=None):
     if not dom['n']:
         return None, family
     traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'r03_pmc_dominant_kernel.json')
-    if args.branch == 3 and args.batch == 20 and args.variant == 'model' and os.path.exists(pmc):
-        try:        # rocprofv3 PMC passes over exactly these shapes (tools/pmc_dominant.py; not collectable in-process)
-            rec = json.load(open(pmc))
-            if rec.get('launches_per_step') == dom['n']:
-                traffic = int(rec['traffic_bytes_per_launch'])
-        except (KeyError, ValueError):
-            traffic = None
+    for tag in ('r04', 'r03'):       # the newest committed PMC record whose launch set is the one measured here
+        pmc = os.path.join(ROOT, 'profiles', '%s_pmc_dominant_kernel.json' % tag)
+        if traffic is None and args.branch == 3 and args.batch == 20 and args.variant == 'model' and os.path.exists(pmc):
+            try:    # rocprofv3 PMC passes over exactly these shapes (tools/pmc_dominant.py; not collectable in-process)
+                rec = json.load(open(pmc))
+                if rec.get('launches_per_step') == dom['n']:
+                    traffic = int(rec['traffic_bytes_per_launch'])
+            except (KeyError, ValueError):
+                traffic = None
     ach = dom['fl'] / (dom['t'] * 1e-6) / 1e12
     dominant = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                 'traffic': traffic,

@@ -78,6 +78,10 @@ typedef struct sba_conv_geom {
      * GEMM-like layers' weight gradients are bound by that traffic: 268 MB for D_NET256's widest layer).  Paths
      * that add with atomics ignore it.  0 = always accumulate. */
     int32_t first_write;
+    /* sba_conv_igemm: layout of the packed weights `w`.  0 = row-major [Cout][ntaps][Cin].  1 = FRAGMENT-MAJOR
+     * (sba_pack_frag_multi): accepted only where sba_conv_igemm_plan reports family 0 (the halo-tile 3x3 kernel, bf16,
+     * Cin = 64 or 128, Cout % 64 == 0), which then keeps the weight fragments in registers instead of LDS. */
+    int32_t w_layout;
 } sba_conv_geom;
 #define SBA_IGEMM_TILES 15
 
@@ -147,7 +151,8 @@ int sba_conv_igemm_plan(int dtype, const sba_conv_geom* g, int64_t workspace_byt
  * do not overlap -- as ONE grid (bf16 only, no split-K, no statistics; bias / ReLU (g->relu) / addend /
  * relu_mask per item as in sba_conv_igemm_bias).  For the branches of an Inception block at one depth level (model.py:226-262:
  * the reference runs them one after the other): each alone is 120..273 workgroups of a 64 x 64 tile on 256 CUs.
- * tile: 1 = 64x64, 3 = 96x64, 5 = 128x64 (0 = 1).  The item array is HOST memory, read during the call. */
+ * tile: 1 = 64x64, 3 = 96x64, 5 = 128x64, 7 = 128x128 (0 = 1; 7 falls back to 5 when some Cin % 64 != 0).  The item array
+ * is HOST memory, read during the call. */
 #define SBA_GROUP_MAX 8
 typedef struct sba_conv_group_item {
     const void* x; const void* w; void* y; const void* addend; const float* bias; const void* relu_mask;
@@ -193,6 +198,16 @@ typedef struct sba_pack_desc {
     int32_t co_tiles, ci_tiles;
 } sba_pack_desc;
 int sba_pack_weights_multi(int dtype, const sba_pack_desc* descs, int ndesc, int total_tiles, void* stream);
+/* Row-major packed bf16 conv operands [R][taps][K] (R, K multiples of 64: the outputs of sba_pack_weight /
+ * sba_pack_weights_multi) -> FRAGMENT-MAJOR copies [R/64][K/64][taps][2][4][64][8]: the 64 lanes' 16-byte MFMA B fragments
+ * of one (tap, 32-row tile, 16-deep k-step) contiguous (1 KB), lane = ((k >> 3) & 1) * 32 + (r & 31).  `descs` is a DEVICE
+ * array; one work unit = 16 bytes, tensor d owns units [unit_begin[d], unit_begin[d+1]); total_units = sum R*taps*K/8. */
+typedef struct sba_frag_desc {
+    const void* src;
+    void* dst;
+    int32_t R, taps, K, unit_begin;
+} sba_frag_desc;
+int sba_pack_frag_multi(const sba_frag_desc* descs, int ndesc, int total_units, void* stream);
 /* sum each 2x2 block: dx[n][y][x][c] = sum dup[n][2y+a][2x+b][c] (bwd of nearest x2). */
 int sba_pool2x2_sum(int dtype, const void* dup, void* dx, int N, int H, int W, int C, void* stream);
 

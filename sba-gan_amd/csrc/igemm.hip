@@ -1351,6 +1351,174 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const bf16_t* __restr
 }
 
 // ---------------------------------------------------------------------------
+// Halo-tile 3x3 convolution, third form: WEIGHT FRAGMENTS IN REGISTERS.  PMC of the kernel above on the ResBlock conv
+// (64 -> 64 at 128 x 128, B = 20; profiles/r04_pmc_halo_res128.txt): waves parked at a barrier / s_waitcnt 53 % of their
+// cycles, matrix cores busy 12 %, LDS array active 11 % -- it is bound by the nine per-tap barriers of the
+// double-buffered weight rows and by two workgroups per CU (69 KB of LDS each), not by LDS bandwidth or the MFMAs.
+// Here the weights never enter LDS: they are packed FRAGMENT-MAJOR (sba_pack_frag_multi: the 64 lanes' 16-byte B
+// fragments of one (tap, 32-channel column tile, 16-deep k-step) are 1 KB contiguous), every wave loads the eight
+// fragments of the NEXT tap with eight coalesced 1 KB instructions while it multiplies the current one (they are L1 / L2
+// hits: 72 KB per layer shared by the whole grid), and the main loop has no barrier at all: the halo tile is read-only
+// after the staging barrier.  LDS = the halo tile alone (49 KB; 37 KB behind the nearest x2 upsample): three workgroups
+// per CU, and half the LDS reads per MFMA (A fragments only).
+// ---------------------------------------------------------------------------
+template <int CIN, int UPS>
+__global__ __launch_bounds__(256, 3) void conv3x3_halo3_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wf,
+                                                               bf16_t* __restrict__ y, const bf16_t* __restrict__ addend,
+                                                               float* __restrict__ stats, const sba_conv_geom g,
+                                                               const EpiX ex) {
+    typedef bf16_t T;
+    constexpr int TH = 8, TW = 32, BM = TH * TW, BN = 64;
+    constexpr int PIXB = CIN * 2 + 16;
+    constexpr int HR = UPS ? TH / 2 + 2 : TH + 2, HC = UPS ? TW / 2 + 2 : TW + 2;
+    constexpr int A_BYTES = HR * HC * PIXB;
+    constexpr int OUT_BYTES = BM * (BN * 2 + 16);         // the epilogue's bf16 staging tile reuses the halo buffer
+    constexpr int STAGE = A_BYTES > OUT_BYTES ? A_BYTES : OUT_BYTES;
+    constexpr int TM = 2, TN = 2;
+    constexpr int CPP = CIN / 8;                          // 16-byte chunks per pixel
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STAGE + BM * 4 + BN * 8];
+    unsigned char* const lA = lds;
+    int* rowoff = reinterpret_cast<int*>(lds + STAGE);
+    float* s_stat = reinterpret_cast<float*>(lds + STAGE + BM * 4);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = g.OW / TW, tiles_y = g.OH / TH;
+    const int tx_ = blockIdx.x % tiles_x, ty_ = (blockIdx.x / tiles_x) % tiles_y, n = blockIdx.x / (tiles_x * tiles_y);
+    const int oy0 = ty_ * TH, ox0 = tx_ * TW;
+    const int n_base = blockIdx.y * BN;
+    const int xcs = g.x_cstride ? g.x_cstride : g.Cin;
+    const int ycs = g.y_cstride ? g.y_cstride : g.Cout;
+    rowoff[tid] = (n * g.OH + oy0 + (tid >> 5)) * g.OW + ox0 + (tid & 31);      // BM == 256 threads
+    for (int c = tid; c < 2 * BN; c += 256) s_stat[c] = 0.f;
+
+    constexpr uint32_t OOB = 0xFFFFFFFFu;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    const uint32_t x_bytes = (uint32_t)((int64_t)g.N * g.IH * g.IW * xcs * 2);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
+    const int nchunks = g.Cin / CIN, ntaps_all = 9 * nchunks;
+    const int sy0 = UPS ? (oy0 >> 1) - 1 : oy0 - 1, sx0 = UPS ? (ox0 >> 1) - 1 : ox0 - 1;
+    constexpr int NCH = HR * HC * CPP, NI = (NCH + 255) / 256, HB = 4;
+    auto stage_halo = [&](const int chunk) {
+        const uint32_t cbytes = (uint32_t)(g.x_coff * 2 + chunk * CIN * 2);
+#pragma unroll
+        for (int i0 = 0; i0 < NI; i0 += HB) {
+            u32x4_t hv[HB];
+#pragma unroll
+            for (int u = 0; u < HB; ++u) {
+                const int idx = tid + 256 * (i0 + u);
+                const int p = idx / CPP, ch = idx - p * CPP;
+                const int hr = p / HC, hc = p - hr * HC;
+                const int iy = sy0 + hr, ix = sx0 + hc;
+                const bool ok = i0 + u < NI && idx < NCH && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+                const uint32_t o = ok ? (uint32_t)((n * g.IH + iy) * g.IW + ix) * (uint32_t)(xcs * 2) + cbytes +
+                                            (uint32_t)ch * 16u
+                                      : OOB;
+                hv[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, o, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < HB; ++u) {
+                const int idx = tid + 256 * (i0 + u);
+                const int p = idx / CPP, ch = idx - p * CPP;
+                if (i0 + u < NI && idx < NCH)
+                    *reinterpret_cast<uint4*>(lA + p * PIXB + ch * 16) = make_uint4(hv[u][0], hv[u][1], hv[u][2], hv[u][3]);
+            }
+        }
+    };
+    // weight fragments of (chunk, tap): [n-block][chunk][tap][j][k16][lane][8]
+    struct BFrag { bf16x8_t v[TN][CIN / 16]; };
+    const bf16_t* const wbase = wf + ((int64_t)blockIdx.y * nchunks * 9) * (TN * (CIN / 16) * 512) + lane * 8;
+    auto bload = [&](BFrag& b, const int t) {
+        const bf16_t* p = wbase + (int64_t)t * (TN * (CIN / 16) * 512);      // t = chunk * 9 + tap
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int k = 0; k < CIN / 16; ++k)
+                b.v[j][k] = *reinterpret_cast<const bf16x8_t*>(p + (j * (CIN / 16) + k) * 512);
+    };
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int rl = lane & 31, hf = lane >> 5;
+    // ONE set of weight fragments (32 registers): fragment (j, k16) of the NEXT tap is loaded into its registers right
+    // behind the last MFMA that reads the current tap's -- a 16-MFMA (~0.2 us) head start on an L1 / L2 hit, the other
+    // waves of the SIMD cover the rest (two sets, 64 registers, spilled at three waves per SIMD)
+    BFrag b;
+    bload(b, 0);
+#pragma unroll 1
+    for (int t = 0; t < ntaps_all; ++t) {
+        const int chunk = t / 9, tap = t - chunk * 9;
+        if (tap == 0) {                         // (wave-uniform) a new 64-channel chunk of Cin: (re)stage the halo tile
+            if (chunk) __syncthreads();         // everybody has finished reading the previous chunk's tile
+            stage_halo(chunk);
+            __syncthreads();
+        }
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const unsigned char* ap[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int hr, hc;
+            if (UPS) {
+                hr = ((2 * wid + i + ky - 1) >> 1) + 1;
+                hc = ((rl + kx - 1) >> 1) + 1;
+            } else {
+                hr = 2 * wid + i + ky;
+                hc = rl + kx;
+            }
+            ap[i] = lA + (hr * HC + hc) * PIXB + hf * 16;
+        }
+        const bool more = t + 1 < ntaps_all;
+        const bf16_t* pn = wbase + (int64_t)(more ? t + 1 : t) * (TN * (CIN / 16) * 512);
+#pragma unroll
+        for (int k16 = 0; k16 < CIN / 16; ++k16) {
+            bf16x8_t a[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(ap[i] + k16 * 32);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b.v[j][k16], acc[i][j], 0, 0, 0);
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b.v[j][k16] = *reinterpret_cast<const bf16x8_t*>(pn + (j * (CIN / 16) + k16) * 512);
+            }
+        }
+    }
+    __syncthreads();                            // the epilogue stages through the halo buffer
+    tile_epilogue<T, BM, BN, TM, TN, 256, STAGE>(acc, true, lds, rowoff, s_stat, wid * 64, 0, lane, n_base, ycs, g, y,
+                                                 addend, stats, ex);
+}
+
+// row-major packed conv operand [R][taps][K] (bf16; R, K multiples of 64) -> fragment-major
+// [R/64][K/64][taps][2][4][64 lanes][8]: lane = ((k >> 3) & 1) * 32 + (r & 31).  One thread = 16 bytes.
+__global__ __launch_bounds__(256) void pack_frag_kernel(const sba_frag_desc* __restrict__ descs, const int ndesc,
+                                                        const int total_units) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= total_units) return;
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].unit_begin <= u) lo = mid; else hi = mid - 1;
+    }
+    const sba_frag_desc d = descs[lo];
+    const int local = u - d.unit_begin;
+    const int k8n = d.K / 8;
+    const int k8 = local % k8n, rest = local / k8n;
+    const int t = rest % d.taps, r = rest / d.taps;
+    const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(d.src) + ((int64_t)r * d.taps + t) * d.K + 8 * k8);
+    const int nb = r >> 6, j = (r >> 5) & 1, nn = r & 31, chunk = k8 >> 3, k16 = (k8 >> 1) & 3, gg = k8 & 1, nch = d.K / 64;
+    const int64_t o = ((((((int64_t)nb * nch + chunk) * d.taps + t) * 2 + j) * 4 + k16) * 512) + (gg * 32 + nn) * 8;
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(d.dst) + o) = v;
+}
+
+// ---------------------------------------------------------------------------
 // Persistent halo-tile 3x3 convolution (Cin = 64): the kernel above pays, per 8 x 32 output tile, a serialised
 // prologue (halo staging through registers, first weight tap), nine barriers for the double-buffered weight
 // taps and an epilogue -- 17.8 us per workgroup-round for 5.8 us of MFMA issue.  Here
@@ -2579,6 +2747,11 @@ static void launch_halo(const sba_conv_geom& g, const bf16_t* x, const bf16_t* w
     // BN = 64 for every Cout: the 128-wide variant needs 86 KB of LDS (one workgroup per CU) and
     // measured slower; re-staging the halo tile for the second channel block is cheap
     dim3 grid(tiles, nblocks);
+    if (g.w_layout == 1) {      // fragment-major weights: the register-resident form (geom_ok has checked the layout's needs)
+        if (g.ups) SBA_LAUNCH((conv3x3_halo3_kernel<64, 1>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, ex);
+        else SBA_LAUNCH((conv3x3_halo3_kernel<64, 0>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, ex);
+        return;
+    }
     if (g.ups) SBA_LAUNCH((conv3x3_halo_kernel<64, 64, 1>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, ex);
     else SBA_LAUNCH((conv3x3_halo_kernel<64, 64, 0>), grid, dim3(256), 0, st, x, w, y, addend, stats, g, ex);
 }
@@ -2591,6 +2764,7 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
     // gen 2 (64-channel slabs), 2 LDS-DMA gen 1, 3 register-staged), plan[1] = tile id / configuration, plan[2] = K splits
     const int M = g.N * g.OHs * g.OWs;
     const T* xp = (const T*)x; const T* wp = (const T*)w; T* yp = (T*)y; const T* ap = (const T*)addend;
+    if (g.w_layout != 0 && !(g.w_layout == 1 && sizeof(T) == 2 && halo_ok(g))) return SBA_E_ARG;   // fragment-major weights: halo-tile kernel only
     if (sizeof(T) == 2 && halo_ok(g)) {
         if (plan) { plan[0] = 0; plan[1] = g.ups ? 1 : 0; plan[2] = 1; return SBA_OK; }
         launch_halo(g, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, (const bf16_t*)addend, stats, ex, st);
@@ -2869,13 +3043,14 @@ static int group_dispatch(int dtype, int n, const sba_conv_group_item* items, in
             case 0: case 1: return launch_group<64, 64, 32, 32, 4>(items, n, st, ksplit, ws);
             case 3: return launch_group<96, 64, 32, 64, 3>(items, n, st, ksplit, ws);
             case 5: return launch_group<128, 64, 32, 64, 3>(items, n, st, ksplit, ws);
+            case 7: return launch_group<128, 128, 64, 64, 3>(items, n, st, ksplit, ws);
             default: return SBA_E_ARG;
         }
     }
     switch (tile) {     // some member has Cin % 64 == 32: 32-channel slabs for the whole group
         case 0: case 1: return launch_group<64, 64, 32, 32, 4, 2>(items, n, st);
         case 3: return launch_group<96, 64, 32, 64, 3, 2>(items, n, st);
-        case 5: return launch_group<128, 64, 32, 64, 4, 1>(items, n, st);
+        case 5: case 7: return launch_group<128, 64, 32, 64, 4, 1>(items, n, st);
         default: return SBA_E_ARG;
     }
 }
@@ -3115,6 +3290,12 @@ extern "C" int sba_pack_weights_multi(int dtype, const sba_pack_desc* descs, int
     if (((uintptr_t)descs & 7) != 0) return SBA_E_ARG;
     SBA_DISPATCH(dtype, SBA_LAUNCH((pack_multi_kernel<T>), dim3(total_tiles), dim3(256), 0,
                                            (hipStream_t)stream, descs, ndesc));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_pack_frag_multi(const sba_frag_desc* descs, int ndesc, int total_units, void* stream) {
+    if (!descs || ndesc <= 0 || total_units <= 0 || ((uintptr_t)descs & 7) != 0) return SBA_E_ARG;
+    SBA_LAUNCH(pack_frag_kernel, dim3(cdiv(total_units, 256)), dim3(256), 0, (hipStream_t)stream, descs, ndesc, total_units);
     return SBA_CHECK_LAUNCH();
 }
 

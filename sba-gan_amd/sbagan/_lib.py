@@ -31,7 +31,8 @@ class ConvGeom(Structure):
                 ('ups', c_int32), ('ntaps', c_int32),
                 ('ty', c_int8 * MAX_TAPS), ('tx', c_int8 * MAX_TAPS),
                 ('x_cstride', c_int32), ('x_coff', c_int32), ('y_cstride', c_int32), ('y_coff', c_int32),
-                ('relu', c_int32), ('tile', c_int32), ('ksplit', c_int32), ('first_write', c_int32)]
+                ('relu', c_int32), ('tile', c_int32), ('ksplit', c_int32), ('first_write', c_int32),
+                ('w_layout', c_int32)]
 
 
 class ConvGroupItem(Structure):
@@ -58,6 +59,7 @@ SIGNATURES = {
     'sba_conv_igemm_group_splitk': [I, I, POINTER(ConvGroupItem), I, I, P, L, P],
     'sba_conv_wgrad': [I, P, P, P, G, I, P],
     'sba_pack_weight': [I, P, P, I, I, I, I, I, P],
+    'sba_pack_frag_multi': [P, I, I, P],
     'sba_pack_weights_multi': [I, P, I, I, P],
     'sba_pool2x2_sum': [I, P, P, I, I, I, I, P],
     'sba_bn_stats': [I, P, P, L, I, I, P],

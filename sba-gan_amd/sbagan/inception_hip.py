@@ -23,6 +23,7 @@ BN_EPS = 1e-3
 SAVE_ARGMAX = os.environ.get('SBA_ENC_SAVE_ARGMAX', '1') != '0'    # max-pool forward keeps the window argmax for the backward
 GROUP_MIN_TILES = int(os.environ.get('SBA_ENC_GROUP_MIN_TILES', '512'))
 GROUP_TILE = int(os.environ.get('SBA_ENC_GROUP_TILE', '0'))             # tuning aid: force the grouped launches' tile id
+GROUP_T7_MIN = int(os.environ.get('SBA_ENC_GROUP_T7_MIN', '0'))         # 128 x 128 tiles (tile id 7) when a level has at least this many (0 = never)
 
 
 def _pad32(c):
@@ -244,7 +245,7 @@ class InceptionHIP(object):
                 self._igemm(*part[0])
                 continue
             arr = (ConvGroupItem * len(part))()
-            m128 = m96 = 0
+            m128 = m96 = m7 = 0
             for a, (x_ptr, w, y_ptr, addend_ptr, bias, g, mask_ptr) in zip(arr, part):
                 a.x, a.w, a.y, a.addend = x_ptr, w.data_ptr(), y_ptr, addend_ptr
                 a.bias = None if bias is None else bias.data_ptr()
@@ -254,8 +255,11 @@ class InceptionHIP(object):
                 ny = (g.Cout + 63) // 64
                 m128 += ((M + 127) // 128) * ny
                 m96 += ((M + 95) // 96) * ny
+                m7 += ((M + 127) // 128) * ((g.Cout + 127) // 128)
             # bigger tiles move fewer bytes L2 -> LDS per FLOP; use them when they still fill two workgroups per CU
             tile = 5 if m128 >= GROUP_MIN_TILES else (3 if m96 >= GROUP_MIN_TILES else 1)
+            if GROUP_T7_MIN and m7 >= GROUP_T7_MIN:
+                tile = 7
             if GROUP_TILE:
                 tile = GROUP_TILE
             call('sba_conv_igemm_group', _lib.SBA_BF16, len(part), arr, tile, ops._stream())

@@ -187,6 +187,8 @@ class PackedWeight(object):
         self.group = None
         self._fwd = self._dgrad = None
         self._kf = self._kd = None
+        self._ffwd = self._fdgrad = None        # fragment-major copies (halo-tile 3x3 kernel: weights in registers)
+        self._kff = self._kfd = None
 
     def _key(self, dtype):
         cell = _EPOCH_CELL.get(id(self.param))
@@ -214,6 +216,35 @@ class PackedWeight(object):
             self._kf = k
         return self._fwd
 
+    def fwd_frag(self, dtype):
+        """the forward operand FRAGMENT-MAJOR (include/sbagan_hip.h: sba_pack_frag_multi), or None when the layer does not
+        qualify (bf16, Cin 64 / 128, Cout % 64 == 0, 3 x 3)"""
+        O, I, KH, KW = self.param.shape
+        if not FRAG_WEIGHTS or dtype != torch.bfloat16 or KH != 3 or KW != 3 or I not in (64, 128) or O % 64:
+            return None
+        src = self.fwd(dtype)                   # (refreshes the group, frag copies included, when stale)
+        k = self._key(dtype)
+        if self._kff != k:
+            if self._ffwd is None:
+                self._ffwd = torch.empty(O * 9 * I, dtype=dtype, device=src.device)
+            _pack_frag([(src, self._ffwd, O, 9, I)], src.device)
+            self._kff = k
+        return self._ffwd
+
+    def dgrad_frag(self, dtype, kind):
+        """the data-gradient operand of a stride-1 3 x 3 conv ([Cin][flipped tap][Cout]) fragment-major, or None"""
+        O, I, KH, KW = self.param.shape
+        if not FRAG_WEIGHTS or dtype != torch.bfloat16 or kind != '3x3' or O not in (64, 128) or I % 64:
+            return None
+        src = self.dgrad(dtype, kind)
+        k = self._key(dtype) + (kind,)
+        if self._kfd != k:
+            if self._fdgrad is None:
+                self._fdgrad = torch.empty(O * 9 * I, dtype=dtype, device=src.device)
+            _pack_frag([(src, self._fdgrad, I, 9, O)], src.device)
+            self._kfd = k
+        return self._fdgrad
+
     def dgrad(self, dtype, kind):
         k = self._key(dtype) + (kind,)
         if self._kd != k:
@@ -230,6 +261,32 @@ class PackedWeight(object):
             call('sba_pack_weight', dcode, _p(p), _p(self._dgrad), O, KH, KW, I, mode, _stream())
             self._kd = k
         return self._dgrad
+
+
+FRAG_WEIGHTS = os.environ.get('SBA_FRAG_WEIGHTS', '1') != '0'
+_FRAG_DESC = [('src', '<u8'), ('dst', '<u8'), ('R', '<i4'), ('taps', '<i4'), ('K', '<i4'), ('unit_begin', '<i4')]
+
+
+def _frag_descs(items, device):
+    """device array of sba_frag_desc for items = [(src tensor, dst tensor, R, taps, K)] and the total unit count"""
+    import numpy as np
+    desc = np.zeros(len(items), dtype=np.dtype(_FRAG_DESC, align=True))
+    assert desc.dtype.itemsize == 32
+    units = 0
+    for d, (src, dst, R, taps, K) in zip(desc, items):
+        d['src'], d['dst'], d['R'], d['taps'], d['K'], d['unit_begin'] = src.data_ptr(), dst.data_ptr(), R, taps, K, units
+        units += R * taps * K // 8
+    return torch.from_numpy(desc.view(np.uint8).copy()).to(device), units
+
+
+def _pack_frag(items, device):
+    descs, units = _frag_descs(items, device)
+    call('sba_pack_frag_multi', descs.data_ptr(), len(items), units, _stream())
+    _KEEP_DESC.append(descs)
+    del _KEEP_DESC[:-64]
+
+
+_KEEP_DESC = []         # descriptor arrays of the un-grouped path stay alive until their launch has surely run
 
 
 class PackGroup(object):
@@ -284,6 +341,22 @@ class PackGroup(object):
         st['descs'] = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
         st['ptrs'] = [pw.param.data_ptr() for pw, _ in self.layers]
         st['tiles'] = tiles
+        # fragment-major copies of the 3 x 3 layers the halo-tile kernel serves (ONE more launch per refresh)
+        st['frag'] = None
+        if FRAG_WEIGHTS and dtype == torch.bfloat16:
+            items = []
+            for pw, kind in self.layers:
+                O, I, KH, KW = pw.param.shape
+                if kind != '3x3' or KH != 3:
+                    continue
+                if I in (64, 128) and O % 64 == 0:
+                    pw._ffwd = torch.empty(O * 9 * I, dtype=dtype, device=dev)
+                    items.append((pw._fwd, pw._ffwd, O, 9, I))
+                if kind == '3x3' and O in (64, 128) and I % 64 == 0:
+                    pw._fdgrad = torch.empty(O * 9 * I, dtype=dtype, device=dev)
+                    items.append((pw._dgrad, pw._fdgrad, I, 9, O))
+            if items:
+                st['frag'] = _frag_descs(items, dev) + (len(items),)
         self.state = {dtype: st}        # one compute dtype at a time (the views above belong to it)
         return st
 
@@ -296,9 +369,13 @@ class PackGroup(object):
                 raise RuntimeError('conv parameters must be stored channels_last (use sbagan layers)')
         dcode = _lib.SBA_BF16 if dtype == torch.bfloat16 else _lib.SBA_F32
         call('sba_pack_weights_multi', dcode, st['descs'].data_ptr(), len(self.layers), st['tiles'], _stream())
+        if st.get('frag') is not None:
+            fd, units, nfrag = st['frag']
+            call('sba_pack_frag_multi', fd.data_ptr(), nfrag, units, _stream())
         for pw, kind in self.layers:
             k = pw._key(dtype)
             pw._kf, pw._kd = k, k + (kind,)
+            pw._kff, pw._kfd = k, k + (kind,)
 
 
 class ZeroArena(object):
@@ -423,10 +500,30 @@ def tune_geom(g, dt):
         IGEMM_LOG.append(g)
 
 
-def _igemm(dt, x, w, y, addend, stats, g, device):
+def _igemm(dt, x, w, y, addend, stats, g, device, w_frag=None):
+    """w_frag: the fragment-major copy of `w` (or None): used when the geometry goes to the halo-tile 3 x 3 kernel"""
     ws = workspace(device)
     tune_geom(g, _lib.SBA_BF16 if dt == _lib.SBA_BF16_YH else dt)
-    call('sba_conv_igemm', dt, x, w, y, addend, stats, ctypes.byref(g), ws.data_ptr(), WORKSPACE_BYTES, _stream())
+    g.w_layout = 0
+    if w_frag is not None and _halo_family(g):
+        w, g.w_layout = w_frag.data_ptr(), 1
+    try:
+        call('sba_conv_igemm', dt, x, w, y, addend, stats, ctypes.byref(g), ws.data_ptr(), WORKSPACE_BYTES, _stream())
+    finally:
+        g.w_layout = 0
+
+
+def _halo_family(g):
+    """does sba_conv_igemm send this (bf16) geometry to the halo-tile 3 x 3 kernel?  (asked once per geometry object)"""
+    h = getattr(g, '_halo', None)
+    if h is None:
+        plan = (ctypes.c_int * 3)()
+        old = g.w_layout
+        g.w_layout = 0
+        call('sba_conv_igemm_plan', _lib.SBA_BF16, ctypes.byref(g), WORKSPACE_BYTES, plan)
+        g.w_layout = old
+        h = g._halo = plan[0] == 0
+    return h
 
 
 # ----------------------------------------------------------------------------
@@ -447,7 +544,11 @@ def conv_forward(x, pw, kind, want_stats=True, addend=None, pre_bn=False):
         y = empty_act(N, O, OH, OW, x)
     stats = zeros_f32((BN_STAT_SLOTS, 2 * O), x.device) if want_stats else None
     g = _geom((kind, N, H, W, Cin, O, None))
-    _igemm(_lib.SBA_BF16_YH if yh else _dt(x), _p(x), _p(pw.fwd(x.dtype)), _p(y), _p(addend), _p(stats), g, x.device)
+    # (behind the nearest x2 upsample the register-weight kernel measured no faster than the LDS-weight one at four
+    #  workgroups per CU -- G3.up 124.5 vs 124.9 us, it is bound by its 335 MB of output -- so '3x3up' keeps row-major weights)
+    wf = pw.fwd_frag(x.dtype) if kind == '3x3' else None
+    _igemm(_lib.SBA_BF16_YH if yh else _dt(x), _p(x), _p(pw.fwd(x.dtype)), _p(y), _p(addend), _p(stats), g, x.device,
+           w_frag=wf)
     return y, stats
 
 
@@ -460,7 +561,7 @@ def conv_dgrad(dy, pw, kind, in_hw, addend=None):
     if kind == '3x3':
         g = _geom(('3x3', N, OH, OW, O, I, None))
         dx = empty_act(N, I, H, W, dy)
-        _igemm(_dt(dy), _p(dy), _p(wd), _p(dx), _p(addend), None, g, dy.device)
+        _igemm(_dt(dy), _p(dy), _p(wd), _p(dx), _p(addend), None, g, dy.device, w_frag=pw.dgrad_frag(dy.dtype, kind))
         return dx
     if kind == '3x3up':
         # every source pixel collects a 4x4 window of dy with the tap sums packed by mode 3: one stride-2

@@ -324,7 +324,7 @@ def _golden_case_body(dev, dt, case, launch, golden_dir, det, img_l2=None, loss_
             report['s%d/%s' % (step, k)] = rel
             tolk = base * (3 if k.startswith('gnorm') else 1)
             if k == 'gnormG' and not step:
-                tolk = GNORM_G_TOL[dt] * (0.25 if B == 20 else 1)
+                tolk = GNORM_G_TOL[dt] * (0.25 if (B == 20 and loss_tol is None) else 1)   # (bert / mix at B = 20: f32 6e-4)
             if step and k == 'gnormG':
                 # ill-conditioned: the same step evaluated in float64 differs from the reference's float32 value
                 # by 2.2e-2 (bert; profiles/r02_conditioning.txt, tools/conditioning.py) -- rounding noise through

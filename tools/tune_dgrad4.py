@@ -67,7 +67,7 @@ def main():
             g0 = ops._geom(('4x4s2_dgrad', n, oh, oh, cout, cin, (0, 0)))
             ns64 = 4 * (cout // 64)
             best = None
-            for tile in (1, 3, 5):
+            for tile in (1, 3, 5, 7):
                 for split in (1, 2, 3, 4, 6, 8):
                     if split > 1 and (ns64 // split < 4 or n * oh * oh > 4096):
                         continue
