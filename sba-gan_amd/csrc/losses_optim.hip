@@ -61,6 +61,25 @@ __global__ void adam_prepare_kernel(AdamState* st, float lr, float beta1, float 
     }
 }
 
+// NT: non-temporal loads and stores.  The update of D_NET256 streams 2 GB (28 B per parameter) through a 32 MB L2 while two
+// or three other chains of the step run beside it: with ordinary accesses it evicts their working sets and the small
+// latency-bound launches next to it stretch 5-10x (profiles/r04_step_inception_v1_timeline.txt: a 7 us global-average-pool
+// backward at 292 us, a 36 us stem data gradient at 387 us, a 10 us 8x8 conv at 280 us while adam_step runs).  Nothing in
+// the update is read twice, so every access is marked streaming.  MEASURED (same box, two runs each,
+// gpurun_out/r4_ab_adam_nt*.json): 10.54 / 10.69 ms with, 10.59 / 10.67 ms without -- no difference: the neighbours are
+// slowed by the HBM queues, not by L2 evictions.  Kept (harmless, SBA_ADAM_NT=0 turns it off).
+template <bool NT>
+__device__ __forceinline__ f32x4_t ld4(const float* a, int64_t i) {
+    const f32x4_t* q = reinterpret_cast<const f32x4_t*>(a) + i;
+    return NT ? __builtin_nontemporal_load(q) : *q;
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float* a, int64_t i, f32x4_t x) {
+    f32x4_t* q = reinterpret_cast<f32x4_t*>(a) + i;
+    if (NT) __builtin_nontemporal_store(x, q); else *q = x;
+}
+
+template <bool NT>
 __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, float* __restrict__ avg, bf16_t* __restrict__ shadow,
                                  const AdamState* __restrict__ st, int64_t n, float beta1, float beta2, float eps,
@@ -69,11 +88,11 @@ __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict_
     const int64_t n4 = n / 4;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
          i += (int64_t)gridDim.x * blockDim.x) {
-        float4 pv = reinterpret_cast<float4*>(p)[i];
-        const float4 gv = reinterpret_cast<const float4*>(g)[i];
-        float4 mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
-        float4 av;
-        if (avg) av = reinterpret_cast<float4*>(avg)[i];
+        f32x4_t pv = ld4<NT>(p, i);
+        const f32x4_t gv = ld4<NT>(g, i);
+        f32x4_t mv = ld4<NT>(m, i), vv = ld4<NT>(v, i);
+        f32x4_t av;
+        if (avg) av = ld4<NT>(avg, i);
         float* pp = (float*)&pv; const float* gp = (const float*)&gv;
         float* mp = (float*)&mv; float* vp = (float*)&vv; float* ap = (float*)&av;
 #pragma unroll
@@ -85,10 +104,10 @@ __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict_
             pp[k] -= step_size * mp[k] / denom;
             if (avg) ap[k] = 0.999f * ap[k] + 0.001f * pp[k];
         }
-        reinterpret_cast<float4*>(p)[i] = pv;
-        reinterpret_cast<float4*>(m)[i] = mv;
-        reinterpret_cast<float4*>(v)[i] = vv;
-        if (avg) reinterpret_cast<float4*>(avg)[i] = av;
+        st4<NT>(p, i, pv);
+        st4<NT>(m, i, mv);
+        st4<NT>(v, i, vv);
+        if (avg) st4<NT>(avg, i, av);
         if (shadow) {
             ushort4 s;
             s.x = f2bf(pp[0]); s.y = f2bf(pp[1]); s.z = f2bf(pp[2]); s.w = f2bf(pp[3]);
@@ -149,8 +168,14 @@ extern "C" int sba_adam_step(float* p, const float* g, float* m, float* v, float
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    SBA_LAUNCH(adam_step_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, avg,
-                       (bf16_t*)shadow, (const AdamState*)state, n, beta1, beta2, eps, grad_scale);
+    static int nt = -1;         // SBA_ADAM_NT=0: ordinary (cached) accesses (A/B aid)
+    if (nt < 0) { const char* e = getenv("SBA_ADAM_NT"); nt = (e && e[0] == '0') ? 0 : 1; }
+    if (nt)
+        SBA_LAUNCH(adam_step_kernel<true>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, avg,
+                   (bf16_t*)shadow, (const AdamState*)state, n, beta1, beta2, eps, grad_scale);
+    else
+        SBA_LAUNCH(adam_step_kernel<false>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, avg,
+                   (bf16_t*)shadow, (const AdamState*)state, n, beta1, beta2, eps, grad_scale);
     return SBA_CHECK_LAUNCH();
 }
 
