@@ -716,19 +716,24 @@ __global__ __launch_bounds__(1024) void damsm_sent_direct_kernel(const float* __
     }
     __syncthreads();
     if (!dcnn) return;
+    // the two coefficients of every pair once (they were recomputed -- two square roots, three divisions -- for each of the
+    // nef channels): k0 -> s[p], ka -> w12[p]
+    for (int p = tid; p < B * B; p += blockDim.x) {
+        const int j = p / B, i = p - j * B;
+        const float den = sqrtf(nc[j]) * sqrtf(nr[i]);
+        const bool clamped = den < eps;
+        const float gq = ds[p] * gamma3;
+        const float k0 = gq / fmaxf(den, eps);
+        const float ka = clamped ? 0.f : gq * (w12[p] / den) / nc[j];
+        s[p] = k0;
+        w12[p] = ka;
+    }
+    __syncthreads();
     for (int o = tid; o < B * nef; o += blockDim.x) {
         const int j = o / nef, c = o - j * nef;
         const float a = cnn[o];
         float acc = 0.f;
-        for (int i = 0; i < B; ++i) {
-            const int p = j * B + i;
-            const float den = sqrtf(nc[j]) * sqrtf(nr[i]);
-            const bool clamped = den < eps;
-            const float gq = ds[p] * gamma3;
-            const float k0 = gq / fmaxf(den, eps);
-            const float ka = clamped ? 0.f : gq * (w12[p] / den) / nc[j];
-            acc += k0 * rnn[(int64_t)i * nef + c] - ka * a;
-        }
+        for (int i = 0; i < B; ++i) acc += s[j * B + i] * rnn[(int64_t)i * nef + c] - w12[j * B + i] * a;
         dcnn[o] = acc;
     }
 }

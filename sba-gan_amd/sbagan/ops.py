@@ -1695,6 +1695,14 @@ class SentLossFn(torch.autograd.Function):
 
 
 _LAMBDA_CELL = {}
+_DAMSM_SIDE = {}
+
+
+def _damsm_side_stream(dev):
+    s = _DAMSM_SIDE.get(dev)
+    if s is None:
+        s = _DAMSM_SIDE[dev] = torch.cuda.Stream(device=dev)
+    return s
 
 
 def damsm_terms_direct(region_features, cnn_code, words_embs, sent_emb, cap_lens, mask, gammas, lam, eps=1e-8):
@@ -1716,18 +1724,26 @@ def damsm_terms_direct(region_features, cnn_code, words_embs, sent_emb, cap_lens
     dev = feat.device
     cap_lens = cap_lens.to(device=dev, dtype=torch.int64).contiguous()
     st = _stream()
+    losses = torch.empty(2, dtype=torch.float32, device=dev)        # [w_loss, s_loss], written by the two head kernels
+    dcnn = torch.empty_like(cnn)
+    # the sentence loss depends on nothing of the words path: a one-workgroup launch (96 us inside the step) -- on a side
+    # stream, beside the words kernels; joined below (its outputs were allocated above, on this stream, and outlive the join)
+    cur = torch.cuda.current_stream()
+    side = _damsm_side_stream(dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        call('sba_damsm_sent_direct', _p(cnn), _p(rnn), _p(mask), g3, eps, float(lam), _p(losses[1:2]), _p(dcnn), B, nef,
+             _stream())
     sim = torch.empty((B, B), dtype=torch.float32, device=dev)
     attn = torch.empty((B * B, L, R), dtype=torch.float32, device=dev)
     attn1 = torch.empty((B * B, L, R), dtype=torch.float32, device=dev)
     wctx = torch.empty((B * B, L, nef), dtype=torch.float32, device=dev)
     prep = _damsm_prep(feat, words, cap_lens, B, nef, R, L)
     _damsm_words_fwd(prep, feat, words, cap_lens, sim, attn, attn1, wctx, B, nef, R, L, g1, g2, st)
-    losses = torch.empty(2, dtype=torch.float32, device=dev)        # [w_loss, s_loss], written by the two head kernels
     dsim = torch.empty_like(sim)
     call('sba_ce_pair_direct', _p(sim), _p(mask), g3, float(lam), _p(losses[0:1]), _p(dsim), B, st)
     dfeat = _damsm_words_bwd(prep, feat, words, cap_lens, sim, attn, attn1, wctx, dsim, None, B, nef, R, L, g1, g2, st)
-    dcnn = torch.empty_like(cnn)
-    call('sba_damsm_sent_direct', _p(cnn), _p(rnn), _p(mask), g3, eps, float(lam), _p(losses[1:2]), _p(dcnn), B, nef, st)
+    cur.wait_stream(side)
     w_loss, s_loss = losses[0], losses[1]
     return w_loss, s_loss, dfeat, dcnn
 
