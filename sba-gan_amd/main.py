@@ -3,11 +3,7 @@
     python main.py --cfg cfg/bird_style.yml --gpu 0 --data_dir ../data/birds [--manualSeed N]
 
 cfg.TRAIN.FLAG: train; otherwise cfg.B_VALIDATION ? sampling(split) : gen_example(example_filenames.txt)."""
-import argparse
-import datetime
 import os
-import pprint
-import random
 import sys
 import time
 
@@ -19,17 +15,12 @@ if _HERE not in sys.path:
     sys.path.insert(0, _HERE)
 
 from datasets import TextDataset, tokenize  # noqa: E402
-from miscc import transforms  # noqa: E402
-from miscc.config import cfg, cfg_from_file  # noqa: E402
+from miscc import cli, transforms  # noqa: E402
+from miscc.config import cfg  # noqa: E402
 
 
 def parse_args(argv=None):
-    parser = argparse.ArgumentParser(description='Train a AttnGAN network')
-    parser.add_argument('--cfg', dest='cfg_file', help='optional config file', default='cfg/bird_attn2.yml', type=str)
-    parser.add_argument('--gpu', dest='gpu_id', type=int, default=0)
-    parser.add_argument('--data_dir', dest='data_dir', type=str, default='')
-    parser.add_argument('--manualSeed', type=int, help='manual seed')
-    return parser.parse_args(argv)
+    return cli.options('Train a AttnGAN network', 'cfg/bird_attn2.yml', argv)
 
 
 def _encode_sentences(path, wordtoix):
@@ -66,42 +57,22 @@ def gen_example(wordtoix, algo):
 
 def main(argv=None):
     args = parse_args(argv)
-    if args.cfg_file is not None:
-        cfg_from_file(args.cfg_file)
-    if args.gpu_id != -1:
-        cfg.GPU_ID = args.gpu_id
-    else:
-        raise RuntimeError('--gpu -1 (CPU): the HIP modules have no CPU path; the CPU restatement of the step is '
-                           'the test oracle (oracle/), not a product path')
-    if args.data_dir != '':
-        cfg.DATA_DIR = args.data_dir
-    print('Using config:')
-    pprint.pprint(cfg)
-    if not cfg.TRAIN.FLAG:
-        args.manualSeed = 100
-    elif args.manualSeed is None:
-        args.manualSeed = random.randint(1, 10000)
-    random.seed(args.manualSeed)
-    np.random.seed(args.manualSeed)
-    torch.manual_seed(args.manualSeed)
-    torch.cuda.manual_seed_all(args.manualSeed)
-    timestamp = datetime.datetime.now().strftime('%Y_%m_%d_%H_%M_%S')
-    output_dir = '../output/%s_%s_%s' % (cfg.DATASET_NAME, cfg.CONFIG_NAME, timestamp)
-    split_dir, bshuffle = 'train', True
-    if not cfg.TRAIN.FLAG:
-        split_dir = 'test'
-    imsize = cfg.TREE.BASE_SIZE * (2 ** (cfg.TREE.BRANCH_NUM - 1))
+    cli.configure(args)
+    output_dir = cli.output_dir()
+    training = bool(cfg.TRAIN.FLAG)
+    split_dir = 'train' if training else 'test'
+    imsize = cli.image_size()
     image_transform = transforms.Compose([transforms.Resize(int(imsize * 76 / 64)), transforms.RandomCrop(imsize),
                                           transforms.RandomHorizontalFlip()])
     dataset = TextDataset(cfg.DATA_DIR, split_dir, base_size=cfg.TREE.BASE_SIZE, transform=image_transform)
     assert dataset
     dataloader = torch.utils.data.DataLoader(dataset, batch_size=cfg.TRAIN.BATCH_SIZE, drop_last=True,
-                                             shuffle=bshuffle, num_workers=int(cfg.WORKERS))
+                                             shuffle=True, num_workers=int(cfg.WORKERS))
     print(len(dataloader))
     from trainer import condGANTrainer as trainer
     algo = trainer(output_dir, dataloader, dataset.n_words, dataset.ixtoword)
     start_t = time.time()
-    if cfg.TRAIN.FLAG:
+    if training:
         algo.train()
     elif cfg.B_VALIDATION:
         algo.sampling(split_dir)

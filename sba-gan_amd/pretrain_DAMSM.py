@@ -4,15 +4,10 @@
 
 train / evaluate / build_models keep the reference's signatures; the per-batch work is sbagan.damsm.DAMSMStep
 (HIP kernels).  The attention-map PNGs of the reference's logging (build_super_images) are out of scope."""
-import argparse
-import datetime
 import os
-import pprint
-import random
 import sys
 import time
 
-import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -20,8 +15,8 @@ if _HERE not in sys.path:
     sys.path.insert(0, _HERE)
 
 from datasets import TextDataset, prepare_data  # noqa: E402
-from miscc import transforms  # noqa: E402
-from miscc.config import cfg, cfg_from_file  # noqa: E402
+from miscc import cli, transforms  # noqa: E402
+from miscc.config import cfg  # noqa: E402
 from miscc.utils import mkdir_p  # noqa: E402
 from model import CNN_ENCODER, RNN_ENCODER  # noqa: E402
 
@@ -29,12 +24,7 @@ UPDATE_INTERVAL = 50
 
 
 def parse_args(argv=None):
-    parser = argparse.ArgumentParser(description='Train a DAMSM network')
-    parser.add_argument('--cfg', dest='cfg_file', help='optional config file', default='cfg/DAMSM/bird.yml', type=str)
-    parser.add_argument('--gpu', dest='gpu_id', type=int, default=0)
-    parser.add_argument('--data_dir', dest='data_dir', type=str, default='')
-    parser.add_argument('--manualSeed', type=int, help='manual seed')
-    return parser.parse_args(argv)
+    return cli.options('Train a DAMSM network', 'cfg/DAMSM/bird.yml', argv)
 
 
 def train(dataloader, cnn_model, rnn_model, batch_size, labels, optimizer, epoch, ixtoword, image_dir,
@@ -91,12 +81,10 @@ def build_models(n_words, batch_size):
     if cfg.TRAIN.NET_E != '':
         text_encoder.load_state_dict(torch.load(cfg.TRAIN.NET_E, map_location='cpu'))
         print('Load ', cfg.TRAIN.NET_E)
-        name = cfg.TRAIN.NET_E.replace('text_encoder', 'image_encoder')
+        name = cfg.TRAIN.NET_E.replace('text_encoder', 'image_encoder')     # (the pair is saved side by side)
         image_encoder.load_state_dict(torch.load(name, map_location='cpu'))
         print('Load ', name)
-        istart = cfg.TRAIN.NET_E.rfind('_') + 8
-        iend = cfg.TRAIN.NET_E.rfind('.')
-        start_epoch = int(cfg.TRAIN.NET_E[istart:iend]) + 1
+        start_epoch = cli.epoch_of(cfg.TRAIN.NET_E) + 1                     # text_encoder<epoch>.pth
         print('start_epoch', start_epoch)
     dev = torch.device('cuda', cfg.GPU_ID)
     return text_encoder.to(dev), image_encoder.to(dev), labels.to(dev), start_epoch
@@ -104,30 +92,13 @@ def build_models(n_words, batch_size):
 
 def main(argv=None, max_steps=None):
     args = parse_args(argv)
-    if args.cfg_file is not None:
-        cfg_from_file(args.cfg_file)
-    if args.gpu_id == -1:
-        raise RuntimeError('--gpu -1: the HIP modules have no CPU path')
-    cfg.GPU_ID = args.gpu_id
-    if args.data_dir != '':
-        cfg.DATA_DIR = args.data_dir
-    print('Using config:')
-    pprint.pprint(cfg)
-    if not cfg.TRAIN.FLAG:
-        args.manualSeed = 100
-    elif args.manualSeed is None:
-        args.manualSeed = random.randint(1, 10000)
-    random.seed(args.manualSeed)
-    np.random.seed(args.manualSeed)
-    torch.manual_seed(args.manualSeed)
-    torch.cuda.manual_seed_all(args.manualSeed)
-    timestamp = datetime.datetime.now().strftime('%Y_%m_%d_%H_%M_%S')
-    output_dir = '../output/%s_%s_%s' % (cfg.DATASET_NAME, cfg.CONFIG_NAME, timestamp)
+    cli.configure(args)
+    output_dir = cli.output_dir()
     model_dir, image_dir = os.path.join(output_dir, 'Model'), os.path.join(output_dir, 'Image')
     mkdir_p(model_dir)
     mkdir_p(image_dir)
     torch.cuda.set_device(cfg.GPU_ID)
-    imsize = cfg.TREE.BASE_SIZE * (2 ** (cfg.TREE.BRANCH_NUM - 1))
+    imsize = cli.image_size()
     batch_size = cfg.TRAIN.BATCH_SIZE
     image_transform = transforms.Compose([transforms.Scale(int(imsize * 76 / 64)), transforms.RandomCrop(imsize),
                                           transforms.RandomHorizontalFlip()])
