@@ -79,8 +79,9 @@ typedef struct sba_conv_geom {
      * that add with atomics ignore it.  0 = always accumulate. */
     int32_t first_write;
     /* sba_conv_igemm: layout of the packed weights `w`.  0 = row-major [Cout][ntaps][Cin].  1 = FRAGMENT-MAJOR
-     * (sba_pack_frag_multi): accepted only where sba_conv_igemm_plan reports family 0 (the halo-tile 3x3 kernel, bf16,
-     * Cin = 64 or 128, Cout % 64 == 0), which then keeps the weight fragments in registers instead of LDS. */
+     * (sba_pack_frag_multi): accepted only where sba_conv_igemm_plan (asked with w_layout = 1) reports family 0 or 4 -- the
+     * halo-tile 3x3 kernels, bf16, stride 1, the nine taps = the nine cells of a 3 x 3 window, Cin % 32 == 0,
+     * Cout % 32 == 0, no statistics for family 4 -- which keep the weight fragments in registers instead of LDS. */
     int32_t w_layout;
 } sba_conv_geom;
 #define SBA_IGEMM_TILES 15
@@ -144,7 +145,8 @@ int sba_conv_igemm_bias(int dtype, const void* x, const void* w, void* y, const 
                         float* stats, const float* bias, const void* relu_mask, const sba_conv_geom* g,
                         void* workspace, int64_t workspace_bytes, void* stream);
 /* Which kernel sba_conv_igemm launches for a geometry (nothing is launched; measurement / reporting aid):
- * plan[0] = family (0 halo-tile 3x3 conv3x3_halo_kernel, 1 igemm_dma2_kernel, 2 igemm_dma_kernel, 3 igemm_kernel),
+ * plan[0] = family (0 halo-tile 3x3 conv3x3_halo_kernel, 1 igemm_dma2_kernel, 2 igemm_dma_kernel, 3 igemm_kernel, 4 the general
+ * register-weight halo kernel conv3x3_halo3g_kernel -- only with g->w_layout = 1),
  * plan[1] = tile id (families 1 / 2: the ids of sba_conv_geom.tile) or configuration, plan[2] = K splits. */
 int sba_conv_igemm_plan(int dtype, const sba_conv_geom* g, int64_t workspace_bytes, int* plan);
 /* GROUPED launch: n <= SBA_GROUP_MAX independent convolutions -- no output of one is an input of another, their outputs
@@ -199,8 +201,9 @@ typedef struct sba_pack_desc {
 } sba_pack_desc;
 int sba_pack_weights_multi(int dtype, const sba_pack_desc* descs, int ndesc, int total_tiles, void* stream);
 /* Row-major packed bf16 conv operands [R][taps][K] (R, K multiples of 64: the outputs of sba_pack_weight /
- * sba_pack_weights_multi) -> FRAGMENT-MAJOR copies [R/64][K/64][taps][2][4][64][8]: the 64 lanes' 16-byte MFMA B fragments
- * of one (tap, 32-row tile, 16-deep k-step) contiguous (1 KB), lane = ((k >> 3) & 1) * 32 + (r & 31).  `descs` is a DEVICE
+ * sba_pack_weights_multi; R a multiple of 32, K of 16) -> FRAGMENT-MAJOR copies [ceil(R/64)][taps][2][K/16][64][8] (the
+ * destination holds ceil(R/64)*64 * taps * K elements): the 64 lanes' 16-byte MFMA B fragments of one (tap, 32-row tile,
+ * 16-deep k-step) contiguous (1 KB), lane = ((k >> 3) & 1) * 32 + (r & 31).  `descs` is a DEVICE
  * array; one work unit = 16 bytes, tensor d owns units [unit_begin[d], unit_begin[d+1]); total_units = sum R*taps*K/8. */
 typedef struct sba_frag_desc {
     const void* src;

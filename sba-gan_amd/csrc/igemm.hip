@@ -1425,15 +1425,21 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo3_kernel(const bf16_t* __r
         }
     };
     // weight fragments of (chunk, tap): [n-block][chunk][tap][j][k16][lane][8]
+    // weight fragments: [64-row block][tap][j][K / 16 k-steps][lane][8]; (chunk, tap) t -> k-steps chunk * CIN/16 ..
     struct BFrag { bf16x8_t v[TN][CIN / 16]; };
-    const bf16_t* const wbase = wf + ((int64_t)blockIdx.y * nchunks * 9) * (TN * (CIN / 16) * 512) + lane * 8;
+    const int KSW = g.Cin / 16;                 // k-steps of one (tap, j) row
+    const bf16_t* const wbase = wf + ((int64_t)blockIdx.y * 9 * 2) * KSW * 512 + lane * 8;
+    auto wptr = [&](const int t) {              // t = chunk * 9 + tap
+        const int chunk = t / 9, tap = t - chunk * 9;
+        return wbase + ((int64_t)(tap * 2) * KSW + chunk * (CIN / 16)) * 512;
+    };
     auto bload = [&](BFrag& b, const int t) {
-        const bf16_t* p = wbase + (int64_t)t * (TN * (CIN / 16) * 512);      // t = chunk * 9 + tap
+        const bf16_t* p = wptr(t);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int k = 0; k < CIN / 16; ++k)
-                b.v[j][k] = *reinterpret_cast<const bf16x8_t*>(p + (j * (CIN / 16) + k) * 512);
+                b.v[j][k] = *reinterpret_cast<const bf16x8_t*>(p + ((int64_t)j * KSW + k) * 512);
     };
 
     f32x16_t acc[TM][TN];
@@ -1473,7 +1479,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo3_kernel(const bf16_t* __r
             ap[i] = lA + (hr * HC + hc) * PIXB + hf * 16;
         }
         const bool more = t + 1 < ntaps_all;
-        const bf16_t* pn = wbase + (int64_t)(more ? t + 1 : t) * (TN * (CIN / 16) * 512);
+        const bf16_t* pn = wptr(more ? t + 1 : t);
 #pragma unroll
         for (int k16 = 0; k16 < CIN / 16; ++k16) {
             bf16x8_t a[TM];
@@ -1487,7 +1493,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo3_kernel(const bf16_t* __r
             if (more) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    b.v[j][k16] = *reinterpret_cast<const bf16x8_t*>(pn + (j * (CIN / 16) + k16) * 512);
+                    b.v[j][k16] = *reinterpret_cast<const bf16x8_t*>(pn + ((int64_t)j * KSW + k16) * 512);
             }
         }
     }
@@ -1496,8 +1502,151 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo3_kernel(const bf16_t* __r
                                                  addend, stats, ex);
 }
 
-// row-major packed conv operand [R][taps][K] (bf16; R, K multiples of 64) -> fragment-major
-// [R/64][K/64][taps][2][4][64 lanes][8]: lane = ((k >> 3) & 1) * 32 + (r & 31).  One thread = 16 bytes.
+// ---------------------------------------------------------------------------
+// The register-weight halo-tile kernel for ANY stride-1 3 x 3 window (round 4): ragged maps (tiles of 8 x 32 output
+// pixels cut at the border), taps anywhere in a 3 x 3 window of offsets ('same', 'valid', their data gradients, flipped
+// orders), Cin in chunks of CIN = 32 or 64 channels, 32 * TN output channels per workgroup.  Written for the first 3 x 3
+// layers of the Inception trunk (model.py:170-199: 32 -> 32 and 32 -> 64 at 147 x 147, 80 -> 192 at 71 x 71) and their data
+// gradients: the implicit-GEMM kernels gather every tap separately through L2 -> LDS (9x the input bytes) and run them
+// at ~85 TFLOP/s -- 94 us for a layer whose tensors take 11 us to stream -- six launches on the image encoder's chain,
+// the critical one of the step.
+// ---------------------------------------------------------------------------
+template <int CIN, int TN>
+__global__ __launch_bounds__(256, 3) void conv3x3_halo3g_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wf,
+                                                                bf16_t* __restrict__ y, const bf16_t* __restrict__ addend,
+                                                                const sba_conv_geom g, const EpiX ex) {
+    typedef bf16_t T;
+    constexpr int TH = 8, TW = 32, BM = TH * TW, BN = 32 * TN;
+    constexpr int PIXB = CIN * 2 + 16;
+    constexpr int HR = TH + 2, HC = TW + 2;
+    constexpr int A_BYTES = HR * HC * PIXB;
+    constexpr int OUT_BYTES = BM * (BN * 2 + 16);
+    constexpr int STAGE = A_BYTES > OUT_BYTES ? A_BYTES : OUT_BYTES;
+    constexpr int TM = 2;
+    constexpr int CPP = CIN / 8;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STAGE + BM * 4 + BN * 8];
+    unsigned char* const lA = lds;
+    int* rowoff = reinterpret_cast<int*>(lds + STAGE);
+    float* s_stat = reinterpret_cast<float*>(lds + STAGE + BM * 4);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (g.OW + TW - 1) / TW, tiles_y = (g.OH + TH - 1) / TH;
+    const int tx_ = blockIdx.x % tiles_x, ty_ = (blockIdx.x / tiles_x) % tiles_y, n = blockIdx.x / (tiles_x * tiles_y);
+    const int oy0 = ty_ * TH, ox0 = tx_ * TW;
+    const int n_base = blockIdx.y * BN;
+    const int xcs = g.x_cstride ? g.x_cstride : g.Cin;
+    const int ycs = g.y_cstride ? g.y_cstride : g.Cout;
+    {
+        const int oy = oy0 + (tid >> 5), ox = ox0 + (tid & 31);
+        rowoff[tid] = (oy < g.OH && ox < g.OW) ? (n * g.OH + oy) * g.OW + ox : -1;
+    }
+    for (int c = tid; c < 2 * BN; c += 256) s_stat[c] = 0.f;
+    // the 3 x 3 window of tap offsets
+    int ymin = g.ty[0], xmin = g.tx[0];
+#pragma unroll
+    for (int t = 1; t < 9; ++t) { ymin = min(ymin, (int)g.ty[t]); xmin = min(xmin, (int)g.tx[t]); }
+    uint32_t kyx = 0;                               // 4 bits per tap: ky * 4 + kx (taps 0..7; tap 8 apart)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) kyx |= (uint32_t)((g.ty[t] - ymin) * 4 + (g.tx[t] - xmin)) << (4 * t);
+    const uint32_t kyx8 = (uint32_t)((g.ty[8] - ymin) * 4 + (g.tx[8] - xmin));
+
+    constexpr uint32_t OOB = 0xFFFFFFFFu;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    const uint32_t x_bytes = (uint32_t)((int64_t)g.N * g.IH * g.IW * xcs * 2);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
+    const int nchunks = g.Cin / CIN, ntaps_all = 9 * nchunks;
+    const int sy0 = oy0 + ymin, sx0 = ox0 + xmin;
+    constexpr int NCH = HR * HC * CPP, NI = (NCH + 255) / 256, HB = 4;
+    auto stage_halo = [&](const int chunk) {
+        const uint32_t cbytes = (uint32_t)(g.x_coff * 2 + chunk * CIN * 2);
+#pragma unroll
+        for (int i0 = 0; i0 < NI; i0 += HB) {
+            u32x4_t hv[HB];
+#pragma unroll
+            for (int u = 0; u < HB; ++u) {
+                const int idx = tid + 256 * (i0 + u);
+                const int p = idx / CPP, ch = idx - p * CPP;
+                const int hr = p / HC, hc = p - hr * HC;
+                const int iy = sy0 + hr, ix = sx0 + hc;
+                const bool ok = i0 + u < NI && idx < NCH && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+                const uint32_t o = ok ? (uint32_t)((n * g.IH + iy) * g.IW + ix) * (uint32_t)(xcs * 2) + cbytes +
+                                            (uint32_t)ch * 16u
+                                      : OOB;
+                hv[u] = __builtin_amdgcn_raw_buffer_load_b128(xr, o, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < HB; ++u) {
+                const int idx = tid + 256 * (i0 + u);
+                const int p = idx / CPP, ch = idx - p * CPP;
+                if (i0 + u < NI && idx < NCH)
+                    *reinterpret_cast<uint4*>(lA + p * PIXB + ch * 16) = make_uint4(hv[u][0], hv[u][1], hv[u][2], hv[u][3]);
+            }
+        }
+    };
+    // weight fragments: [64-row block][tap][j][K / 16][lane][8]; this workgroup's rows n_base .. n_base + BN
+    struct BFrag { bf16x8_t v[TN][CIN / 16]; };
+    const int KSW = g.Cin / 16;
+    const int j0 = (n_base >> 5) & 1;               // BN = 32: the odd 32-row tiles are j = 1 of their 64-row block
+    const bf16_t* const wbase = wf + ((int64_t)(n_base >> 6) * 9 * 2) * KSW * 512 + lane * 8;
+    auto wptr = [&](const int t) {                  // t = chunk * 9 + tap
+        const int chunk = t / 9, tap = t - chunk * 9;
+        return wbase + ((int64_t)(tap * 2 + j0) * KSW + chunk * (CIN / 16)) * 512;
+    };
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int rl = lane & 31, hf = lane >> 5;
+    BFrag b;
+    {
+        const bf16_t* p = wptr(0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int k = 0; k < CIN / 16; ++k) b.v[j][k] = *reinterpret_cast<const bf16x8_t*>(p + ((int64_t)j * KSW + k) * 512);
+    }
+#pragma unroll 1
+    for (int t = 0; t < ntaps_all; ++t) {
+        const int chunk = t / 9, tap = t - chunk * 9;
+        if (tap == 0) {
+            if (chunk) __syncthreads();
+            stage_halo(chunk);
+            __syncthreads();
+        }
+        const uint32_t code = tap < 8 ? (kyx >> (4 * tap)) & 15u : kyx8;
+        const int ky = (int)(code >> 2), kx = (int)(code & 3u);
+        const unsigned char* ap[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ap[i] = lA + ((2 * wid + i + ky) * HC + rl + kx) * PIXB + hf * 16;
+        const bool more = t + 1 < ntaps_all;
+        const bf16_t* pn = wptr(more ? t + 1 : t);
+#pragma unroll
+        for (int k16 = 0; k16 < CIN / 16; ++k16) {
+            bf16x8_t a[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(ap[i] + k16 * 32);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b.v[j][k16], acc[i][j], 0, 0, 0);
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b.v[j][k16] = *reinterpret_cast<const bf16x8_t*>(pn + ((int64_t)j * KSW + k16) * 512);
+            }
+        }
+    }
+    __syncthreads();
+    tile_epilogue<T, BM, BN, TM, TN, 256, STAGE>(acc, true, lds, rowoff, s_stat, wid * 64, 0, lane, n_base, ycs, g, y,
+                                                 addend, nullptr, ex);
+}
+
+// row-major packed conv operand [R][taps][K] (bf16; R a multiple of 32, K of 16) -> fragment-major
+// [ceil(R/64)][taps][2][K/16][64 lanes][8]: lane = ((k >> 3) & 1) * 32 + (r & 31).  One thread = 16 bytes.
 __global__ __launch_bounds__(256) void pack_frag_kernel(const sba_frag_desc* __restrict__ descs, const int ndesc,
                                                         const int total_units) {
     const int u = blockIdx.x * 256 + threadIdx.x;
@@ -1513,8 +1662,8 @@ __global__ __launch_bounds__(256) void pack_frag_kernel(const sba_frag_desc* __r
     const int k8 = local % k8n, rest = local / k8n;
     const int t = rest % d.taps, r = rest / d.taps;
     const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(d.src) + ((int64_t)r * d.taps + t) * d.K + 8 * k8);
-    const int nb = r >> 6, j = (r >> 5) & 1, nn = r & 31, chunk = k8 >> 3, k16 = (k8 >> 1) & 3, gg = k8 & 1, nch = d.K / 64;
-    const int64_t o = ((((((int64_t)nb * nch + chunk) * d.taps + t) * 2 + j) * 4 + k16) * 512) + (gg * 32 + nn) * 8;
+    const int nb = r >> 6, j = (r >> 5) & 1, nn = r & 31, k16 = k8 >> 1, gg = k8 & 1, ks = d.K / 16;
+    const int64_t o = (((((int64_t)nb * d.taps + t) * 2 + j) * ks + k16) * 512) + (gg * 32 + nn) * 8;
     *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(d.dst) + o) = v;
 }
 
@@ -2726,6 +2875,38 @@ static bool halo_ok(const sba_conv_geom& g) {
     return tiles >= 128 && tiles <= 0x7fffffff;
 }
 
+// the general register-weight halo kernel (fragment-major weights only): any stride-1 3 x 3 window, ragged maps
+static bool halo3g_ok(const sba_conv_geom& g) {
+    if (g.w_layout != 1 || g.ups) return false;
+    if (g.ntaps != 9 || g.sy != 1 || g.sx != 1 || g.osy != 1 || g.osx != 1 || g.ooy || g.oox) return false;
+    if (g.OHs != g.OH || g.OWs != g.OW || g.Cin % 32 || g.Cout % 32) return false;
+    int ymin = g.ty[0], ymax = g.ty[0], xmin = g.tx[0], xmax = g.tx[0];
+    unsigned seen = 0;
+    for (int t = 0; t < 9; ++t) {
+        ymin = g.ty[t] < ymin ? g.ty[t] : ymin; ymax = g.ty[t] > ymax ? g.ty[t] : ymax;
+        xmin = g.tx[t] < xmin ? g.tx[t] : xmin; xmax = g.tx[t] > xmax ? g.tx[t] : xmax;
+    }
+    if (ymax - ymin != 2 || xmax - xmin != 2) return false;
+    for (int t = 0; t < 9; ++t) seen |= 1u << ((g.ty[t] - ymin) * 3 + (g.tx[t] - xmin));
+    if (seen != 0x1ffu) return false;               // the nine taps are the nine cells of the window
+    const int64_t tiles = (int64_t)g.N * cdiv(g.OH, 8) * cdiv(g.OW, 32);
+    return tiles >= 128 && tiles <= 0x7fffffff;
+}
+
+static void launch_halo3g(const sba_conv_geom& g, const bf16_t* x, const bf16_t* w, bf16_t* y, const bf16_t* addend,
+                          const EpiX ex, hipStream_t st) {
+    const int tiles = g.N * cdiv(g.OH, 8) * cdiv(g.OW, 32);
+    const bool tn2 = g.Cout % 64 == 0;
+    dim3 grid(tiles, g.Cout / (tn2 ? 64 : 32));
+    if (g.Cin % 64 == 0) {
+        if (tn2) SBA_LAUNCH((conv3x3_halo3g_kernel<64, 2>), grid, dim3(256), 0, st, x, w, y, addend, g, ex);
+        else SBA_LAUNCH((conv3x3_halo3g_kernel<64, 1>), grid, dim3(256), 0, st, x, w, y, addend, g, ex);
+    } else {
+        if (tn2) SBA_LAUNCH((conv3x3_halo3g_kernel<32, 2>), grid, dim3(256), 0, st, x, w, y, addend, g, ex);
+        else SBA_LAUNCH((conv3x3_halo3g_kernel<32, 1>), grid, dim3(256), 0, st, x, w, y, addend, g, ex);
+    }
+}
+
 static void launch_halo(const sba_conv_geom& g, const bf16_t* x, const bf16_t* w, bf16_t* y, const bf16_t* addend,
                         float* stats, const EpiX ex, hipStream_t st) {
     const int tiles = g.N * (g.OH / 8) * (g.OW / 32);
@@ -2764,7 +2945,14 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
     // gen 2 (64-channel slabs), 2 LDS-DMA gen 1, 3 register-staged), plan[1] = tile id / configuration, plan[2] = K splits
     const int M = g.N * g.OHs * g.OWs;
     const T* xp = (const T*)x; const T* wp = (const T*)w; T* yp = (T*)y; const T* ap = (const T*)addend;
-    if (g.w_layout != 0 && !(g.w_layout == 1 && sizeof(T) == 2 && halo_ok(g))) return SBA_E_ARG;   // fragment-major weights: halo-tile kernel only
+    // fragment-major weights: the halo-tile kernels only (family 0: the strict form; family 4: the general form)
+    if (g.w_layout != 0 && !(g.w_layout == 1 && sizeof(T) == 2 && (halo_ok(g) || halo3g_ok(g)))) return SBA_E_ARG;
+    if (sizeof(T) == 2 && g.w_layout == 1 && !halo_ok(g)) {
+        if (plan) { plan[0] = 4; plan[1] = g.Cin % 64 == 0 ? 64 : 32; plan[2] = 1; return SBA_OK; }
+        if (stats) return SBA_E_ARG;
+        launch_halo3g(g, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, (const bf16_t*)addend, ex, st);
+        return SBA_CHECK_LAUNCH();
+    }
     if (sizeof(T) == 2 && halo_ok(g)) {
         if (plan) { plan[0] = 0; plan[1] = g.ups ? 1 : 0; plan[2] = 1; return SBA_OK; }
         launch_halo(g, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, (const bf16_t*)addend, stats, ex, st);

@@ -23,6 +23,7 @@ BN_EPS = 1e-3
 SAVE_ARGMAX = os.environ.get('SBA_ENC_SAVE_ARGMAX', '1') != '0'    # max-pool forward keeps the window argmax for the backward
 GROUP_MIN_TILES = int(os.environ.get('SBA_ENC_GROUP_MIN_TILES', '512'))
 GROUP_TILE = int(os.environ.get('SBA_ENC_GROUP_TILE', '0'))             # tuning aid: force the grouped launches' tile id
+FRAG_STEM = os.environ.get('SBA_ENC_FRAG_STEM', '1') != '0'         # register-weight halo kernel for the trunk's first 3 x 3 layers
 GROUP_T7_MIN = int(os.environ.get('SBA_ENC_GROUP_T7_MIN', '0'))         # 128 x 128 tiles (tile id 7) when a level has at least this many (0 = never)
 
 
@@ -135,6 +136,7 @@ class InceptionHIP(object):
         self.dtype = dtype or ops.compute_dtype()
         self.nef = enc.nef
         self._convs = {}
+        self._frag, self._frag_keep = {}, []
         self._fused = {}
         self._geoms = {}
         self._side, self._branch_ops, self._block = None, None, None
@@ -173,6 +175,7 @@ class InceptionHIP(object):
             if m.__class__.__name__ == 'BasicConv2d':
                 self._convs[name] = _Conv(m.conv, m.bn, self.dtype)
         self._fused = {}
+        self._frag, self._frag_keep = {}, []        # (keyed by the old operands' addresses)
         stem = self.enc.Conv2d_1a_3x3
         s = stem.bn.weight.detach().float() / torch.sqrt(stem.bn.running_var.detach().float() + stem.bn.eps)
         self.stem_w = (stem.conv.weight.detach().float() * s.view(-1, 1, 1, 1)).contiguous(
@@ -213,7 +216,45 @@ class InceptionHIP(object):
              stats.data_ptr(), ctypes.byref(g), ws.data_ptr(), ops.WORKSPACE_BYTES, ops._stream())
         self._bn_relu_train(y, L.bn, N * OH * OW, L.O, out.t, out.shape[3], out.coff, stats)
 
+    def _frag_for(self, w, g):
+        """the fragment-major copy of the packed weights `w` ([R][9][K], frozen) when this launch goes to the register-weight
+        halo-tile kernel (include/sbagan_hip.h: sba_conv_geom.w_layout): stride-1 3 x 3 convs on the big maps of the trunk's
+        first layers (>= 64 pixels wide) and their data gradients; None otherwise"""
+        if not (ops.FRAG_WEIGHTS and FRAG_STEM) or self.dtype != torch.bfloat16 or g.ntaps != 9 or g.sy != 1 or \
+                g.osy != 1 or g.OW < 64 or g.OWs != g.OW or w.dim() != 3 or w.shape[0] % 32 or w.shape[2] % 32:
+            return None
+        key = (w.data_ptr(), g.OH, g.OW, g.IH, g.IW, g.N)
+        ent = self._frag.get(key)
+        if ent is None:
+            plan = (ctypes.c_int * 3)()
+            g.w_layout = 1
+            try:
+                rc = _lib.lib.sba_conv_igemm_plan(_lib.SBA_BF16, ctypes.byref(g), ops.WORKSPACE_BYTES, plan)
+            finally:
+                g.w_layout = 0
+            ent = False
+            if rc == 0 and plan[0] in (0, 4):
+                R, taps, K = w.shape
+                dst = self._frag.get(('w', w.data_ptr()))
+                if dst is None:
+                    dst = torch.zeros((R + 63) // 64 * 64 * taps * K, dtype=w.dtype, device=w.device)
+                    ops._pack_frag([(w, dst, R, taps, K)], w.device)
+                    self._frag[('w', w.data_ptr())] = dst
+                    self._frag_keep.append(w)          # (the key is its address)
+                ent = dst
+            self._frag[key] = ent
+        return ent if ent is not False else None
+
     def _igemm(self, x_ptr, w, y_ptr, addend_ptr, bias, g, mask_ptr=None):
+        wf = self._frag_for(w, g)
+        if wf is not None:          # register-weight halo kernel: a launch of its own (never part of a grouped level)
+            g.w_layout = 1
+            try:
+                call('sba_conv_igemm_bias', self._dt(), x_ptr, wf.data_ptr(), y_ptr, addend_ptr, None,
+                     None if bias is None else bias.data_ptr(), mask_ptr, ctypes.byref(g), None, 0, ops._stream())
+            finally:
+                g.w_layout = 0
+            return
         if self._pending is not None:
             self._pending.append((x_ptr, w, y_ptr, addend_ptr, bias, g, mask_ptr))
             return

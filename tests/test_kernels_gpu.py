@@ -278,6 +278,80 @@ def test_inception_conv_geometries(dev, dt, geom):
     close(gx[..., :I].permute(0, 3, 1, 2), gx_ref, dt, 'dx')
 
 
+@pytest.mark.parametrize('geom', [(32, 32, 0, 149, 2), (32, 64, 1, 147, 2), (80, 192, 0, 73, 4), (64, 96, 1, 67, 5)])
+def test_register_weight_halo_kernel_general(dev, geom):
+    """conv3x3_halo3g_kernel (fragment-major weights, include/sbagan_hip.h: w_layout = 1) on the geometries of the
+    Inception trunk's first 3 x 3 layers -- 'valid' and 'same' windows, ragged maps, 32- and 64-channel chunks, 32 / 64
+    output channels per workgroup -- forward (bias + ReLU) and data gradient (addend + ReLU mask) against F.conv2d and
+    against the implicit-GEMM kernels on row-major weights (same products, another summation order)."""
+    import ctypes
+    from sbagan import _lib, ops
+    from sbagan.inception_hip import _Conv, _geom
+    I, O, pad, S, N = geom
+    dt = torch.bfloat16
+    conv = torch.nn.Conv2d(I, O, 3, stride=1, padding=pad, bias=False)
+    bn = torch.nn.BatchNorm2d(O, eps=1e-3).eval()
+    with torch.no_grad():
+        conv.weight.copy_(fill.unit((O, I, 3, 3), 21) / np.sqrt(I * 9))
+        bn.weight.copy_(1.0 + 0.2 * fill.uniform((O,), 22))
+        bn.bias.copy_(0.1 * fill.uniform((O,), 23))
+        bn.running_mean.copy_(0.1 * fill.uniform((O,), 24))
+        bn.running_var.copy_(1.0 + 0.3 * fill.uniform((O,), 25))
+    L = _Conv(conv.to(dev), bn.to(dev), dt, relu=True)
+    ws = ops.workspace(dev)
+
+    def frag(w):
+        R, taps, K = w.shape
+        dst = torch.zeros((R + 63) // 64 * 64 * taps * K, dtype=w.dtype, device=dev)
+        ops._pack_frag([(w, dst, R, taps, K)], dev)
+        return dst
+
+    def run(x, w, y, bias, g, layout, addend=None, mask=None):
+        g.w_layout = layout
+        plan = (ctypes.c_int * 3)()
+        _lib.call('sba_conv_igemm_plan', _lib.SBA_BF16, ctypes.byref(g), ops.WORKSPACE_BYTES, plan)
+        _lib.call('sba_conv_igemm_bias', _lib.SBA_BF16, x.data_ptr(), w.data_ptr(), y.data_ptr(),
+                  None if addend is None else addend.data_ptr(), None, None if bias is None else bias.data_ptr(),
+                  None if mask is None else mask.data_ptr(), ctypes.byref(g), ws.data_ptr(), ops.WORKSPACE_BYTES,
+                  ops._stream())
+        g.w_layout = 0
+        return plan[0]
+
+    x = fill.unit((N, I, S, S), 26)
+    xa = torch.zeros((N, S, S, L.Ip), dtype=dt, device=dev)
+    xa[..., :I] = x.permute(0, 2, 3, 1).to(dev).to(dt)
+    OH = OW = S + 2 * pad - 2
+    taps = [(t // 3 - pad, t % 3 - pad) for t in range(9)]
+    g = _geom(N, S, S, L.Ip, OH, OW, L.Op, taps, xcs=L.Ip, ycs=L.Op, relu=1)
+    y0 = torch.empty((N, OH, OW, L.Op), dtype=dt, device=dev)
+    y1 = torch.full((N, OH, OW, L.Op), float('nan'), dtype=dt, device=dev)
+    assert run(xa, L.w_fwd, y0, L.bias, g, 0) != 4
+    assert run(xa, frag(L.w_fwd), y1, L.bias, g, 1) in (0, 4)
+    torch.cuda.synchronize()
+    wf = L.w_fwd.float().cpu()[:O, :, :I].reshape(O, 3, 3, I).permute(0, 3, 1, 2).contiguous()
+    xr = rounded(x, dt).requires_grad_(True)
+    pre = F.conv2d(xr, wf, None, 1, pad)
+    close(y1[..., :O].permute(0, 3, 1, 2), torch.relu(pre + L.bias.cpu()[:O].view(1, -1, 1, 1)), dt, 'y')
+    assert rel_l2(y1.float().cpu(), y0.float().cpu()) < 1e-3, 'register-weight kernel vs implicit GEMM'
+    assert float(y1[..., O:].float().abs().max()) == 0.0 if L.Op > O else True, 'padded output channels'
+    # data gradient with an addend and the ReLU mask of the tensor it completes
+    dy = fill.unit((N, O, OH, OW), 27)
+    (gx_ref,) = torch.autograd.grad(pre, xr, rounded(dy, dt))
+    dya = torch.zeros((N, OH, OW, L.Op), dtype=dt, device=dev)
+    dya[..., :O] = dy.permute(0, 2, 3, 1).to(dev).to(dt)
+    add = fill.unit((N, S, S, L.Ip), 28).to(dev).to(dt)
+    mask = fill.unit((N, S, S, L.Ip), 29).to(dev).to(dt)
+    gd = _geom(N, OH, OW, L.Op, S, S, L.Ip, L.dtaps[0], xcs=L.Op, ycs=L.Ip)
+    gx0 = torch.zeros((N, S, S, L.Ip), dtype=dt, device=dev)
+    gx1 = torch.full((N, S, S, L.Ip), float('nan'), dtype=dt, device=dev)
+    run(dya, L.w_dgrad[0], gx0, None, gd, 0, addend=add, mask=mask)
+    assert run(dya, frag(L.w_dgrad[0]), gx1, None, gd, 1, addend=add, mask=mask) in (0, 4)
+    torch.cuda.synchronize()
+    want = (gx_ref + add.float().cpu()[..., :I].permute(0, 3, 1, 2)) * (mask.float().cpu()[..., :I].permute(0, 3, 1, 2) > 0)
+    close(gx1[..., :I].permute(0, 3, 1, 2), want, dt, 'dx')
+    assert rel_l2(gx1.float().cpu(), gx0.float().cpu()) < 1e-3, 'data gradient: register-weight kernel vs implicit GEMM'
+
+
 # ------------------------------------------------------------------ every bf16 tile configuration, forced
 # sba_conv_geom.tile / .ksplit (include/sbagan_hip.h) pick the kernel instantiation; the measured table only ever uses a
 # few per shape, so each id is forced here on the weight-streaming shapes of the discriminator tails (model.py:560-607:
