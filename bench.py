@@ -517,6 +517,8 @@ def main():
             step.overlap_g, step.bucket_d = flags
     if dp_graph is not None:
         graph = dp_graph
+        if dp_mode == '4':      # (a step with its collectives: after the ranks have agreed on the launch mode)
+            graph.prioritize(verbose=1)
         for _ in range(2):
             graph.replay()
         torch.cuda.synchronize()
@@ -560,6 +562,7 @@ def main():
                 from sbagan.trainer import ReplayedStep
                 g3 = ReplayedStep(step, *a, recorded_prologue=encode,
                                   max_streams=int(os.environ.get('SBA_REPLAY_STREAMS', '4')), verbose=True)
+                g3.prioritize(verbose=int(os.environ.get('SBA_REPLAY_PRIO_VERBOSE', '1')))
                 for _ in range(2):
                     g3.replay()
                 torch.cuda.synchronize()

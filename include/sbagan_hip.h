@@ -84,7 +84,7 @@ typedef struct sba_conv_geom {
      * Cout % 32 == 0, no statistics for family 4 -- which keep the weight fragments in registers instead of LDS. */
     int32_t w_layout;
 } sba_conv_geom;
-#define SBA_IGEMM_TILES 15
+#define SBA_IGEMM_TILES 18
 
 const char* sba_version(void);
 
@@ -501,6 +501,20 @@ int sba_lstm_bidir_fwd(const int64_t* captions, const int64_t* cap_lens, const f
 int sba_replay_create(void* hip_graph, int max_streams, int flags, void** out_handle);
 int sba_replay_launch(void* handle, void* stream);
 int sba_replay_info(void* handle, int* info8);
+/* PRIORITIES for the longest dependency path.  Kernels of independent chains that run side by side share the CUs, and the
+ * chain the step's duration hangs on (generator forward -> image encoder -> DAMSM -> their backward passes) is slowed by the
+ * three discriminator updates beside it as much as they are by it.  sba_replay_prioritize
+ *   1. issues every recorded node ONCE, alone, in order on `stream` with an event between neighbours -- this IS one
+ *      execution of the recording (host-call nodes included: the callback runs), the caller counts it as a replay -- and keeps
+ *      the durations;
+ *   2. computes every node's earliest start and longest path to the end from them; nodes whose slack against the longest
+ *      path of the whole recording is <= slack_frac of it are CRITICAL;
+ *   3. assigns streams again, in two pools: n_high streams for the critical nodes, max_streams - n_high for the rest, created
+ *      with hipStreamCreateWithPriority: mode 1 = (high, normal), 2 = (high, low), 3 = (normal, low); 0 = one pool, no
+ *      priorities (only max_streams changes).
+ * The dependencies enforced are the recorded ones in every mode: results do not depend on it.  verbose: 1 = a summary on
+ * stderr, 2 = also the longest path node by node (start, duration alone, kernel, grid), 3 = also every node (duration alone, slack). */
+int sba_replay_prioritize(void* handle, void* stream, int mode, int max_streams, int n_high, float slack_frac, int verbose);
 /* HOST-CALL nodes.  sba_replay_marker launches a no-op kernel carrying `tag` (>= 0) on `stream`; captured into the graph it
  * becomes a node with the dependencies of its stream position.  A replay does not launch that node: it calls the callback
  * registered with sba_replay_set_callback -- void fn(int tag, void* stream, void* user) -- with the stream the node was

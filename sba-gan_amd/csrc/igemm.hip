@@ -3022,7 +3022,7 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
         if (det) split = 1;
         static int gen2 = -1;       // SBA_IGEMM_DMA2=0: first-generation kernels only (A/B aid)
         if (gen2 < 0) { const char* e = getenv("SBA_IGEMM_DMA2"); gen2 = (e && e[0] == '0') ? 0 : 1; }
-        if (tile >= 13 && tile <= 15 && !(gen2 && g.Cin % 64 == 0)) {       // gen-2 only: back to the rules
+        if (tile >= 13 && tile != 12 && !(gen2 && g.Cin % 64 == 0)) {       // gen-2 only: back to the rules
             static const int rule_tile[4] = {7, 9, 5, 1};
             tile = best <= 3 ? rule_tile[best] : 11;
             split = det ? 1 : best_split;
@@ -3047,6 +3047,9 @@ int launch_igemm(const void* x, const void* w, void* y, const void* addend, floa
                 case 13: launch_dma2<320, 64, 64, 64, 3>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
                 case 14: launch_dma2<160, 64, 32, 64, 4>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
                 case 15: launch_dma2<160, 64, 32, 64, 2>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+                case 16: launch_dma2<256, 128, 128, 64, 3>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+                case 17: launch_dma2<256, 128, 64, 64, 3>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
+                case 18: launch_dma2<256, 128, 128, 64, 2>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
                 default: launch_dma2<96, 128, 32, 128, 5>(xb, wb, yb, ab, stats, g, M, ns64, sp, ws, ws_bytes, st, ex); return SBA_CHECK_LAUNCH();
             }
         }

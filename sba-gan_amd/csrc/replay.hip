@@ -61,6 +61,12 @@ struct Replayer {
     int n_kernels = 0, n_copies = 0, n_memsets = 0, n_waits = 0, n_markers = 0;
     sba_replay_cb cb = nullptr;
     void* cb_user = nullptr;
+    // the recorded dependencies (positions in `nodes`) and what the stream assignment works from
+    std::vector<std::vector<int>> deps;
+    std::vector<char> critical;   // per node: 1 = on (or within the slack threshold of) the longest path; sba_replay_prioritize
+    std::vector<float> dur_us;    // per node: duration measured alone (sba_replay_prioritize), else empty
+    int max_streams = 1, n_high = 0, prio_mode = 0;
+    bool on_caller = false;
 };
 
 #define RCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
@@ -72,7 +78,134 @@ static bool is_1d(const hipMemcpy3DParms& p) {
            p.srcPos.x == 0 && p.srcPos.y == 0 && p.srcPos.z == 0 && p.dstPos.x == 0 && p.dstPos.y == 0 && p.dstPos.z == 0;
 }
 
+
+// Give every node a stream and place events where a dependency crosses streams.  A chain keeps its stream: a node continues
+// the stream of the LAST-issued dependency that nobody continues yet; a fork (or a root) takes the stream that has been quiet
+// longest -- a finished branch's stream rather than one a long chain is still being issued to.  With priorities
+// (R->prio_mode, sba_replay_prioritize) the streams form two pools -- [0, n_high) for the nodes marked critical, created with
+// the higher priority, the rest for everything else -- and a node continues a dependency's stream only inside its own pool.
+static int assign_streams(Replayer* R) {
+    const int n = (int)R->nodes.size(), S = R->max_streams;
+    for (hipStream_t s : R->streams) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    for (hipEvent_t e : R->events) if (e) (void)hipEventDestroy(e);
+    R->streams.clear(); R->events.clear(); R->tail_event.clear(); R->n_waits = 0;
+    const bool pools = R->prio_mode != 0 && !R->on_caller && S >= 2;
+    const int nh = pools ? std::max(1, std::min(R->n_high, S - 1)) : 0;
+    std::vector<char> taken(n, 0);                  // a successor already continues this node's stream
+    std::vector<int> last_use(S, -1), load(S, 0);   // issue position of the last node each stream was given
+    int used_streams = 0, rr = 0;
+    const char* pol = getenv("SBA_REPLAY_POLICY");
+    const int policy = pol ? atoi(pol) : 0;
+    for (int u = 0; u < n; ++u) {
+        RNode& r = R->nodes[u];
+        r.waits.clear();
+        r.record = -1;
+        const int lo = pools ? (R->critical[u] ? 0 : nh) : 0, hi = pools ? (R->critical[u] ? nh : S) : S;
+        int s = -1, best = -1;
+        for (int d : R->deps[u]) {
+            const int sd = R->nodes[d].stream;
+            if (!taken[d] && d > best && sd >= lo && sd < hi) { best = d; s = sd; }
+        }
+        if (s >= 0) {
+            taken[best] = 1;
+        } else {
+            s = lo;
+            if (policy == 1) {              // (A/B aid) the stream with the fewest nodes so far
+                for (int t = lo + 1; t < hi; ++t) if (load[t] < load[s]) s = t;
+            } else if (policy == 2) {       // (A/B aid) round robin over the forks
+                s = lo + (rr++) % (hi - lo);
+            } else {
+                for (int t = lo + 1; t < hi; ++t) if (last_use[t] < last_use[s]) s = t;
+            }
+        }
+        ++load[s];
+        used_streams = std::max(used_streams, s + 1);
+        r.stream = s;
+        last_use[s] = u;
+    }
+    // events where a dependency crosses streams.  Within one stream the issue order IS the dependency order,
+    // and a wait on producer p also covers everything issued before p on p's stream.
+    std::vector<int> last_waited(used_streams * used_streams, -1);   // [consumer stream][producer stream] -> issue position
+    for (int u = 0; u < n; ++u) {
+        RNode& r = R->nodes[u];
+        for (int d : R->deps[u]) {
+            RNode& p = R->nodes[d];
+            if (p.stream == r.stream) continue;
+            int& lw = last_waited[r.stream * used_streams + p.stream];
+            if (lw >= d) continue;                          // already ordered behind a later node of that stream
+            if (p.record < 0) {
+                p.record = (int)R->events.size();
+                R->events.push_back(nullptr);
+            }
+            r.waits.push_back(p.record);
+            lw = d;
+            ++R->n_waits;
+        }
+    }
+    // on_caller: stream 0 of the assignment IS the caller's stream (sba_replay_launch): a single-chain graph -- one phase
+    // of the step -- then needs no stream of its own (a process has only 4 hardware queues by default; every extra stream
+    // shares one).  Not for a caller on the NULL stream: the whole step with its main chain there measured 12.0 against
+    // 11.15 ms on a stream of the replayer's own.
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);         // (numerically: least >= greatest)
+    const int p_hi = (R->prio_mode == 3) ? 0 : greatest, p_lo = (R->prio_mode == 1) ? 0 : least;
+    R->streams.assign(used_streams, nullptr);
+    for (int s = R->on_caller ? 1 : 0; s < used_streams; ++s) {
+        const hipError_t e = pools ? hipStreamCreateWithPriority(&R->streams[s], hipStreamNonBlocking, s < nh ? p_hi : p_lo)
+                                   : hipStreamCreateWithFlags(&R->streams[s], hipStreamNonBlocking);
+        if (e != hipSuccess) { (void)hipGetLastError(); return SBA_E_LAUNCH; }
+    }
+    for (auto& e : R->events)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return SBA_E_LAUNCH;
+    R->tail_event.assign(used_streams, -1);
+    for (int s = 0; s < used_streams; ++s) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return SBA_E_LAUNCH;
+        R->tail_event[s] = (int)R->events.size();
+        R->events.push_back(e);
+    }
+    return SBA_OK;
+}
+
+// one recorded node onto stream s
+static int issue_node(Replayer* R, RNode& r, hipStream_t s) {
+    switch (r.type) {
+        case hipGraphNodeTypeKernel:
+            if (r.marker >= 0) {
+                // host-call node: everything it depends on has been ISSUED (stream-ordered before s's current
+                // position); the callback may enqueue on s and make s wait for other streams
+                if (R->cb) R->cb(r.marker, (void*)s, R->cb_user);
+                break;
+            }
+            if (r.hfunc)
+                RCHECK(hipModuleLaunchKernel(r.hfunc, r.kp.gridDim.x, r.kp.gridDim.y, r.kp.gridDim.z, r.kp.blockDim.x,
+                                             r.kp.blockDim.y, r.kp.blockDim.z, r.kp.sharedMemBytes, s,
+                                             r.kp.kernelParams, r.kp.extra));
+            else
+                RCHECK(hipLaunchKernel(r.kp.func, r.kp.gridDim, r.kp.blockDim, r.kp.kernelParams,
+                                       r.kp.sharedMemBytes, s));
+            break;
+        case hipGraphNodeTypeMemcpy:
+            RCHECK(hipMemcpyAsync(r.cp.dstPtr.ptr, r.cp.srcPtr.ptr, r.cp.extent.width, r.cp.kind, s));
+            break;
+        case hipGraphNodeTypeMemset:
+            if (r.ms.height <= 1) {
+                if (r.ms.elementSize == 4) RCHECK(hipMemsetD32Async((hipDeviceptr_t)r.ms.dst, (int)r.ms.value, r.ms.width, s));
+                else if (r.ms.elementSize == 2) RCHECK(hipMemsetD16Async((hipDeviceptr_t)r.ms.dst, (unsigned short)r.ms.value, r.ms.width, s));
+                else RCHECK(hipMemsetAsync(r.ms.dst, (int)r.ms.value, r.ms.width, s));
+            } else {
+                RCHECK(hipMemset2DAsync(r.ms.dst, r.ms.pitch, (int)r.ms.value, r.ms.width * r.ms.elementSize, r.ms.height, s));
+            }
+            break;
+        default:
+            break;      // empty node: ordering only
+    }
+    return SBA_OK;
+}
+
 }  // namespace
+
+extern "C" int sba_replay_destroy(void* handle);
 
 extern "C" int sba_replay_create(void* hip_graph, int max_streams, int flags, void** out) {
     if (!hip_graph || !out || max_streams < 1 || max_streams > 32) return SBA_E_ARG;
@@ -109,19 +242,14 @@ extern "C" int sba_replay_create(void* hip_graph, int max_streams, int flags, vo
     if (order.size() != n) return SBA_E_ARG;       // a cycle: not a captured graph
 
     Replayer* R = new Replayer();
+    R->max_streams = max_streams;
+    R->on_caller = on_caller;
     std::vector<int> pos(n, -1);                    // graph node -> position in R->nodes
-    std::vector<int> stream_of(n, -1);
-    std::vector<char> stream_taken(n, 0);           // a successor already continues this node's stream
-    std::vector<int> last_use(max_streams, -1);     // issue position of the last node each stream was given
-    int used_streams = 0, undecodable = 0;
-    std::vector<int> load(max_streams, 0);
-    int rr = 0;
-    const char* pol = getenv("SBA_REPLAY_POLICY");
-    const int policy = pol ? atoi(pol) : 0;
+    int undecodable = 0;
     for (int u : order) {
         RNode r;
         memset(&r.kp, 0, sizeof(r.kp)); memset(&r.cp, 0, sizeof(r.cp)); memset(&r.ms, 0, sizeof(r.ms));
-        r.hfunc = nullptr; r.record = -1; r.sink = succ[u].empty(); r.marker = -1;
+        r.hfunc = nullptr; r.record = -1; r.sink = succ[u].empty(); r.marker = -1; r.stream = 0;
         if (hipGraphNodeGetType(gn[u], &r.type) != hipSuccess) { delete R; return SBA_E_LAUNCH; }
         if (r.type == hipGraphNodeTypeKernel) {
             if (hipGraphKernelNodeGetParams(gn[u], &r.kp) != hipSuccess) { delete R; return SBA_E_LAUNCH; }
@@ -166,72 +294,20 @@ extern "C" int sba_replay_create(void* hip_graph, int max_streams, int flags, vo
             delete R;
             return SBA_E_UNSUPPORTED;
         }
-        // stream: continue the stream of the LAST-issued dependency that nobody continues yet, else fork
-        int s = -1, best = -1;
-        for (int d : deps[u])
-            if (!stream_taken[d] && pos[d] > best) { best = pos[d]; s = stream_of[d]; }
-        if (s >= 0) {
-            for (int d : deps[u]) if (pos[d] == best) stream_taken[d] = 1;
-        } else {
-            // a fork (or a root): the stream that has been quiet longest -- a finished branch's stream rather
-            // than one a long chain is still being issued to
-            s = 0;
-            if (policy == 1) {              // (A/B aid) the stream with the fewest nodes so far
-                for (int t = 1; t < max_streams; ++t) if (load[t] < load[s]) s = t;
-            } else if (policy == 2) {       // (A/B aid) round robin over the forks
-                s = (rr++) % max_streams;
-            } else {
-                for (int t = 1; t < max_streams; ++t) if (last_use[t] < last_use[s]) s = t;
-            }
-        }
-        ++load[s];
-        used_streams = std::max(used_streams, s + 1);
-        stream_of[u] = s;
-        r.stream = s;
         pos[u] = (int)R->nodes.size();
-        last_use[s] = pos[u];
         R->nodes.push_back(r);
+        std::vector<int> dp;
+        for (int d : deps[u]) dp.push_back(pos[d]);
+        R->deps.push_back(dp);
     }
     if (undecodable) { delete R; return SBA_E_UNSUPPORTED; }
-    // events where a dependency crosses streams.  Within one stream the issue order IS the dependency order,
-    // and a wait on producer p also covers everything issued before p on p's stream.
-    std::vector<int> last_waited(used_streams * used_streams, -1);   // [consumer stream][producer stream] -> issue position
-    for (int u : order) {
-        RNode& r = R->nodes[pos[u]];
-        for (int d : deps[u]) {
-            RNode& p = R->nodes[pos[d]];
-            if (p.stream == r.stream) continue;
-            int& lw = last_waited[r.stream * used_streams + p.stream];
-            if (lw >= pos[d]) continue;                     // already ordered behind a later node of that stream
-            if (p.record < 0) {
-                p.record = (int)R->events.size();
-                R->events.push_back(nullptr);
-            }
-            r.waits.push_back(p.record);
-            lw = pos[d];
-            ++R->n_waits;
-        }
-    }
-    // flags bit 1: stream 0 of the assignment IS the caller's stream (sba_replay_launch): a single-chain graph -- one phase
-    // of the step -- then needs no stream of its own (a process has only 4 hardware queues by default; every extra stream
-    // shares one).  Not for a caller on the NULL stream: the whole step with its main chain there measured 12.0 against
-    // 11.15 ms on a stream of the replayer's own.
-    R->streams.assign(used_streams, nullptr);
-    for (int s = on_caller ? 1 : 0; s < used_streams; ++s)
-        if (hipStreamCreateWithFlags(&R->streams[s], hipStreamNonBlocking) != hipSuccess) { delete R; return SBA_E_LAUNCH; }
-    for (auto& e : R->events)
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete R; return SBA_E_LAUNCH; }
+    R->critical.assign(R->nodes.size(), 0);
     if (hipEventCreateWithFlags(&R->start, hipEventDisableTiming) != hipSuccess) { delete R; return SBA_E_LAUNCH; }
-    R->tail_event.assign(used_streams, -1);
-    for (int s = 0; s < used_streams; ++s) {
-        hipEvent_t e;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete R; return SBA_E_LAUNCH; }
-        R->tail_event[s] = (int)R->events.size();
-        R->events.push_back(e);
-    }
+    const int rc = assign_streams(R);
+    if (rc != SBA_OK) { sba_replay_destroy(R); return rc; }
     if (verbose)
-        fprintf(stderr, "sba_replay: %zu nodes (%d kernels, %d copies, %d memsets), %zu edges -> %d streams, %d cross-stream waits\n",
-                n, R->n_kernels, R->n_copies, R->n_memsets, ne, used_streams, R->n_waits);
+        fprintf(stderr, "sba_replay: %zu nodes (%d kernels, %d copies, %d memsets), %zu edges -> %zu streams, %d cross-stream waits\n",
+                n, R->n_kernels, R->n_copies, R->n_memsets, ne, R->streams.size(), R->n_waits);
     *out = R;
     return SBA_OK;
 }
@@ -250,37 +326,7 @@ extern "C" int sba_replay_launch(void* handle, void* stream) {
     for (RNode& r : R->nodes) {
         hipStream_t s = R->streams[r.stream] ? R->streams[r.stream] : caller;
         for (int e : r.waits) RCHECK(hipStreamWaitEvent(s, R->events[e], 0));
-        switch (r.type) {
-            case hipGraphNodeTypeKernel:
-                if (r.marker >= 0) {
-                    // host-call node: everything it depends on has been ISSUED (stream-ordered before s's current
-                    // position); the callback may enqueue on s and make s wait for other streams
-                    if (R->cb) R->cb(r.marker, (void*)s, R->cb_user);
-                    break;
-                }
-                if (r.hfunc)
-                    RCHECK(hipModuleLaunchKernel(r.hfunc, r.kp.gridDim.x, r.kp.gridDim.y, r.kp.gridDim.z, r.kp.blockDim.x,
-                                                 r.kp.blockDim.y, r.kp.blockDim.z, r.kp.sharedMemBytes, s,
-                                                 r.kp.kernelParams, r.kp.extra));
-                else
-                    RCHECK(hipLaunchKernel(r.kp.func, r.kp.gridDim, r.kp.blockDim, r.kp.kernelParams,
-                                           r.kp.sharedMemBytes, s));
-                break;
-            case hipGraphNodeTypeMemcpy:
-                RCHECK(hipMemcpyAsync(r.cp.dstPtr.ptr, r.cp.srcPtr.ptr, r.cp.extent.width, r.cp.kind, s));
-                break;
-            case hipGraphNodeTypeMemset:
-                if (r.ms.height <= 1) {
-                    if (r.ms.elementSize == 4) RCHECK(hipMemsetD32Async((hipDeviceptr_t)r.ms.dst, (int)r.ms.value, r.ms.width, s));
-                    else if (r.ms.elementSize == 2) RCHECK(hipMemsetD16Async((hipDeviceptr_t)r.ms.dst, (unsigned short)r.ms.value, r.ms.width, s));
-                    else RCHECK(hipMemsetAsync(r.ms.dst, (int)r.ms.value, r.ms.width, s));
-                } else {
-                    RCHECK(hipMemset2DAsync(r.ms.dst, r.ms.pitch, (int)r.ms.value, r.ms.width * r.ms.elementSize, r.ms.height, s));
-                }
-                break;
-            default:
-                break;      // empty node: ordering only
-        }
+        { const int rc = issue_node(R, r, s); if (rc != SBA_OK) return rc; }
         if (r.record >= 0) RCHECK(hipEventRecord(R->events[r.record], s));
     }
     for (size_t s = own0 ? 0 : 1; s < R->streams.size(); ++s) {
@@ -295,6 +341,93 @@ extern "C" int sba_replay_launch(void* handle, void* stream) {
                                       R->nodes.size(), us, us / R->nodes.size());
     }
     return SBA_OK;
+}
+
+
+extern "C" int sba_replay_prioritize(void* handle, void* stream, int mode, int max_streams, int n_high, float slack_frac,
+                                     int verbose) {
+    if (!handle || mode < 0 || mode > 3 || max_streams < 2 || max_streams > 32 || n_high < 1 || n_high >= max_streams ||
+        !(slack_frac >= 0.f && slack_frac <= 1.f))
+        return SBA_E_ARG;
+    Replayer* R = (Replayer*)handle;
+    if (R->on_caller) return SBA_E_ARG;
+    hipStream_t caller = (hipStream_t)stream;
+    const int n = (int)R->nodes.size();
+    (void)hipGetLastError();
+    // 1. every node alone, in issue order on the caller's stream, an event between neighbours: durations without contention
+    std::vector<hipEvent_t> ev(n + 1, nullptr);
+    for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return SBA_E_LAUNCH;
+    int rc = SBA_OK;
+    for (int u = 0; u < n && rc == SBA_OK; ++u) {
+        if (hipEventRecord(ev[u], caller) != hipSuccess) rc = SBA_E_LAUNCH;
+        if (rc == SBA_OK) rc = issue_node(R, R->nodes[u], caller);
+    }
+    if (rc == SBA_OK && hipEventRecord(ev[n], caller) != hipSuccess) rc = SBA_E_LAUNCH;
+    if (hipStreamSynchronize(caller) != hipSuccess) rc = SBA_E_LAUNCH;
+    R->dur_us.assign(n, 0.f);
+    for (int u = 0; u < n && rc == SBA_OK; ++u) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev[u], ev[u + 1]) != hipSuccess) rc = SBA_E_LAUNCH;
+        R->dur_us[u] = ms * 1e3f;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    if (rc != SBA_OK) { (void)hipGetLastError(); return rc; }
+    // 2. earliest start (tl) and longest path to the end (bl) of every node; slack = longest path of the step - (tl + bl)
+    std::vector<double> tl(n, 0.0), bl(n, 0.0), below(n, 0.0);
+    for (int u = 0; u < n; ++u)
+        for (int d : R->deps[u]) tl[u] = std::max(tl[u], tl[d] + (double)R->dur_us[d]);
+    for (int u = n - 1; u >= 0; --u) {
+        bl[u] = (double)R->dur_us[u] + below[u];
+        for (int d : R->deps[u]) below[d] = std::max(below[d], bl[u]);
+    }
+    double cp = 0.0, total = 0.0;
+    for (int u = 0; u < n; ++u) { cp = std::max(cp, tl[u] + bl[u]); total += R->dur_us[u]; }
+    const double thr = slack_frac * cp;
+    int ncrit = 0;
+    double tcrit = 0.0;
+    for (int u = 0; u < n; ++u) {
+        const double slack = cp - tl[u] - bl[u];
+        bool c = slack <= thr;
+        if (!c && slack <= 2.0 * thr)           // hysteresis: a chain does not hop between the pools at the threshold
+            for (int d : R->deps[u]) c = c || R->critical[d];
+        R->critical[u] = (mode != 0 && c) ? 1 : 0;
+        if (c) { ++ncrit; tcrit += R->dur_us[u]; }
+    }
+    if (verbose) {
+        fprintf(stderr, "sba_replay_prioritize: %d nodes, %.0f us of work alone, longest dependency path %.0f us; %d nodes "
+                        "(%.0f us) within %.0f us of it -> %d high-priority stream(s) of %d (mode %d)\n",
+                n, total, cp, ncrit, tcrit, thr, n_high, max_streams, mode);
+        auto node_name = [&](const RNode& r) -> const char* {
+            const char* nm = r.type == hipGraphNodeTypeKernel ? (r.marker >= 0 ? "(host call)" : (r.hfunc ? "(module function)" : hipKernelNameRefByPtr(r.kp.func, nullptr)))
+                             : r.type == hipGraphNodeTypeMemcpy ? "(copy)" : r.type == hipGraphNodeTypeMemset ? "(fill)" : "(empty)";
+            return nm ? nm : "(?)";
+        };
+        if (verbose > 2)                        // every node: duration alone, slack, kernel
+            for (int v = 0; v < n; ++v)
+                fprintf(stderr, "  node %4d %7.1f %8.1f  %.100s (%u,%u,%u)\n", v, R->dur_us[v], cp - tl[v] - bl[v], node_name(R->nodes[v]),
+                        R->nodes[v].kp.gridDim.x, R->nodes[v].kp.gridDim.y, R->nodes[v].kp.gridDim.z);
+        if (verbose > 1) {                      // the longest path, node by node
+            int u = -1;
+            for (int v = 0; v < n; ++v) if (R->deps[v].empty() && bl[v] >= cp - 1e-6) { u = v; break; }
+            std::vector<std::vector<int>> succ(n);
+            for (int v = 0; v < n; ++v) for (int d : R->deps[v]) succ[d].push_back(v);
+            while (u >= 0) {
+                const RNode& r = R->nodes[u];
+                fprintf(stderr, "  cp %8.1f %7.1f  %.100s (%u,%u,%u)\n", tl[u], R->dur_us[u], node_name(r), r.kp.gridDim.x, r.kp.gridDim.y, r.kp.gridDim.z);
+                int nx = -1;
+                for (int v : succ[u]) if (nx < 0 || bl[v] > bl[nx]) nx = v;
+                u = nx;
+            }
+        }
+    }
+    // 3. the streams again, in two pools
+    R->prio_mode = mode;
+    R->max_streams = max_streams;
+    R->n_high = n_high;
+    rc = assign_streams(R);
+    if (verbose)
+        fprintf(stderr, "sba_replay_prioritize: %zu streams, %d cross-stream waits\n", R->streams.size(), R->n_waits);
+    return rc;
 }
 
 extern "C" int sba_replay_info(void* handle, int* info8) {

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SBA_LIB_PATH') or os.path.join(os.path.dirname(_HERE), 'csrc', 'libsbagan_hip.so')
 
 SBA_F32, SBA_BF16, SBA_BF16_YH = 0, 1, 2
-IGEMM_TILES = 15          # SBA_IGEMM_TILES of include/sbagan_hip.h
+IGEMM_TILES = 18          # SBA_IGEMM_TILES of include/sbagan_hip.h
 ACT_NONE, ACT_GLU, ACT_LRELU, ACT_RELU = 0, 1, 2, 3
 MAX_TAPS = 32
 
@@ -135,6 +135,7 @@ SIGNATURES = {
     'sba_replay_create': [P, I, I, POINTER(c_void_p)],
     'sba_replay_launch': [P, P],
     'sba_replay_info': [P, POINTER(c_int)],
+    'sba_replay_prioritize': [P, P, I, I, I, c_float, I],
     'sba_replay_marker': [I, P],
     'sba_replay_set_callback': [P, P, P],
     'sba_replay_destroy': [P],

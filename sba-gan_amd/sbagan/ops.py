@@ -475,7 +475,8 @@ def _table_section(name):
     global _TABLE_FILE
     if _TABLE_FILE is None:
         _TABLE_FILE = {}
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'igemm_table.json')
+        path = os.environ.get('SBA_IGEMM_TABLE_FILE') or os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                      'igemm_table.json')      # (the override: an A/B aid)
         if os.environ.get('SBA_IGEMM_TABLE', '1') != '0' and os.path.exists(path):
             import json
             with open(path) as f:

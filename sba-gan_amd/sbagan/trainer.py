@@ -671,6 +671,13 @@ class GANStep(object):
     def _d_streams(self):
         if getattr(self, '_streams', None) is None:
             self._streams = [torch.cuda.Stream(device=self.device) for _ in range(len(self.netsD) + 1)]
+            # The two small discriminators' updates (and their generator-loss terms) share ONE stream: D_NET64 then D_NET128,
+            # 3.1 + 4.3 ms of slack against the longest path (sba_replay_prioritize's report, profiles/r04_ab_stream_priorities.txt).
+            # Three chains beside the image encoder's instead of four: the encoder's ~160 short launches, which gate the
+            # generator's backward pass, get a third of the dispatch slots instead of a quarter -- 10.46 -> 10.19..10.39 ms
+            # (profiles/r04_ab_d_merge.txt).  SBA_D_MERGE=0: one stream per discriminator.
+            if os.environ.get('SBA_D_MERGE', '1') == '1' and len(self.netsD) >= 3:
+                self._streams[0] = self._streams[1]
         return self._streams
 
     def grad_norm(self, flat):
@@ -1000,6 +1007,10 @@ class GraphedStep(object):
 
 
 
+# ReplayedStep.prioritize: 'mode:streams:n_high:slack' unless SBA_REPLAY_PRIO says otherwise ('0' = no priorities)
+REPLAY_PRIO_DEFAULT = '0'
+
+
 class ReplayedStep(object):
     """GANStep re-issued by the native multi-stream launch replayer (csrc/replay.hip): the whole step is stream-
     captured ONCE into a hipGraph -- with every fork GANStep.step makes (the three discriminator updates, the
@@ -1075,10 +1086,7 @@ class ReplayedStep(object):
         if rc != 0:
             raise RuntimeError('sba_replay_create failed (%d): the captured step holds a node the replayer '
                                'cannot re-issue' % rc)
-        info = (ctypes.c_int * 8)()
-        call('sba_replay_info', self.handle, info)
-        self.info = dict(zip(('nodes', 'kernels', 'copies', 'memsets', 'streams', 'waits', 'events', 'host_calls'),
-                             list(info)))
+        self._refresh_info()
         self._cb = self._cb_error = None
         if self._rec is not None:
             assert self.info['host_calls'] == len(self._rec.calls), (self.info, len(self._rec.calls))
@@ -1107,6 +1115,41 @@ class ReplayedStep(object):
     def finish(self):
         """data-parallel: apply the generator update the last replay left pending (GANStep.finish)"""
         self.gan.finish()
+
+    def _refresh_info(self):
+        info = (ctypes.c_int * 8)()
+        call('sba_replay_info', self.handle, info)
+        self.info = dict(zip(('nodes', 'kernels', 'copies', 'memsets', 'streams', 'waits', 'events', 'host_calls'),
+                             list(info)))
+
+    def prioritize(self, spec=None, verbose=0):
+        """Stream priorities for the recording's longest dependency path (include/sbagan_hip.h: sba_replay_prioritize).
+        THIS IS ONE TRAINING STEP -- the recording is executed once, every launch alone, to time it -- and is to be counted
+        as a replay() by the caller; afterwards replay() issues the nodes within `slack` of the longest path on `n_high`
+        streams of the higher priority and the rest on `streams - n_high` others.
+        spec: 'mode[:streams[:n_high[:slack]]]' (None = SBA_REPLAY_PRIO from the environment, default below); mode 0 = off
+        (returns None without running anything).  Data-parallel: every rank calls it at the same point (the step's
+        collectives run)."""
+        spec = os.environ.get('SBA_REPLAY_PRIO', REPLAY_PRIO_DEFAULT) if spec is None else str(spec)
+        f = spec.split(':')
+        if f[0] == 'c':         # calibrate only (the durations / the longest path on stderr), one pool, no priorities
+            mode = 0
+        else:
+            mode = int(f[0])
+            if mode == 0:
+                return None
+        streams = int(f[1]) if len(f) > 1 else 6
+        n_high = int(f[2]) if len(f) > 2 else 2
+        slack = float(f[3]) if len(f) > 3 else 0.08
+        ops.weights_changed()
+        self._draw()
+        call('sba_replay_prioritize', self.handle, torch.cuda.current_stream().cuda_stream, mode, streams, n_high,
+             ctypes.c_float(slack), int(verbose))
+        if self._cb_error is not None:
+            e, self._cb_error = self._cb_error, None
+            raise e
+        self._refresh_info()
+        return self.out
 
     def replay(self):
         ops.weights_changed()

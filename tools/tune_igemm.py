@@ -14,9 +14,9 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import torch  # noqa: E402
 
-NTILES = 15
-TILE_BM = {1: 64, 2: 64, 3: 96, 4: 96, 5: 128, 6: 128, 7: 128, 8: 128, 9: 256, 10: 256, 11: 320, 12: 96, 13: 320, 14: 160, 15: 160}
-TILE_BN = {1: 64, 2: 64, 3: 64, 4: 64, 5: 64, 6: 64, 7: 128, 8: 128, 9: 64, 10: 64, 11: 128, 12: 128, 13: 64, 14: 64, 15: 64}
+NTILES = 18
+TILE_BM = {1: 64, 2: 64, 3: 96, 4: 96, 5: 128, 6: 128, 7: 128, 8: 128, 9: 256, 10: 256, 11: 320, 12: 96, 13: 320, 14: 160, 15: 160, 16: 256, 17: 256, 18: 256}
+TILE_BN = {1: 64, 2: 64, 3: 64, 4: 64, 5: 64, 6: 64, 7: 128, 8: 128, 9: 64, 10: 64, 11: 128, 12: 128, 13: 64, 14: 64, 15: 64, 16: 128, 17: 128, 18: 128}
 
 
 def main():
@@ -58,12 +58,16 @@ def main():
     total_rule = total_best = 0.0
     # TUNE_MAX_M=n: re-measure only the shapes with at most n rows, keep the committed entries of the others
     max_m = int(os.environ.get('TUNE_MAX_M', '0'))
+    # TUNE_MIN_GFLOP=f: re-measure only the shapes of at least f GFLOP (the large GEMM-like layers), keep the others
+    min_gflop = float(os.environ.get('TUNE_MIN_GFLOP', '0'))
     out = os.path.join(ROOT, 'sba-gan_amd', 'sbagan', 'igemm_table.json')
-    if max_m:
+    if max_m or min_gflop:
         with open(out) as f:
             table = json.load(f)['bf16']
     for k, (g0, count) in sorted(uniq.items()):
         if max_m and g0.N * g0.OHs * g0.OWs > max_m:
+            continue
+        if min_gflop and 2.0 * g0.N * g0.OHs * g0.OWs * g0.Cout * g0.ntaps * g0.Cin < min_gflop * 1e9:
             continue
         table.pop(k, None)
         g = ConvGeom()
@@ -102,7 +106,7 @@ def main():
         cands = []
         for tile in range(1, NTILES + 1):
             bm, bn = TILE_BM[tile], TILE_BN[tile]
-            if bm >= 2 * M + 64 or (bn == 128 and g.Cout <= 64) or (tile in (13, 14, 15) and (g.Cin % 64 or M > 4096)):
+            if bm >= 2 * M + 64 or (bn == 128 and g.Cout <= 64) or (tile in (13, 14, 15) and (g.Cin % 64 or M > 4096)) or (tile >= 16 and (g.Cin % 64 or M < 2048)):
                 continue
             tiles = -(-M // bm) * -(-g.Cout // bn)
             splits = [1]
