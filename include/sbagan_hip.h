@@ -368,6 +368,10 @@ int sba_enc_stem_fwd(int dtype, const float* img, const float* w, const float* b
                      void* stream);
 int sba_enc_stem_bwd(int dtype, const float* w, const void* out, const void* dout, float* dimg, int N, int S, int C,
                      void* stream);
+/* both of the above in one launch: the stem conv (C = 32) reading the S -> D bilinear resize of the image on the fly -- the
+ * D x D tensor (model.py:210: 299 x 299) is never written; the interpolation is sba_resize_bilinear's expression. */
+int sba_enc_stem_resize_fwd(int dtype, const float* img, const float* w, const float* bias, void* out, int N, int S, int D,
+                            int C, void* stream);
 /* F.max_pool2d(x, 3, 2) on NHWC channel slices (cs = channel stride, co = channel offset); the backward
  * routes each window's gradient to its first maximum in scan order (torch's tie rule). */
 int sba_maxpool3x3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, int xcs, int xco, int ycs,
@@ -379,7 +383,9 @@ int sba_maxpool3x3s2_bwd(int dtype, const void* x, const void* dy, void* dx, int
 int sba_maxpool3x3s2_fwd_arg(int dtype, const void* x, void* y, uint8_t* argmax, int N, int H, int W, int C, int xcs,
                              int xco, int ycs, int yco, void* stream);
 int sba_maxpool3x3s2_bwd_arg(int dtype, const uint8_t* argmax, const void* dy, void* dx, int N, int H, int W, int C,
-                             int dycs, int dyco, int dxcs, int dxco, int accumulate, void* stream);
+                             int dycs, int dyco, int dxcs, int dxco, int accumulate, const void* relu_mask, void* stream);
+/* (relu_mask, optional: a tensor laid out like dx -- the pooled tensor itself when a ReLU produced it; dx is zeroed where
+ * it is <= 0, after the accumulation: the ReLU's backward without a pass of its own) */
 /* F.avg_pool2d(x, 3, 1, 1) (count_include_pad); self-adjoint, so it is also its own backward. */
 int sba_avgpool3x3(int dtype, const void* x, void* y, int N, int H, int W, int C, int xcs, int xco, int ycs, int yco,
                    int accumulate, void* stream);

@@ -104,6 +104,59 @@ __global__ __launch_bounds__(256) void enc_stem_fwd_kernel(const float* __restri
     }
 }
 
+// The same conv reading the bilinear resize (resize_fwd_kernel: align_corners, S -> D) of the image ON THE FLY: the D x D
+// tensor is never written.  thread = one output pixel, all C <= 32 channels (the 27 interpolated inputs are computed once
+// per pixel; weights are LDS broadcasts); the interpolation is resize_fwd_kernel's expression term by term.
+template <typename T, int C>
+__global__ __launch_bounds__(256) void enc_stem_resize_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, T* __restrict__ out,
+                                                                  int N, int S, int D, int O) {
+    constexpr int V = Vec16<T>::N;
+    __shared__ float s_w[27 * C];        // [27][C]
+    for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) {
+        const int co = i / 27, k = i - co * 27;
+        s_w[k * C + co] = w[i];
+    }
+    __syncthreads();
+    const float sc = (float)(S - 1) / (float)(D - 1);
+    const int64_t total = (int64_t)N * O * O;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(p % O), oy = (int)((p / O) % O), n = (int)(p / ((int64_t)O * O));
+        int y0[3], y1[3], x0[3], x1[3];
+        float wy[3], wx[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float fy = (2 * oy + k) * sc, fx = (2 * ox + k) * sc;
+            y0[k] = min((int)fy, S - 1); x0[k] = min((int)fx, S - 1);
+            y1[k] = min(y0[k] + 1, S - 1); x1[k] = min(x0[k] + 1, S - 1);
+            wy[k] = fy - y0[k]; wx[k] = fx - x0[k];
+        }
+        float acc[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) acc[k] = bias ? bias[k] : 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float* q = img + ((int64_t)n * 3 + ci) * S * S;
+                    const float v = (1.f - wy[kh]) * ((1.f - wx[kw]) * q[y0[kh] * S + x0[kw]] + wx[kw] * q[y0[kh] * S + x1[kw]]) +
+                                    wy[kh] * ((1.f - wx[kw]) * q[y1[kh] * S + x0[kw]] + wx[kw] * q[y1[kh] * S + x1[kw]]);
+                    const float* wr = &s_w[((kh * 3 + kw) * 3 + ci) * C];
+#pragma unroll
+                    for (int k = 0; k < C; ++k) acc[k] += v * wr[k];
+                }
+#pragma unroll
+        for (int c = 0; c < C; c += V) {
+            Vec16<T> o;
+#pragma unroll
+            for (int k = 0; k < V; ++k) o.set(k, bias ? fmaxf(acc[c + k], 0.f) : acc[c + k]);
+            st16(out + p * C + c, o);
+        }
+    }
+}
+
 // dimg[n][ci][iy][ix] = sum over output pixels (<= 2 x 2) reading it and all co of dout*(out>0)*w
 template <typename T>
 __global__ __launch_bounds__(256) void enc_stem_bwd_kernel(const float* __restrict__ w, const T* __restrict__ out,
@@ -220,7 +273,7 @@ __global__ void maxpool_fwd_arg_kernel(const T* __restrict__ x, T* __restrict__ 
 template <typename T>
 __global__ void maxpool_bwd_arg_kernel(const uint8_t* __restrict__ arg, const T* __restrict__ dy, T* __restrict__ dx,
                                        int N, int H, int W, int C, int dycs, int dyco, int dxcs, int dxco,
-                                       int accumulate) {
+                                       int accumulate, const T* __restrict__ relu_mask) {
     constexpr int V = Vec16<T>::N;
     const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1, cv = C / V;
     const int64_t total = (int64_t)N * H * W * cv;
@@ -255,6 +308,11 @@ __global__ void maxpool_bwd_arg_kernel(const uint8_t* __restrict__ arg, const T*
         if (accumulate) o = ld16(op);
 #pragma unroll
         for (int k = 0; k < V; ++k) o.set(k, g[k] + (accumulate ? o.get(k) : 0.f));
+        if (relu_mask) {        // laid out like dx: the backward of the ReLU that produced the pooled tensor
+            const Vec16<T> m = ld16(relu_mask + p * dxcs + dxco + c);
+#pragma unroll
+            for (int k = 0; k < V; ++k) if (!(m.get(k) > 0.f)) o.set(k, 0.f);
+        }
         st16(op, o);
     }
 }
@@ -486,14 +544,24 @@ extern "C" int sba_maxpool3x3s2_fwd_arg(int dtype, const void* x, void* y, uint8
 }
 
 extern "C" int sba_maxpool3x3s2_bwd_arg(int dtype, const uint8_t* argmax, const void* dy, void* dx, int N, int H, int W,
-                                        int C, int dycs, int dyco, int dxcs, int dxco, int accumulate, void* stream) {
+                                        int C, int dycs, int dyco, int dxcs, int dxco, int accumulate,
+                                        const void* relu_mask, void* stream) {
     if (!argmax || !dy || !dx || N <= 0 || H < 3 || W < 3 || !slice_ok(dtype, C, dycs, dyco) ||
         !slice_ok(dtype, C, dxcs, dxco) || ((uintptr_t)argmax & 7) != 0)
         return SBA_E_ARG;
     const int V = dtype == SBA_BF16 ? 8 : 4;
     SBA_DISPATCH(dtype, SBA_LAUNCH((maxpool_bwd_arg_kernel<T>), dim3(grid_for((int64_t)N * H * W * (C / V))),
                                            dim3(256), 0, (hipStream_t)stream, argmax, (const T*)dy, (T*)dx, N, H, W, C,
-                                           dycs, dyco, dxcs, dxco, accumulate));
+                                           dycs, dyco, dxcs, dxco, accumulate, (const T*)relu_mask));
+    return SBA_CHECK_LAUNCH();
+}
+
+extern "C" int sba_enc_stem_resize_fwd(int dtype, const float* img, const float* w, const float* bias, void* out, int N,
+                                       int S, int D, int C, void* stream) {
+    if (!img || !w || !out || N <= 0 || S < 2 || D < 3 || C != 32) return SBA_E_ARG;
+    const int O = (D - 3) / 2 + 1;
+    SBA_DISPATCH(dtype, SBA_LAUNCH((enc_stem_resize_fwd_kernel<T, 32>), dim3(grid_for((int64_t)N * O * O, 8192)),
+                                           dim3(256), 0, (hipStream_t)stream, img, w, bias, (T*)out, N, S, D, O));
     return SBA_CHECK_LAUNCH();
 }
 

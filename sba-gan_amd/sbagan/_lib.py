@@ -94,11 +94,12 @@ SIGNATURES = {
     'sba_cond_cat_bwd': [I, P, P, P, I, I, I, I, P],
     'sba_resize_bilinear': [P, P, I, I, I, I, P],
     'sba_enc_stem_fwd': [I, P, P, P, P, I, I, I, P],
+    'sba_enc_stem_resize_fwd': [I, P, P, P, P, I, I, I, I, P],
     'sba_enc_stem_bwd': [I, P, P, P, P, I, I, I, P],
     'sba_maxpool3x3s2_fwd': [I, P, P, I, I, I, I, I, I, I, I, P],
     'sba_maxpool3x3s2_bwd': [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P],
     'sba_maxpool3x3s2_fwd_arg': [I, P, P, P, I, I, I, I, I, I, I, I, P],
-    'sba_maxpool3x3s2_bwd_arg': [I, P, P, P, I, I, I, I, I, I, I, I, I, P],
+    'sba_maxpool3x3s2_bwd_arg': [I, P, P, P, I, I, I, I, I, I, I, I, I, P, P],
     'sba_avgpool3x3': [I, P, P, I, I, I, I, I, I, I, I, I, P],
     'sba_relu_bwd': [I, P, P, P, L, I, I, I, I, I, P],
     'sba_global_avgpool': [I, P, P, I, I, I, I, P],

@@ -446,14 +446,21 @@ class InceptionHIP(object):
     def _maxpool_bwd(self, x, out, arg=None):
         gy, gx = self._grad_of(out), self._grad_of(x)
         N, H, W, Ct = x.shape
+        kx = self._key(x)
+        self._readers[kx] -= 1
+        # the last reader of a ReLU output to run its backward applies the ReLU's mask (as the data-gradient convs do in
+        # their epilogue): the stem's two pools, whose producers then skip the separate relu_bwd pass
+        final = arg is not None and self._readers[kx] == 0 and kx in self._relu_slices
         if arg is not None:
             call('sba_maxpool3x3s2_bwd_arg', self._dt(), arg.data_ptr(), gy[0].data_ptr(), gx[0].data_ptr(), N, H, W, x.C,
-                 out.shape[3], out.coff, Ct, x.coff, 1 if self._has_grad(x) else 0, ops._stream())
+                 out.shape[3], out.coff, Ct, x.coff, 1 if self._has_grad(x) else 0, x.t.data_ptr() if final else None,
+                 ops._stream())
         else:
             call('sba_maxpool3x3s2_bwd', self._dt(), x.t.data_ptr(), gy[0].data_ptr(), gx[0].data_ptr(), N, H, W, x.C, Ct,
                  x.coff, out.shape[3], out.coff, Ct, x.coff, 1 if self._has_grad(x) else 0, ops._stream())
-        self._filled.add(self._key(x))
-        self._readers[self._key(x)] -= 1
+        self._filled.add(kx)
+        if final:
+            self._masked.add(kx)
 
     def avgpool(self, x):
         N, H, W, Ct = x.shape
@@ -666,18 +673,17 @@ class InceptionHIP(object):
         self._readers, self._relu_slices, self._masked, self._filled = {}, set(), set(), set()
         self.named = {}
         st = ops._stream()
-        x299 = torch.empty((N, 3, 299, 299), dtype=torch.float32, device=self.device)
-        call('sba_resize_bilinear', img.data_ptr(), x299.data_ptr(), N * 3, S, 299, 0, st)
+        # the 299 x 299 resize (model.py:210) is never written: the stem conv interpolates on the fly
         a0 = _Act(self._new(N, 149, 149, 32))
         if self._train:
             stem = self.enc.Conv2d_1a_3x3
             wraw = stem.conv.weight.detach().float().contiguous(memory_format=torch.channels_last)
             y0 = torch.empty((N, 149, 149, 32), dtype=self.dtype, device=self.device)
-            call('sba_enc_stem_fwd', dt, x299.data_ptr(), wraw.data_ptr(), None, y0.data_ptr(), N, 299, 32, st)
+            call('sba_enc_stem_resize_fwd', dt, img.data_ptr(), wraw.data_ptr(), None, y0.data_ptr(), N, S, 299, 32, st)
             self._bn_relu_train(y0, stem.bn, N * 149 * 149, 32, a0.t, 32, 0)
         else:
-            call('sba_enc_stem_fwd', dt, x299.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(),
-                 a0.t.data_ptr(), N, 299, 32, st)
+            call('sba_enc_stem_resize_fwd', dt, img.data_ptr(), self.stem_w.data_ptr(), self.stem_b.data_ptr(),
+                 a0.t.data_ptr(), N, S, 299, 32, st)
         nm = self.named
         nm['Conv2d_1a_3x3'] = a0
         a = nm['Conv2d_2a_3x3'] = self.conv('Conv2d_2a_3x3', a0)
@@ -704,7 +710,7 @@ class InceptionHIP(object):
         nef = self.nef
         features = torch.empty((N, f.C, 17, 17), dtype=torch.float32, device=self.device)
         call('sba_layout_nhwc_nchw', dt, f.t.data_ptr(), features.data_ptr(), N, 289, f.C, 0, st)
-        self._saved = (img.shape, x299, a0, f, a, pooled_t, code)
+        self._saved = (img.shape, None, a0, f, a, pooled_t, code)
         return features[:, :nef], code.t.view(N, -1)[:, :nef].float()
 
     def trunk_features(self, img, train=False):
@@ -824,7 +830,7 @@ class InceptionHIP(object):
             for op in sorted(held, key=lambda o: 0 if o[0] != 'conv' else 1) + list(reversed(pre)):
                 run(op)
         g0 = self._grad_of(a0)
-        d299 = torch.empty_like(x299)
+        d299 = torch.empty((N, 3, 299, 299), dtype=torch.float32, device=self.device)
         call('sba_enc_stem_bwd', dt, self.stem_w.data_ptr(), a0.t.data_ptr(), g0[0].data_ptr(), d299.data_ptr(), N,
              299, 32, st)
         dimg = torch.empty(ishape, dtype=torch.float32, device=self.device)

@@ -415,7 +415,15 @@ def test_maxpool3x3s2_pairs(dev, dt):
             _lib.call('sba_maxpool3x3s2_fwd_arg', dtc, xa.data_ptr(), y.data_ptr(), arg.data_ptr(), N, H, W, C, Ct, co,
                       C, 0, st)
             _lib.call('sba_maxpool3x3s2_bwd_arg', dtc, arg.data_ptr(), dya.data_ptr(), gx.data_ptr(), N, H, W, C, C, 0,
-                      Ct, co, 1, st)
+                      Ct, co, 1, None, st)
+            # the same with the ReLU mask of the pooled tensor folded in (x doubles as the mask: zeroed where x <= 0)
+            gm = torch.zeros((N, H, W, Ct), dtype=dt, device=dev)
+            gm[..., co:co + C] = base.permute(0, 2, 3, 1).to(dev).to(dt)
+            _lib.call('sba_maxpool3x3s2_bwd_arg', dtc, arg.data_ptr(), dya.data_ptr(), gm.data_ptr(), N, H, W, C, C, 0,
+                      Ct, co, 1, xa.data_ptr(), st)
+            torch.cuda.synchronize()
+            want = gx[..., co:co + C] * (xa[..., co:co + C] > 0)
+            assert torch.equal(gm[..., co:co + C], want), 'masked maxpool backward'
         else:
             _lib.call('sba_maxpool3x3s2_fwd', dtc, xa.data_ptr(), y.data_ptr(), N, H, W, C, Ct, co, C, 0, st)
             _lib.call('sba_maxpool3x3s2_bwd', dtc, xa.data_ptr(), dya.data_ptr(), gx.data_ptr(), N, H, W, C, Ct, co, C, 0,
@@ -424,6 +432,38 @@ def test_maxpool3x3s2_pairs(dev, dt):
         assert torch.equal(y.float().cpu().permute(0, 3, 1, 2), yr.detach()), 'max is exact'
         close(gx[..., co:co + C].permute(0, 3, 1, 2), gref + base, dt, 'dx keep=%s' % keep)
         assert float(gx[..., :co].float().abs().max()) == 0.0 and float(gx[..., co + C:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('dt', DTYPES)
+def test_stem_conv_on_the_resized_image(dev, dt):
+    """Conv2d_1a_3x3 reading the 299 x 299 bilinear resize on the fly (sba_enc_stem_resize_fwd) against the two launches
+    it replaces (sba_resize_bilinear + sba_enc_stem_fwd) and against F.interpolate + F.conv2d (model.py:210-213)."""
+    from sbagan import _lib, ops
+    N, S, D, C = 3, 64, 75, 32
+    dtc = _lib.SBA_BF16 if dt == torch.bfloat16 else _lib.SBA_F32
+    img = fill.unit((N, 3, S, S), 41)
+    w = fill.unit((C, 3, 3, 3), 42) / 5
+    b = fill.unit((C,), 43) / 10
+    st = ops._stream()
+    imga = img.to(dev)
+    wa = w.to(dev).contiguous(memory_format=torch.channels_last)
+    ba = b.to(dev)
+    O = (D - 3) // 2 + 1
+    x = torch.empty((N, 3, D, D), dtype=torch.float32, device=dev)
+    y2 = torch.empty((N, O, O, C), dtype=dt, device=dev)
+    y1 = torch.full((N, O, O, C), float('nan'), dtype=dt, device=dev)
+    _lib.call('sba_resize_bilinear', imga.data_ptr(), x.data_ptr(), N * 3, S, D, 0, st)
+    _lib.call('sba_enc_stem_fwd', dtc, x.data_ptr(), wa.data_ptr(), ba.data_ptr(), y2.data_ptr(), N, D, C, st)
+    _lib.call('sba_enc_stem_resize_fwd', dtc, imga.data_ptr(), wa.data_ptr(), ba.data_ptr(), y1.data_ptr(), N, S, D, C, st)
+    torch.cuda.synchronize()
+    ref = torch.relu(F.conv2d(F.interpolate(img, size=(D, D), mode='bilinear', align_corners=True), w, b, stride=2))
+    close(y1.permute(0, 3, 1, 2), ref, dt, 'fused stem')
+    assert rel_l2(y1.float().cpu(), y2.float().cpu()) < (2e-3 if dt == torch.bfloat16 else 1e-6), 'fused vs two launches'
+    # no bias: the raw conv output of the training-mode trunk (no ReLU either)
+    _lib.call('sba_enc_stem_resize_fwd', dtc, imga.data_ptr(), wa.data_ptr(), None, y1.data_ptr(), N, S, D, C, st)
+    torch.cuda.synchronize()
+    ref = F.conv2d(F.interpolate(img, size=(D, D), mode='bilinear', align_corners=True), w, None, stride=2)
+    close(y1.permute(0, 3, 1, 2), ref, dt, 'fused stem, raw')
 
 
 # ------------------------------------------------------------------ fused blocks vs the oracle
