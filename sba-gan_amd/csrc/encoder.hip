@@ -105,55 +105,61 @@ __global__ __launch_bounds__(256) void enc_stem_fwd_kernel(const float* __restri
 }
 
 // The same conv reading the bilinear resize (resize_fwd_kernel: align_corners, S -> D) of the image ON THE FLY: the D x D
-// tensor is never written.  thread = one output pixel, all C <= 32 channels (the 27 interpolated inputs are computed once
-// per pixel; weights are LDS broadcasts); the interpolation is resize_fwd_kernel's expression term by term.
-template <typename T, int C>
+// tensor is never written.  Same thread mapping as above (output pixel, V channels): the C / V threads of a pixel each
+// interpolate its 27 inputs (L1 hits; the expression is resize_fwd_kernel's term by term); one kernel row at a time keeps
+// the live loads at 36 and the occupancy high -- the kernel is load-latency bound.
+template <typename T>
 __global__ __launch_bounds__(256) void enc_stem_resize_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                                   const float* __restrict__ bias, T* __restrict__ out,
-                                                                  int N, int S, int D, int O) {
+                                                                  int N, int S, int D, int O, int C) {
     constexpr int V = Vec16<T>::N;
-    __shared__ float s_w[27 * C];        // [27][C]
+    extern __shared__ float s_w[];       // [27][C]
     for (int i = threadIdx.x; i < 27 * C; i += blockDim.x) {
         const int co = i / 27, k = i - co * 27;
         s_w[k * C + co] = w[i];
     }
     __syncthreads();
     const float sc = (float)(S - 1) / (float)(D - 1);
-    const int64_t total = (int64_t)N * O * O;
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+    const int cv = C / V;
+    const int64_t total = (int64_t)N * O * O * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * V;
+        const int64_t p = i / cv;
         const int ox = (int)(p % O), oy = (int)((p / O) % O), n = (int)(p / ((int64_t)O * O));
-        int y0[3], y1[3], x0[3], x1[3];
-        float wy[3], wx[3];
+        int x0[3], x1[3];
+        float wx[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float fy = (2 * oy + k) * sc, fx = (2 * ox + k) * sc;
-            y0[k] = min((int)fy, S - 1); x0[k] = min((int)fx, S - 1);
-            y1[k] = min(y0[k] + 1, S - 1); x1[k] = min(x0[k] + 1, S - 1);
-            wy[k] = fy - y0[k]; wx[k] = fx - x0[k];
+            const float fx = (2 * ox + k) * sc;
+            x0[k] = min((int)fx, S - 1);
+            x1[k] = min(x0[k] + 1, S - 1);
+            wx[k] = fx - x0[k];
         }
-        float acc[C];
+        float acc[V];
 #pragma unroll
-        for (int k = 0; k < C; ++k) acc[k] = bias ? bias[k] : 0.f;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+        for (int k = 0; k < V; ++k) acc[k] = bias ? bias[c + k] : 0.f;
+        const float* q0 = img + (int64_t)n * 3 * S * S;
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh) {
+            const float fy = (2 * oy + kh) * sc;
+            const int y0 = min((int)fy, S - 1), y1 = min(y0 + 1, S - 1);
+            const float wy = fy - y0;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
                 for (int ci = 0; ci < 3; ++ci) {
-                    const float* q = img + ((int64_t)n * 3 + ci) * S * S;
-                    const float v = (1.f - wy[kh]) * ((1.f - wx[kw]) * q[y0[kh] * S + x0[kw]] + wx[kw] * q[y0[kh] * S + x1[kw]]) +
-                                    wy[kh] * ((1.f - wx[kw]) * q[y1[kh] * S + x0[kw]] + wx[kw] * q[y1[kh] * S + x1[kw]]);
-                    const float* wr = &s_w[((kh * 3 + kw) * 3 + ci) * C];
+                    const float* q = q0 + (int64_t)ci * S * S;
+                    const float v = (1.f - wy) * ((1.f - wx[kw]) * q[y0 * S + x0[kw]] + wx[kw] * q[y0 * S + x1[kw]]) +
+                                    wy * ((1.f - wx[kw]) * q[y1 * S + x0[kw]] + wx[kw] * q[y1 * S + x1[kw]]);
+                    const float* wr = &s_w[((kh * 3 + kw) * 3 + ci) * C + c];
 #pragma unroll
-                    for (int k = 0; k < C; ++k) acc[k] += v * wr[k];
+                    for (int k = 0; k < V; ++k) acc[k] += v * wr[k];
                 }
-#pragma unroll
-        for (int c = 0; c < C; c += V) {
-            Vec16<T> o;
-#pragma unroll
-            for (int k = 0; k < V; ++k) o.set(k, bias ? fmaxf(acc[c + k], 0.f) : acc[c + k]);
-            st16(out + p * C + c, o);
         }
+        Vec16<T> o;
+#pragma unroll
+        for (int k = 0; k < V; ++k) o.set(k, bias ? fmaxf(acc[k], 0.f) : acc[k]);
+        st16(out + p * C + c, o);
     }
 }
 
@@ -558,10 +564,11 @@ extern "C" int sba_maxpool3x3s2_bwd_arg(int dtype, const uint8_t* argmax, const 
 
 extern "C" int sba_enc_stem_resize_fwd(int dtype, const float* img, const float* w, const float* bias, void* out, int N,
                                        int S, int D, int C, void* stream) {
-    if (!img || !w || !out || N <= 0 || S < 2 || D < 3 || C != 32) return SBA_E_ARG;
-    const int O = (D - 3) / 2 + 1;
-    SBA_DISPATCH(dtype, SBA_LAUNCH((enc_stem_resize_fwd_kernel<T, 32>), dim3(grid_for((int64_t)N * O * O, 8192)),
-                                           dim3(256), 0, (hipStream_t)stream, img, w, bias, (T*)out, N, S, D, O));
+    if (!img || !w || !out || N <= 0 || S < 2 || D < 3 || C <= 0 || C % 8 || C > 256) return SBA_E_ARG;
+    const int O = (D - 3) / 2 + 1, V = dtype == SBA_BF16 ? 8 : 4;
+    SBA_DISPATCH(dtype, SBA_LAUNCH((enc_stem_resize_fwd_kernel<T>), dim3(grid_for((int64_t)N * O * O * (C / V), 8192)),
+                                           dim3(256), sizeof(float) * 27 * C, (hipStream_t)stream, img, w, bias, (T*)out, N,
+                                           S, D, O, C));
     return SBA_CHECK_LAUNCH();
 }
 

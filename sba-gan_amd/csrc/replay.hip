@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <map>
 #include <queue>
@@ -425,8 +426,37 @@ extern "C" int sba_replay_prioritize(void* handle, void* stream, int mode, int m
     R->max_streams = max_streams;
     R->n_high = n_high;
     rc = assign_streams(R);
-    if (verbose)
+    if (verbose) {
         fprintf(stderr, "sba_replay_prioritize: %zu streams, %d cross-stream waits\n", R->streams.size(), R->n_waits);
+        // which chains share a stream: per stream, the work alone and the nodes by slack (a chain's nodes share one slack value)
+        for (size_t st = 0; st < R->streams.size(); ++st) {
+            std::map<long, std::pair<int, double>> by_slack;
+            double w = 0.0;
+            int cnt = 0;
+            for (int u = 0; u < n; ++u)
+                if (R->nodes[u].stream == (int)st) {
+                    auto& b = by_slack[lround(cp - tl[u] - bl[u])];
+                    ++b.first; b.second += R->dur_us[u];
+                    w += R->dur_us[u]; ++cnt;
+                }
+            fprintf(stderr, "  stream %zu: %d nodes, %.0f us alone; slack(us):nodes:us", st, cnt, w);
+            for (auto& kv : by_slack) if (kv.second.first >= 8) fprintf(stderr, "  %ld:%d:%.0f", kv.first, kv.second.first, kv.second.second);
+            fprintf(stderr, "\n");
+        }
+        // the makespan these streams allow when nothing slows anything down: every node starts when its dependencies AND its
+        // predecessor on its stream have finished
+        std::vector<double> fin(n, 0.0), sfree(R->streams.size(), 0.0);
+        double span = 0.0;
+        for (int u = 0; u < n; ++u) {
+            double t0 = sfree[R->nodes[u].stream];
+            for (int d : R->deps[u]) t0 = std::max(t0, fin[d]);
+            fin[u] = t0 + R->dur_us[u];
+            sfree[R->nodes[u].stream] = fin[u];
+            span = std::max(span, fin[u]);
+        }
+        fprintf(stderr, "sba_replay_prioritize: with this stream assignment and no contention the recording takes %.0f us "
+                        "(longest dependency path %.0f us)\n", span, cp);
+    }
     return rc;
 }
 
