@@ -270,8 +270,14 @@ class GANStep(object):
     #                                 forwards ahead as their own passes, split backward passes) -- what a rank of the
     #                                 data-parallel step must reproduce bit for bit in the deterministic mode
 
+    # Single GPU: the discriminators' forward passes on the REAL images need nothing of the generator (losses.py:139): as
+    # their own passes (the reference's shape: netD(real), netD(fake) are separate calls) they run at the start of the step,
+    # beside the generator's forward pass -- a serial chain that leaves most of the chip idle -- instead of inside the
+    # crowded stretch between the generator's forward and backward passes (SBA_REAL_FIRST).
+    real_first = os.environ.get('SBA_REAL_FIRST', '0') == '1'
+
     def _two_pass(self):
-        return (self.distributed and self.overlap_g) or self.force_overlap_layout
+        return (self.distributed and self.overlap_g) or self.force_overlap_layout or self.real_first
 
     def phase_pre(self, imgs, streams=None):
         """netD_i(real_i) for every discriminator, ahead of the generator's (pending) update; a no-op outside the
