@@ -2321,6 +2321,162 @@ __global__ __launch_bounds__(256, 2) void wgrad_small_dma_kernel(const bf16_t* _
 }
 
 // ---------------------------------------------------------------------------
+// The 4x4 / stride-2 down blocks (encode_image_by_16times and the extra down blocks, model.py:540-575): the same
+// decomposition with the workgroup's four waves = the four kw taps of ONE kernel row kh and one 64-channel input tile.
+// The kernel above gathers a 32-pixel x slice per wave (tap): 128 pixel rows per stage.  The four kw taps of a kernel row
+// read the SAME input row(s) at column offsets 0..3 of a stride-2 walk, so here the stage holds that input row segment
+// once -- R output rows x Wc output columns = 32 pixels (Wc = min(OW, 32)) need R x (2 Wc + 2) <= 72 input pixels -- and
+// wave kw reads pixel p of it at LDS row r (2 Wc + 2) + 2 j + kw.  12 KB + 4 KB (dy) per stage instead of 20 KB, four DMA
+// instructions per wave instead of five, 1.6x fewer bytes L2 -> LDS per MFMA (the roofline of this family).
+// Channel chunk c of LDS row L sits at 16-byte position c ^ 2 ((L >> 1) & 3): the four stride-2 rows a 16-lane group reads
+// with ds_read_b64_tr_b16 fall into four different 32-byte bank groups.
+// ---------------------------------------------------------------------------
+struct WgFragS2 {
+    // fragment of channels [c32, c32+32) over output pixels [16 k16, 16 k16 + 16) of the chunk, tap column kw
+    static __device__ __forceinline__ bf16x8_t load(const unsigned char* xs, int k16, int c32, int lane, int kw, int wclog,
+                                                    int xw) {
+        const int g16 = lane >> 4, i16 = lane & 15;
+        const int cbase = c32 + 16 * (g16 & 1), p = 16 * k16 + 8 * (g16 >> 1) + (i16 >> 2), q = i16 & 3;
+        const int r = p >> wclog, j = p & ((1 << wclog) - 1);
+        const int L0 = r * xw + 2 * j + kw, L1 = L0 + 8;        // pixel p + 4: same output row (Wc >= 8)
+        const int c0 = (cbase >> 3) ^ (((L0 >> 1) & 3) << 1), c1 = (cbase >> 3) ^ (((L1 >> 1) & 3) << 1);
+        typedef __attribute__((address_space(3))) s16x4_t* lptr;
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xs + L0 * 128 + c0 * 16 + q * 8));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xs + L1 * 128 + c1 * 16 + q * 8));
+        bf16x8_t v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return v;
+    }
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void wgrad_s2_dma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                           float* __restrict__ dw, const sba_conv_geom g, const int M,
+                                                           const int chunks_per_split, const int use_atomic,
+                                                           const FastDiv dsub, const FastDiv dow, const int64_t zstride,
+                                                           const int wclog) {
+    constexpr int SL = 32 * 128;                 // dy slice: 32 pixels x 64 channels
+    constexpr int XBLK = 12;                     // x region: 12 DMA blocks of 8 rows (<= 72 rows used)
+    constexpr int STAGE = SL + XBLK * 1024;
+    constexpr int LPS = 4;                       // DMA instructions per wave per stage: 3 x blocks + 1 dy block
+    extern __shared__ __attribute__((aligned(1024))) unsigned char wg_lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, kw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = blockIdx.x * 64;
+    const int ci_tiles = g.Cin / 64;
+    const int kh = blockIdx.y / ci_tiles, ci0 = (blockIdx.y - kh * ci_tiles) * 64;
+    const int tap = kh * 4 + kw;
+    int ty = 0, tx0 = 0;
+#pragma unroll
+    for (int t = 0; t < SBA_MAX_TAPS; ++t) {
+        if (t == kh * 4) { ty = g.ty[t]; tx0 = g.tx[t]; }
+    }
+    const int Wc = 1 << wclog, R = 32 >> wclog, XW = 2 * Wc + 2, XR = R * XW;
+    const int sub = g.OH * g.OW;
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)wg_lds;
+    const uint32_t x_bytes = (uint32_t)((int64_t)g.N * g.IH * g.IW * g.Cin * 2);
+    const uint32_t dy_bytes = (uint32_t)((int64_t)g.N * g.OH * g.OW * g.Cout * 2);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
+    constexpr uint32_t OOB = 0xFFFFFFFFu;
+
+    // lane l of a DMA instruction fills 16-byte position (l & 7) of row (l >> 3) of its 8-row block
+    const int rsub = lane >> 3;
+    const int cgx = (lane & 7) ^ (((rsub >> 1) & 3) << 1);              // x rows: chunk c at position c ^ 2 ((L >> 1) & 3)
+    const int cgd = (lane & 7) ^ (((lane >> 4) & 1) << 2);              // dy rows: as in wgrad_small_dma_kernel
+    const uint32_t x_coff = (uint32_t)(ci0 + cgx * 8) * 2u, d_coff = (uint32_t)(co0 + cgd * 8) * 2u;
+    const uint32_t x_pix = (uint32_t)g.Cin * 2u, d_pix = (uint32_t)g.Cout * 2u;
+    // this lane's three x rows: (input row offset, input column offset) relative to the chunk's first pixel; -1 = unused row
+    int xdr[3], xdc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int L = 8 * (kw + 4 * i) + rsub;
+        if (L < XR) { const int r = L / XW; xdr[i] = r * g.sy + ty; xdc[i] = L - r * XW + tx0; }
+        else { xdr[i] = -100000; xdc[i] = 0; }
+    }
+
+    const int chunk_lo = blockIdx.z * chunks_per_split;
+    const int chunk_hi = min(chunk_lo + chunks_per_split, M >> 5);
+    int g_ck = chunk_lo;
+
+    auto issue = [&](const uint32_t dst) {
+        const bool live = g_ck < chunk_hi;
+        const int m0 = g_ck * 32;
+        const int n = (int)fdiv(m0, dsub), rem = m0 - n * sub;
+        const int oy0 = (int)fdiv(rem, dow), ox0 = rem - oy0 * g.OW;
+        const int iy0 = oy0 * g.sy, ix0 = ox0 * g.sx;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int iy = iy0 + xdr[i], ix = ix0 + xdc[i];
+            const bool ok = live & (iy >= 0) & (iy < g.IH) & (ix >= 0) & (ix < g.IW);
+            const uint32_t off = ok ? (uint32_t)((n * g.IH + iy) * g.IW + ix) * x_pix + x_coff : OOB;
+            lds_dma16(xr, off, 0u, dst + (uint32_t)(SL + (kw + 4 * i) * 1024));
+        }
+        {
+            const int m = m0 + 8 * kw + rsub;
+            const uint32_t off = live ? (uint32_t)m * d_pix + d_coff : OOB;
+            lds_dma16(dr, off, 0u, dst + (uint32_t)(kw * 1024));
+        }
+        ++g_ck;
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int islot = 0;
+#pragma unroll
+    for (int p = 0; p < D - 1; ++p) { issue(lds_base + (uint32_t)(islot * STAGE)); ++islot; }
+    if (islot == D) islot = 0;
+    int cslot = 0;
+    for (int ck = chunk_lo; ck < chunk_hi; ++ck) {
+        wait_vmcnt<(D - 2) * LPS>();         // this wave's part of stage ck has landed ...
+        wg_barrier();                        // ... and everybody else's; nobody reads slot (ck - 1) % D any more
+        issue(lds_base + (uint32_t)(islot * STAGE));
+        if (++islot == D) islot = 0;
+        const unsigned char* st = wg_lds + cslot * STAGE;
+        const unsigned char* xs = st + SL;
+#pragma unroll
+        for (int k16 = 0; k16 < 2; ++k16) {
+            bf16x8_t a[2], b[2];
+            b[0] = WgFragS2::load(xs, k16, 0, lane, kw, wclog, XW);
+            b[1] = WgFragS2::load(xs, k16, 32, lane, kw, wclog, XW);
+            a[0] = WgFragDma::load(st, k16, 0, lane);
+            a[1] = WgFragDma::load(st, k16, 32, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (++cslot == D) cslot = 0;
+    }
+    wait_vmcnt<0>();            // the dead stages issued past the end still write (zeros) into the ring
+    wg_barrier();
+
+    const int col_l = lane & 31, rsel = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + rsel;
+                const int ci = ci0 + j * 32 + col_l;
+                float* p = dw + (int64_t)blockIdx.z * zstride + ((int64_t)co * g.ntaps + tap) * g.Cin + ci;
+                if (use_atomic == 1) atomicAdd(p, acc[i][j][r]);
+                else if (use_atomic == 2) *p = acc[i][j][r];       // first write of a cleared gradient
+                else *p += acc[i][j][r];
+            }
+}
+
+// ---------------------------------------------------------------------------
 // weight gradient, large-map 3x3 stride-1 convs (optionally over a nearest-x2 upsampled input)
 // with OW % 64 == 0: the generator's 64..256 px layers, where ~all wgrad FLOPs are.
 // A workgroup owns one 64(co) x 64(ci) tile for ALL nine taps: per 64-pixel segment of an output
@@ -3277,6 +3433,47 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
         return true;
     };
     auto det_end = [&](int nsplit) { if (part) sba_det_fold(part, 1, nsplit, dwn, dw, 0, fw == 2 ? 1 : 0, st); };
+    // 4x4 / stride-2 down blocks: the four kw taps of a kernel row share one staged input row segment (wgrad_s2_dma_kernel).
+    // SBA_WGRAD_S2=0: off (A/B aid).
+    {
+        static int s2 = -1, s2_wgs = -1;
+        if (s2 < 0) { const char* e = getenv("SBA_WGRAD_S2"); s2 = (e && e[0] == '0') ? 0 : 1; }
+        if (s2_wgs < 0) { const char* e = getenv("SBA_WGRAD_S2_WGS"); s2_wgs = e ? atoi(e) : 512; }
+        bool ok = s2 && dtype == SBA_BF16 && g->ntaps == 16 && g->sy == 2 && g->sx == 2 && !g->ups && g->osy == 1 &&
+                  g->osx == 1 && g->ooy == 0 && g->oox == 0 && g->OHs == g->OH && g->OWs == g->OW && g->Cin % 64 == 0 &&
+                  g->Cout % 64 == 0 && g->OW >= 8 && (g->OW & (g->OW - 1)) == 0 && (g->OH * g->OW) % 32 == 0;
+        for (int t = 0; t < 16 && ok; ++t) ok = g->ty[t] == g->ty[(t >> 2) * 4] && g->tx[t] == g->tx[(t >> 2) * 4] + (t & 3);
+        const int64_t xb = (int64_t)g->N * g->IH * g->IW * g->Cin * 2, db = (int64_t)g->N * g->OH * g->OW * g->Cout * 2;
+        if (ok && xb < (1ll << 32) && db < (1ll << 32)) {
+            const int wc = g->OW < 32 ? g->OW : 32;
+            int wclog = 0;
+            while ((1 << wclog) < wc) ++wclog;
+            const int wgs = co_tiles * 4 * (g->Cin / 64);
+            const int tc32 = M / 32;
+            // pixel splits: each one adds a full f32-atomic copy of dW (~1.3 TB/s chip-wide): fill the chip about twice,
+            // keep >= 12 chunks behind a copy
+            // (tools/bench_wgrad.py, B = 40: 128->256 @64 71 us at 512 workgroups, 78 at 384, 94 at 256; the 64->128 layers,
+            // 8 workgroups per split: @128 89 / 86 / 94, @64 42 / 37 / 36)
+            int sp = cdiv(wgs <= 8 ? (s2_wgs * 3) / 4 : s2_wgs, wgs);
+            if (sp > tc32 / 12) sp = tc32 / 12 > 0 ? tc32 / 12 : 1;
+            const int cps32 = cdiv(tc32, sp);
+            sp = cdiv(tc32, cps32);
+            dim3 gd(co_tiles, 4 * (g->Cin / 64), sp);
+            if (gd.y <= 65535 && gd.z <= 65535) {
+                if (!det_begin(sp)) return SBA_E_ARG;
+                float* dwa = part ? part : dw;
+                const int md = part ? 2 : (sp > 1 ? 1 : fw);
+                const int64_t zs = part ? dwn : 0;
+                constexpr int LDS = 4 * (32 * 128 + 12 * 1024);
+                static bool once = false;
+                if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_s2_dma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
+                SBA_LAUNCH((wgrad_s2_dma_kernel<4>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
+                           (const bf16_t*)dy, dwa, *g, M, cps32, md, dsub, dow, zs, wclog);
+                det_end(sp);
+                return SBA_CHECK_LAUNCH();
+            }
+        }
+    }
     static int small_m = -1;
     if (small_m < 0) { const char* e = getenv("SBA_WGRAD_SMALL_M"); small_m = e ? atoi(e) : 12000; }
     if (M <= small_m && co_tiles * items >= 256) {

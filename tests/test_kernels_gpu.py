@@ -88,6 +88,10 @@ CONV_CASES = [
     ('3x3', 3, 224, 544, 4, 4),       # ... ragged: last ci / co tiles 32 channels wide, M = 48 (half-empty second stage)
     ('3x3', 16, 256, 512, 8, 8),      # ... M = 1024: two pixel splits, f32 atomics
     ('3x3', 2, 1024, 1024, 4, 4),     # ... 576 workgroups: register-staged kernel when accumulating, two co tiles per wave (CT = 2) on a first write
+    ('4x4s2', 2, 64, 128, 64, 64),    # wgrad_s2_dma_kernel (the four kw taps of a kernel row share one staged input row): OW = 32
+    ('4x4s2', 3, 128, 64, 32, 32),    # ... OW = 16 (two output rows per 32-pixel chunk), two ci tiles
+    ('4x4s2', 2, 64, 64, 256, 128),   # ... OW = 64 (two chunks per output row), non-square, pixel splits
+    ('4x4s2', 5, 192, 128, 16, 16),   # ... OW = 8 (four output rows per chunk), three ci tiles
 ]
 
 
