@@ -2321,25 +2321,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_small_dma_kernel(const bf16_t* _
 }
 
 // ---------------------------------------------------------------------------
-// The 4x4 / stride-2 down blocks (encode_image_by_16times and the extra down blocks, model.py:540-575): the same
-// decomposition with the workgroup's four waves = the four kw taps of ONE kernel row kh and one 64-channel input tile.
-// The kernel above gathers a 32-pixel x slice per wave (tap): 128 pixel rows per stage.  The four kw taps of a kernel row
-// read the SAME input row(s) at column offsets 0..3 of a stride-2 walk, so here the stage holds that input row segment
-// once -- R output rows x Wc output columns = 32 pixels (Wc = min(OW, 32)) need R x (2 Wc + 2) <= 72 input pixels -- and
-// wave kw reads pixel p of it at LDS row r (2 Wc + 2) + 2 j + kw.  12 KB + 4 KB (dy) per stage instead of 20 KB, four DMA
-// instructions per wave instead of five, 1.6x fewer bytes L2 -> LDS per MFMA (the roofline of this family).
-// Channel chunk c of LDS row L sits at 16-byte position c ^ 2 ((L >> 1) & 3): the four stride-2 rows a 16-lane group reads
-// with ds_read_b64_tr_b16 fall into four different 32-byte bank groups.
+// Kernel-row decomposition: the workgroup's waves = the KW taps of ONE kernel row kh and one 64-channel input tile.
+// wgrad_small_dma_kernel gathers a 32-pixel x slice per wave (tap): 32 KW pixel rows per stage.  The kw taps of a kernel
+// row read the SAME input row(s) at column offsets 0..KW-1 of a stride-SX walk, so here the stage holds that input row
+// segment once -- R output rows x Wc output columns = 32 pixels (Wc = min(OW, 32)) need R x (SX (Wc - 1) + KW) input
+// pixels -- and wave kw reads pixel (r, j) of it at LDS row r XW + SX j + kw.
+//   <4, 2>: the 4x4 / stride-2 down blocks (encode_image_by_16times and the extra down blocks, model.py:540-575): <= 72
+//           input pixels instead of 128: 4 KB (dy) + 9 KB per stage instead of 20 KB, four DMA instructions per wave
+//           instead of five, 1.6x fewer bytes L2 -> LDS per MFMA (the roofline of this family);
+//   <3, 1>: 3x3 stride-1 convs (the generator's 64 x 64 maps): <= 40 input pixels instead of 96, three waves.
+// DMA blocks (8 rows x 128 B) of a stage: 0..3 = the dy slice, 4.. = the x rows, dealt round-robin to the waves.
+// Stride 2: channel chunk c of LDS row L sits at 16-byte position c ^ 2 ((L >> 1) & 3) -- the four stride-2 rows a 16-lane
+// group reads with ds_read_b64_tr_b16 fall into four different 32-byte bank groups; stride 1: c ^ 4 bit1(L) as above.
 // ---------------------------------------------------------------------------
-struct WgFragS2 {
+template <int SX>
+struct WgFragRow {
     // fragment of channels [c32, c32+32) over output pixels [16 k16, 16 k16 + 16) of the chunk, tap column kw
+    static __device__ __forceinline__ int swz(int L) { return SX == 2 ? (((L >> 1) & 3) << 1) : (((L >> 1) & 1) << 2); }
     static __device__ __forceinline__ bf16x8_t load(const unsigned char* xs, int k16, int c32, int lane, int kw, int wclog,
-                                                    int xw) {
+                                                    int xw, int ups, int tx0) {
         const int g16 = lane >> 4, i16 = lane & 15;
         const int cbase = c32 + 16 * (g16 & 1), p = 16 * k16 + 8 * (g16 >> 1) + (i16 >> 2), q = i16 & 3;
         const int r = p >> wclog, j = p & ((1 << wclog) - 1);
-        const int L0 = r * xw + 2 * j + kw, L1 = L0 + 8;        // pixel p + 4: same output row (Wc >= 8)
-        const int c0 = (cbase >> 3) ^ (((L0 >> 1) & 3) << 1), c1 = (cbase >> 3) ^ (((L1 >> 1) & 3) << 1);
+        // (behind a nearest x2 upsample the segment holds LOW-resolution pixels: column (ox0 + j + kw + tx0) >> 1, ox0 even)
+        const int col = ups ? ((j + kw + tx0) >> 1) - (tx0 >> 1) : SX * j + kw;
+        // pixel p + 4: four columns on in the same output row (Wc >= 8), or the next output row (Wc = 4)
+        const int L0 = r * xw + col, L1 = L0 + (wclog == 2 ? xw : (ups ? 2 : 4 * SX));
+        const int c0 = (cbase >> 3) ^ swz(L0), c1 = (cbase >> 3) ^ swz(L1);
         typedef __attribute__((address_space(3))) s16x4_t* lptr;
         s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xs + L0 * 128 + c0 * 16 + q * 8));
         s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xs + L1 * 128 + c1 * 16 + q * 8));
@@ -2350,29 +2358,33 @@ struct WgFragS2 {
     }
 };
 
-template <int D>
-__global__ __launch_bounds__(256, 2) void wgrad_s2_dma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                           float* __restrict__ dw, const sba_conv_geom g, const int M,
-                                                           const int chunks_per_split, const int use_atomic,
-                                                           const FastDiv dsub, const FastDiv dow, const int64_t zstride,
-                                                           const int wclog) {
-    constexpr int SL = 32 * 128;                 // dy slice: 32 pixels x 64 channels
-    constexpr int XBLK = 12;                     // x region: 12 DMA blocks of 8 rows (<= 72 rows used)
-    constexpr int STAGE = SL + XBLK * 1024;
-    constexpr int LPS = 4;                       // DMA instructions per wave per stage: 3 x blocks + 1 dy block
+template <int KW, int XB> struct WgRowCfg {                     // XB: 8-row DMA blocks of the x segment
+    static constexpr int LPS = (4 + XB + KW - 1) / KW;           // DMA instructions per wave per stage
+    static constexpr int STAGE = LPS * KW * 1024;
+};
+
+template <int KW, int SX, int XB, int D>
+__global__ __launch_bounds__(64 * KW, 2) void wgrad_row_dma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                float* __restrict__ dw, const sba_conv_geom g, const int M,
+                                                                const int chunks_per_split, const int use_atomic,
+                                                                const FastDiv dsub, const FastDiv dow, const int64_t zstride,
+                                                                const int wclog) {
+    typedef WgRowCfg<KW, XB> Cfg;
+    constexpr int LPS = Cfg::LPS, STAGE = Cfg::STAGE;
     extern __shared__ __attribute__((aligned(1024))) unsigned char wg_lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, kw = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int co0 = blockIdx.x * 64;
     const int ci_tiles = g.Cin / 64;
     const int kh = blockIdx.y / ci_tiles, ci0 = (blockIdx.y - kh * ci_tiles) * 64;
-    const int tap = kh * 4 + kw;
+    const int tap = kh * KW + kw;
     int ty = 0, tx0 = 0;
 #pragma unroll
     for (int t = 0; t < SBA_MAX_TAPS; ++t) {
-        if (t == kh * 4) { ty = g.ty[t]; tx0 = g.tx[t]; }
+        if (t == kh * KW) { ty = g.ty[t]; tx0 = g.tx[t]; }
     }
-    const int Wc = 1 << wclog, R = 32 >> wclog, XW = 2 * Wc + 2, XR = R * XW;
+    const int ups = g.ups;            // (KW = 3, SX = 1 only) x is the LOW-resolution input of a nearest x2 upsample
+    const int Wc = 1 << wclog, R = 32 >> wclog, XW = ups ? (Wc >> 1) + 2 : SX * (Wc - 1) + KW, XR = R * XW;
     const int sub = g.OH * g.OW;
 
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)wg_lds;
@@ -2384,17 +2396,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_s2_dma_kernel(const bf16_t* __re
 
     // lane l of a DMA instruction fills 16-byte position (l & 7) of row (l >> 3) of its 8-row block
     const int rsub = lane >> 3;
-    const int cgx = (lane & 7) ^ (((rsub >> 1) & 3) << 1);              // x rows: chunk c at position c ^ 2 ((L >> 1) & 3)
+    const int cgx = (lane & 7) ^ WgFragRow<SX>::swz(rsub);              // x rows (8-row blocks: swz(L) = swz(L & 7))
     const int cgd = (lane & 7) ^ (((lane >> 4) & 1) << 2);              // dy rows: as in wgrad_small_dma_kernel
     const uint32_t x_coff = (uint32_t)(ci0 + cgx * 8) * 2u, d_coff = (uint32_t)(co0 + cgd * 8) * 2u;
     const uint32_t x_pix = (uint32_t)g.Cin * 2u, d_pix = (uint32_t)g.Cout * 2u;
-    // this lane's three x rows: (input row offset, input column offset) relative to the chunk's first pixel; -1 = unused row
-    int xdr[3], xdc[3];
+    // this wave's blocks b = kw + KW i.  b < 4: rows 8 b .. of the dy slice (role 0: rr = pixel of the chunk);
+    // 4 <= b < 4 + XB: rows of the x segment (role 1: rr / rc = input row / column relative to the chunk's first pixel);
+    // else a dummy that zero-fills its block (role 2)
+    // (a 4 x 4 map has 16 pixels: a chunk then spans rows_img = OH rows of each of 32 / 16 = 2 images)
+    const int rows_img = g.OH < R ? g.OH : R;
+    int role[LPS], rr[LPS], rc[LPS], rn[LPS];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int L = 8 * (kw + 4 * i) + rsub;
-        if (L < XR) { const int r = L / XW; xdr[i] = r * g.sy + ty; xdc[i] = L - r * XW + tx0; }
-        else { xdr[i] = -100000; xdc[i] = 0; }
+    for (int i = 0; i < LPS; ++i) {
+        const int b = kw + KW * i;
+        role[i] = 2; rr[i] = 0; rc[i] = 0; rn[i] = 0;
+        if (b < 4) { role[i] = 0; rr[i] = 8 * b + rsub; }
+        else {
+            const int L = 8 * (b - 4) + rsub;
+            if (L < XR) {
+                const int r = L / XW;
+                role[i] = 1;
+                rn[i] = r / rows_img;
+                rr[i] = (r - rn[i] * rows_img) * g.sy + ty;             // (ups: an offset in UPSAMPLED rows)
+                rc[i] = ups ? L - r * XW : L - r * XW + tx0;            // (ups: the segment's low-resolution column index)
+            }
+        }
     }
 
     const int chunk_lo = blockIdx.z * chunks_per_split;
@@ -2408,16 +2434,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_s2_dma_kernel(const bf16_t* __re
         const int oy0 = (int)fdiv(rem, dow), ox0 = rem - oy0 * g.OW;
         const int iy0 = oy0 * g.sy, ix0 = ox0 * g.sx;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int iy = iy0 + xdr[i], ix = ix0 + xdc[i];
-            const bool ok = live & (iy >= 0) & (iy < g.IH) & (ix >= 0) & (ix < g.IW);
-            const uint32_t off = ok ? (uint32_t)((n * g.IH + iy) * g.IW + ix) * x_pix + x_coff : OOB;
-            lds_dma16(xr, off, 0u, dst + (uint32_t)(SL + (kw + 4 * i) * 1024));
-        }
-        {
-            const int m = m0 + 8 * kw + rsub;
-            const uint32_t off = live ? (uint32_t)m * d_pix + d_coff : OOB;
-            lds_dma16(dr, off, 0u, dst + (uint32_t)(kw * 1024));
+        for (int i = 0; i < LPS; ++i) {
+            uint32_t off = OOB;
+            if (role[i] == 0) {
+                if (live) off = (uint32_t)(m0 + rr[i]) * d_pix + d_coff;
+                lds_dma16(dr, off, 0u, dst + (uint32_t)((kw + KW * i) * 1024));
+            } else {
+                int iy = iy0 + rr[i], ix = ix0 + rc[i];
+                if (ups) {              // upsampled row v -> low-resolution row v >> 1 (v = -1 and v = 2 IH are the padding)
+                    iy >>= 1;
+                    ix = ((ox0 + tx0) >> 1) + rc[i];
+                }
+                const bool ok = live & (role[i] == 1) & (iy >= 0) & (iy < g.IH) & (ix >= 0) & (ix < g.IW);
+                if (ok) off = (uint32_t)(((n + rn[i]) * g.IH + iy) * g.IW + ix) * x_pix + x_coff;
+                lds_dma16(xr, off, 0u, dst + (uint32_t)((kw + KW * i) * 1024));
+            }
         }
         ++g_ck;
     };
@@ -2441,12 +2472,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_s2_dma_kernel(const bf16_t* __re
         issue(lds_base + (uint32_t)(islot * STAGE));
         if (++islot == D) islot = 0;
         const unsigned char* st = wg_lds + cslot * STAGE;
-        const unsigned char* xs = st + SL;
+        const unsigned char* xs = st + 4 * 1024;
 #pragma unroll
         for (int k16 = 0; k16 < 2; ++k16) {
             bf16x8_t a[2], b[2];
-            b[0] = WgFragS2::load(xs, k16, 0, lane, kw, wclog, XW);
-            b[1] = WgFragS2::load(xs, k16, 32, lane, kw, wclog, XW);
+            b[0] = WgFragRow<SX>::load(xs, k16, 0, lane, kw, wclog, XW, ups, tx0);
+            b[1] = WgFragRow<SX>::load(xs, k16, 32, lane, kw, wclog, XW, ups, tx0);
             a[0] = WgFragDma::load(st, k16, 0, lane);
             a[1] = WgFragDma::load(st, k16, 32, lane);
 #pragma unroll
@@ -3433,42 +3464,71 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
         return true;
     };
     auto det_end = [&](int nsplit) { if (part) sba_det_fold(part, 1, nsplit, dwn, dw, 0, fw == 2 ? 1 : 0, st); };
-    // 4x4 / stride-2 down blocks: the four kw taps of a kernel row share one staged input row segment (wgrad_s2_dma_kernel).
-    // SBA_WGRAD_S2=0: off (A/B aid).
+    // Kernel-row decomposition (wgrad_row_dma_kernel): the kw taps of a kernel row share one staged input row segment.
+    // 4x4 / stride-2 down blocks and 3x3 / stride-1 convs on maps of 8 x 8 .. (below the all-taps halo-row kernel's range).
+    // SBA_WGRAD_S2=0 / SBA_WGRAD_S1=0: off (A/B aids); SBA_WGRAD_S1=1: only below the halo-row kernel's range; 2: also instead
+    // of it; 3 (default): also behind the nearest x2 upsample (G upsample1..4 73 / 92 / 102 / 80 -> 41 / 56 / 55 / 53 us,
+    // upBlock -> 128 px 123 -> 100, -> 256 px 192 -> 187) -- tools/bench_wgrad.py, B = 20: ResBlock 64 x 64 44.0 -> 28.4 us, 64->128 @64 61.6 -> 38.3; at 128 x 128
+    // against wgrad_rows_kernel: 64->64 95.8 -> 54.9 us, 64->128 122.8 -> 92.8 (profiles/r04_wgrad_s2_rows.txt).
     {
-        static int s2 = -1, s2_wgs = -1;
-        if (s2 < 0) { const char* e = getenv("SBA_WGRAD_S2"); s2 = (e && e[0] == '0') ? 0 : 1; }
-        if (s2_wgs < 0) { const char* e = getenv("SBA_WGRAD_S2_WGS"); s2_wgs = e ? atoi(e) : 512; }
-        bool ok = s2 && dtype == SBA_BF16 && g->ntaps == 16 && g->sy == 2 && g->sx == 2 && !g->ups && g->osy == 1 &&
-                  g->osx == 1 && g->ooy == 0 && g->oox == 0 && g->OHs == g->OH && g->OWs == g->OW && g->Cin % 64 == 0 &&
-                  g->Cout % 64 == 0 && g->OW >= 8 && (g->OW & (g->OW - 1)) == 0 && (g->OH * g->OW) % 32 == 0;
-        for (int t = 0; t < 16 && ok; ++t) ok = g->ty[t] == g->ty[(t >> 2) * 4] && g->tx[t] == g->tx[(t >> 2) * 4] + (t & 3);
+        static int s2 = -1, s1 = -1, row_wgs = -1, rows_m1 = -1;
+        if (s2 < 0) { const char* e = getenv("SBA_WGRAD_S2"); s2 = e ? atoi(e) : 1; }
+        if (s1 < 0) { const char* e = getenv("SBA_WGRAD_S1"); s1 = e ? atoi(e) : 3; }
+        if (row_wgs < 0) { const char* e = getenv("SBA_WGRAD_S2_WGS"); row_wgs = e ? atoi(e) : 512; }
+        if (rows_m1 < 0) { const char* e = getenv("SBA_WGRAD_ROWS_M"); rows_m1 = e ? atoi(e) : 131072; }
+        const int kwn = g->ntaps == 16 ? 4 : (g->ntaps == 9 ? 3 : 0), sxy = g->sx;
+        bool ok = dtype == SBA_BF16 && kwn && g->sy == sxy && (!g->ups || (kwn == 3 && s1 >= 3)) && g->osy == 1 && g->osx == 1 && g->ooy == 0 &&
+                  g->oox == 0 && g->OHs == g->OH && g->OWs == g->OW && g->Cin % 64 == 0 && g->Cout % 64 == 0 &&
+                  g->OW >= 4 && (g->OW & (g->OW - 1)) == 0 && !(g->OW == 4 && (g->ups || g->OH != 4)) && M % 32 == 0 &&
+                  ((g->OH * g->OW) % 32 == 0 || g->OW == 4);
+        ok = ok && ((kwn == 4 && sxy == 2 && s2) ||
+                    (kwn == 3 && sxy == 1 && s1 && (s1 >= 2 || M < rows_m1 || g->OW % 64 != 0)));
+        static int ow4 = -1;        // SBA_WGRAD_ROW_OW4=0: not on the 4 x 4 maps (two images per chunk; A/B aid).  B = 40: D256's 3x3
+                                    // 2048->1024 78.6 -> 55.8 us, D128's 1024->512 38.1 -> 27.3, 512->1024 4x4/s2 35.8 -> 27.9
+        if (ow4 < 0) { const char* e = getenv("SBA_WGRAD_ROW_OW4"); ow4 = e ? atoi(e) : 1; }
+        ok = ok && (g->OW > 4 || ow4);
+        for (int t = 0; t < g->ntaps && ok; ++t)
+            ok = g->ty[t] == g->ty[(t / kwn) * kwn] && g->tx[t] == g->tx[(t / kwn) * kwn] + (t % kwn);
         const int64_t xb = (int64_t)g->N * g->IH * g->IW * g->Cin * 2, db = (int64_t)g->N * g->OH * g->OW * g->Cout * 2;
         if (ok && xb < (1ll << 32) && db < (1ll << 32)) {
             const int wc = g->OW < 32 ? g->OW : 32;
             int wclog = 0;
             while ((1 << wclog) < wc) ++wclog;
-            const int wgs = co_tiles * 4 * (g->Cin / 64);
+            const int wgs = co_tiles * kwn * (g->Cin / 64);
             const int tc32 = M / 32;
             // pixel splits: each one adds a full f32-atomic copy of dW (~1.3 TB/s chip-wide): fill the chip about twice,
             // keep >= 12 chunks behind a copy
             // (tools/bench_wgrad.py, B = 40: 128->256 @64 71 us at 512 workgroups, 78 at 384, 94 at 256; the 64->128 layers,
             // 8 workgroups per split: @128 89 / 86 / 94, @64 42 / 37 / 36)
-            int sp = cdiv(wgs <= 8 ? (s2_wgs * 3) / 4 : s2_wgs, wgs);
+            int sp = cdiv(wgs <= 8 ? (row_wgs * 3) / 4 : row_wgs, wgs);
             if (sp > tc32 / 12) sp = tc32 / 12 > 0 ? tc32 / 12 : 1;
             const int cps32 = cdiv(tc32, sp);
             sp = cdiv(tc32, cps32);
-            dim3 gd(co_tiles, 4 * (g->Cin / 64), sp);
+            dim3 gd(co_tiles, kwn * (g->Cin / 64), sp);
             if (gd.y <= 65535 && gd.z <= 65535) {
                 if (!det_begin(sp)) return SBA_E_ARG;
                 float* dwa = part ? part : dw;
                 const int md = part ? 2 : (sp > 1 ? 1 : fw);
                 const int64_t zs = part ? dwn : 0;
-                constexpr int LDS = 4 * (32 * 128 + 12 * 1024);
-                static bool once = false;
-                if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_s2_dma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
-                SBA_LAUNCH((wgrad_s2_dma_kernel<4>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
-                           (const bf16_t*)dy, dwa, *g, M, cps32, md, dsub, dow, zs, wclog);
+                if (kwn == 4) {         // x segment: <= 72 rows (OW >= 8), 80 rows (two 4 x 4 maps)
+                    constexpr int LDS = 4 * WgRowCfg<4, 10>::STAGE;
+                    static bool once = false;
+                    if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_row_dma_kernel<4, 2, 10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
+                    SBA_LAUNCH((wgrad_row_dma_kernel<4, 2, 10, 4>), gd, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)x,
+                               (const bf16_t*)dy, dwa, *g, M, cps32, md, dsub, dow, zs, wclog);
+                } else if (g->OW == 4) {       // 8 rows x 6 = 48 rows
+                    constexpr int LDS = 4 * WgRowCfg<3, 6>::STAGE;
+                    static bool once = false;
+                    if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_row_dma_kernel<3, 1, 6, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
+                    SBA_LAUNCH((wgrad_row_dma_kernel<3, 1, 6, 4>), gd, dim3(192), LDS, (hipStream_t)stream, (const bf16_t*)x,
+                               (const bf16_t*)dy, dwa, *g, M, cps32, md, dsub, dow, zs, wclog);
+                } else {                       // <= 40 rows
+                    constexpr int LDS = 4 * WgRowCfg<3, 5>::STAGE;
+                    static bool once = false;
+                    if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_row_dma_kernel<3, 1, 5, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
+                    SBA_LAUNCH((wgrad_row_dma_kernel<3, 1, 5, 4>), gd, dim3(192), LDS, (hipStream_t)stream, (const bf16_t*)x,
+                               (const bf16_t*)dy, dwa, *g, M, cps32, md, dsub, dow, zs, wclog);
+                }
                 det_end(sp);
                 return SBA_CHECK_LAUNCH();
             }
