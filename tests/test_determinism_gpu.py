@@ -156,6 +156,22 @@ def test_step_is_bit_reproducible_in_every_launch_mode(dev, det, encoder, dt):
         for k in range(2):
             d = _diff(run(fn), e1, name + '_' + tag)
             assert not d, ('%s, replay %d vs eager' % (name, k), d[:8])
+    # sba_replay_prioritize: its calibration pass IS one execution of the recording (every launch alone, in order, on one
+    # stream), and the streams it assigns afterwards -- one pool, or two pools of different HIP priority -- enforce the
+    # recorded dependencies: the pass itself and the replays behind it are the same step, bit for bit
+    def prioritized(spec):
+        def f():
+            rs.prioritize(spec)
+            return rs.out
+        return f
+    for spec in ('c:4:1:0.05', '2:5:2:0.1', '1:6:3:0.3'):
+        d = _diff(run(prioritized(spec)), e1, 'prioritize_' + tag)
+        assert not d, ('calibration pass %s vs eager' % spec, d[:8])
+        d = _diff(run(replay_of(rs)), e1, 'prioritized_replay_' + tag)
+        assert not d, ('native replayer after prioritize(%s) vs eager' % spec, d[:8])
+        assert rs.info['nodes'] > 100 and rs.info['streams'] >= 2, rs.info
+    st.restore(snap)
+    rs.prioritize('c:4:1:0.0')          # back to one pool of four streams
     l1, l2 = run(eager_late), run(eager_late)
     assert not _diff(l1, l2, 'late_' + tag), ('eager (late DAMSM) vs itself', _diff(l1, l2)[:8])
     for k in range(2):
