@@ -2358,30 +2358,42 @@ struct WgFragRow {
     }
 };
 
-template <int KW, int XB> struct WgRowCfg {                     // XB: 8-row DMA blocks of the x segment
-    static constexpr int LPS = (4 + XB + KW - 1) / KW;           // DMA instructions per wave per stage
-    static constexpr int STAGE = LPS * KW * 1024;
+// KR = 1: one kernel row per workgroup (its KW waves); KR = KH: ALL kernel rows (KH x KW waves, the segment of every row
+// staged side by side): the dy slice is then shared by all taps -- for layers whose dW is small enough that the extra
+// pixel splits (fewer workgroups per split) cost nothing: the generator's 3x3 convs (dW <= 0.3 MB).
+template <int KW, int XB, int KR = 1> struct WgRowCfg {         // XB: 8-row DMA blocks of one x segment
+    static constexpr int NW = KW * KR;
+    static constexpr int LPS = (4 + KR * XB + NW - 1) / NW;      // DMA instructions per wave per stage
+    static constexpr int STAGE = LPS * NW * 1024;
 };
 
-template <int KW, int SX, int XB, int D>
-__global__ __launch_bounds__(64 * KW, 2) void wgrad_row_dma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+template <int KW, int SX, int XB, int D, int KR = 1>
+__global__ __launch_bounds__(64 * KW * KR, KR == 1 ? 2 : 1) void wgrad_row_dma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                                 float* __restrict__ dw, const sba_conv_geom g, const int M,
                                                                 const int chunks_per_split, const int use_atomic,
                                                                 const FastDiv dsub, const FastDiv dow, const int64_t zstride,
                                                                 const int wclog) {
-    typedef WgRowCfg<KW, XB> Cfg;
-    constexpr int LPS = Cfg::LPS, STAGE = Cfg::STAGE;
+    typedef WgRowCfg<KW, XB, KR> Cfg;
+    constexpr int LPS = Cfg::LPS, STAGE = Cfg::STAGE, NW = Cfg::NW;
     extern __shared__ __attribute__((aligned(1024))) unsigned char wg_lds[];
 
-    const int tid = threadIdx.x, lane = tid & 63, kw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khl = wv / KW, kw = wv - khl * KW;            // this wave's kernel row inside the workgroup, its tap column
     const int co0 = blockIdx.x * 64;
     const int ci_tiles = g.Cin / 64;
-    const int kh = blockIdx.y / ci_tiles, ci0 = (blockIdx.y - kh * ci_tiles) * 64;
+    const int kh0 = KR == 1 ? blockIdx.y / ci_tiles : 0;    // first kernel row of the workgroup
+    const int ci0 = (KR == 1 ? blockIdx.y - kh0 * ci_tiles : blockIdx.y) * 64;
+    const int kh = kh0 + khl;
     const int tap = kh * KW + kw;
-    int ty = 0, tx0 = 0;
+    // taps are row-structured (checked by the host): row k starts at (ty, tx0) = (g.ty[k KW], g.tx[k KW])
+    auto row_ty = [&](const int k) { int v = 0;
+#pragma unroll
+        for (int t = 0; t < SBA_MAX_TAPS; ++t) if (t == k * KW) v = g.ty[t];
+        return v; };
+    int tx0 = 0;
 #pragma unroll
     for (int t = 0; t < SBA_MAX_TAPS; ++t) {
-        if (t == kh * KW) { ty = g.ty[t]; tx0 = g.tx[t]; }
+        if (t == kh * KW) tx0 = g.tx[t];
     }
     const int ups = g.ups;            // (KW = 3, SX = 1 only) x is the LOW-resolution input of a nearest x2 upsample
     const int Wc = 1 << wclog, R = 32 >> wclog, XW = ups ? (Wc >> 1) + 2 : SX * (Wc - 1) + KW, XR = R * XW;
@@ -2408,16 +2420,17 @@ __global__ __launch_bounds__(64 * KW, 2) void wgrad_row_dma_kernel(const bf16_t*
     int role[LPS], rr[LPS], rc[LPS], rn[LPS];
 #pragma unroll
     for (int i = 0; i < LPS; ++i) {
-        const int b = kw + KW * i;
+        const int b = wv + NW * i;
         role[i] = 2; rr[i] = 0; rc[i] = 0; rn[i] = 0;
         if (b < 4) { role[i] = 0; rr[i] = 8 * b + rsub; }
         else {
-            const int L = 8 * (b - 4) + rsub;
-            if (L < XR) {
+            const int sg = (b - 4) / XB;                                 // which kernel row's segment
+            const int L = 8 * (b - 4 - sg * XB) + rsub;
+            if (sg < KR && L < XR) {
                 const int r = L / XW;
                 role[i] = 1;
                 rn[i] = r / rows_img;
-                rr[i] = (r - rn[i] * rows_img) * g.sy + ty;             // (ups: an offset in UPSAMPLED rows)
+                rr[i] = (r - rn[i] * rows_img) * g.sy + row_ty(kh0 + sg); // (ups: an offset in UPSAMPLED rows)
                 rc[i] = ups ? L - r * XW : L - r * XW + tx0;            // (ups: the segment's low-resolution column index)
             }
         }
@@ -2438,7 +2451,7 @@ __global__ __launch_bounds__(64 * KW, 2) void wgrad_row_dma_kernel(const bf16_t*
             uint32_t off = OOB;
             if (role[i] == 0) {
                 if (live) off = (uint32_t)(m0 + rr[i]) * d_pix + d_coff;
-                lds_dma16(dr, off, 0u, dst + (uint32_t)((kw + KW * i) * 1024));
+                lds_dma16(dr, off, 0u, dst + (uint32_t)((wv + NW * i) * 1024));
             } else {
                 int iy = iy0 + rr[i], ix = ix0 + rc[i];
                 if (ups) {              // upsampled row v -> low-resolution row v >> 1 (v = -1 and v = 2 IH are the padding)
@@ -2447,7 +2460,7 @@ __global__ __launch_bounds__(64 * KW, 2) void wgrad_row_dma_kernel(const bf16_t*
                 }
                 const bool ok = live & (role[i] == 1) & (iy >= 0) & (iy < g.IH) & (ix >= 0) & (ix < g.IW);
                 if (ok) off = (uint32_t)(((n + rn[i]) * g.IH + iy) * g.IW + ix) * x_pix + x_coff;
-                lds_dma16(xr, off, 0u, dst + (uint32_t)((kw + KW * i) * 1024));
+                lds_dma16(xr, off, 0u, dst + (uint32_t)((wv + NW * i) * 1024));
             }
         }
         ++g_ck;
@@ -2472,7 +2485,7 @@ __global__ __launch_bounds__(64 * KW, 2) void wgrad_row_dma_kernel(const bf16_t*
         issue(lds_base + (uint32_t)(islot * STAGE));
         if (++islot == D) islot = 0;
         const unsigned char* st = wg_lds + cslot * STAGE;
-        const unsigned char* xs = st + 4 * 1024;
+        const unsigned char* xs = st + (4 + khl * XB) * 1024;
 #pragma unroll
         for (int k16 = 0; k16 < 2; ++k16) {
             bf16x8_t a[2], b[2];
@@ -3483,6 +3496,13 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
                   ((g->OH * g->OW) % 32 == 0 || g->OW == 4);
         ok = ok && ((kwn == 4 && sxy == 2 && s2) ||
                     (kwn == 3 && sxy == 1 && s1 && (s1 >= 2 || M < rows_m1 || g->OW % 64 != 0)));
+        // SBA_WGRAD_ALLROWS=1 (experiment, off): all three kernel rows of a small-dW 3x3 conv per workgroup (KR = 3: nine waves,
+        // dy shared by nine taps, 1.2 instead of 3 KB staged per tap).  Measured SLOWER almost everywhere (one workgroup of
+        // nine waves per CU behind one barrier per stage): ResBlock 128 x 128 58.9 -> 71.4 us, 64 x 64 29.5 -> 42.3, upsample4
+        // 54.5 -> 68.9 at 256 workgroups (worse at 320 / 512); only the 256 px upBlock gains (183.6 -> 156.8).
+        static int allrows = -1, all9_wgs = -1;
+        if (allrows < 0) { const char* e = getenv("SBA_WGRAD_ALLROWS"); allrows = e ? atoi(e) : 0; }
+        if (all9_wgs < 0) { const char* e = getenv("SBA_WGRAD_ALL9_WGS"); all9_wgs = e ? atoi(e) : 256; }
         static int ow4 = -1;        // SBA_WGRAD_ROW_OW4=0: not on the 4 x 4 maps (two images per chunk; A/B aid).  B = 40: D256's 3x3
                                     // 2048->1024 78.6 -> 55.8 us, D128's 1024->512 38.1 -> 27.3, 512->1024 4x4/s2 35.8 -> 27.9
         if (ow4 < 0) { const char* e = getenv("SBA_WGRAD_ROW_OW4"); ow4 = e ? atoi(e) : 1; }
@@ -3494,17 +3514,20 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
             const int wc = g->OW < 32 ? g->OW : 32;
             int wclog = 0;
             while ((1 << wclog) < wc) ++wclog;
-            const int wgs = co_tiles * kwn * (g->Cin / 64);
+            // all three kernel rows of a 3x3 conv in one workgroup (nine waves, the dy slice shared by the nine taps) where dW
+            // is small: with 1..4 workgroups per pixel split the extra splits' f32 atomics cost nothing
+            const bool all9 = allrows && kwn == 3 && g->OW >= 8 && co_tiles * (g->Cin / 64) <= 4;
+            const int wgs = all9 ? co_tiles * (g->Cin / 64) : co_tiles * kwn * (g->Cin / 64);
             const int tc32 = M / 32;
             // pixel splits: each one adds a full f32-atomic copy of dW (~1.3 TB/s chip-wide): fill the chip about twice,
             // keep >= 12 chunks behind a copy
             // (tools/bench_wgrad.py, B = 40: 128->256 @64 71 us at 512 workgroups, 78 at 384, 94 at 256; the 64->128 layers,
-            // 8 workgroups per split: @128 89 / 86 / 94, @64 42 / 37 / 36)
-            int sp = cdiv(wgs <= 8 ? (row_wgs * 3) / 4 : row_wgs, wgs);
+            // 8 workgroups per split: @128 89 / 86 / 94, @64 42 / 37 / 36; all9: one workgroup per CU)
+            int sp = cdiv(all9 ? all9_wgs : (wgs <= 8 ? (row_wgs * 3) / 4 : row_wgs), wgs);
             if (sp > tc32 / 12) sp = tc32 / 12 > 0 ? tc32 / 12 : 1;
             const int cps32 = cdiv(tc32, sp);
             sp = cdiv(tc32, cps32);
-            dim3 gd(co_tiles, kwn * (g->Cin / 64), sp);
+            dim3 gd(co_tiles, (all9 ? 1 : kwn) * (g->Cin / 64), sp);
             if (gd.y <= 65535 && gd.z <= 65535) {
                 if (!det_begin(sp)) return SBA_E_ARG;
                 float* dwa = part ? part : dw;
@@ -3521,6 +3544,12 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
                     static bool once = false;
                     if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_row_dma_kernel<3, 1, 6, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
                     SBA_LAUNCH((wgrad_row_dma_kernel<3, 1, 6, 4>), gd, dim3(192), LDS, (hipStream_t)stream, (const bf16_t*)x,
+                               (const bf16_t*)dy, dwa, *g, M, cps32, md, dsub, dow, zs, wclog);
+                } else if (all9) {
+                    constexpr int LDS = 3 * WgRowCfg<3, 5, 3>::STAGE;
+                    static bool once = false;
+                    if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_row_dma_kernel<3, 1, 5, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; }
+                    SBA_LAUNCH((wgrad_row_dma_kernel<3, 1, 5, 3, 3>), gd, dim3(576), LDS, (hipStream_t)stream, (const bf16_t*)x,
                                (const bf16_t*)dy, dwa, *g, M, cps32, md, dsub, dow, zs, wclog);
                 } else {                       // <= 40 rows
                     constexpr int LDS = 4 * WgRowCfg<3, 5>::STAGE;
