@@ -3533,6 +3533,7 @@ extern "C" int sba_conv_wgrad(int dtype, const void* x, const void* dy, float* d
                 float* dwa = part ? part : dw;
                 const int md = part ? 2 : (sp > 1 ? 1 : fw);
                 const int64_t zs = part ? dwn : 0;
+                // (ring depth: 3 and 4 measure the same, 6 is 30-60 % slower -- occupancy: profiles/r04_wgrad_s2_rows.txt)
                 if (kwn == 4) {         // x segment: <= 72 rows (OW >= 8), 80 rows (two 4 x 4 maps)
                     constexpr int LDS = 4 * WgRowCfg<4, 10>::STAGE;
                     static bool once = false;
