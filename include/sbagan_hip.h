@@ -144,15 +144,6 @@ int sba_conv_igemm(int dtype, const void* x, const void* w, void* y, const void*
 int sba_conv_igemm_bias(int dtype, const void* x, const void* w, void* y, const void* addend,
                         float* stats, const float* bias, const void* relu_mask, const sba_conv_geom* g,
                         void* workspace, int64_t workspace_bytes, void* stream);
-/* sba_conv_igemm (bf16) whose output is d(GLU output) of a BatchNorm + GLU (ResBlock, model.py:60-65: the data gradient of
- * the block's second conv): the epilogue also adds the two per-channel sums of that BatchNorm's backward over its tile into
- * bn_red -- [SBA_BN_STAT_SLOTS][2][2 Cout] f32, ZERO-FILLED by the caller: sum(dz) and sum(dz xhat) of the 2 Cout
- * pre-activation channels, the layout sba_bn_act_bwd_apply reads -- from bn_y ([pixels][2 Cout] bf16: the BatchNorm's input,
- * same pixels as y) and bn_aux ([scale | shift | mean | rstd][2 Cout], sba_bn_act_fwd's aux): sba_bn_act_bwd_reduce's pass over
- * dz and bn_y is then not needed.  One K pass per tile only (SBA_E_ARG where the geometry's plan splits K), dense y, not in the
- * deterministic mode (the sums meet in f32 atomics). */
-int sba_conv_igemm_bnred(const void* x, const void* w, void* y, const void* addend, const void* bn_y, const float* bn_aux,
-                         float* bn_red, const sba_conv_geom* g, void* workspace, int64_t workspace_bytes, void* stream);
 /* Which kernel sba_conv_igemm launches for a geometry (nothing is launched; measurement / reporting aid):
  * plan[0] = family (0 halo-tile 3x3 conv3x3_halo_kernel, 1 igemm_dma2_kernel, 2 igemm_dma_kernel, 3 igemm_kernel, 4 the general
  * register-weight halo kernel conv3x3_halo3g_kernel -- only with g->w_layout = 1),

@@ -36,12 +36,7 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
 // optional epilogue operands: per-channel bias, and a ReLU mask source (same layout as y): outputs are
 // zeroed where mask <= 0 -- the backward of the ReLU that produced the tensor whose gradient this is
 // yh: store the (bf16-typed) output as IEEE binary16 bits (SBA_BF16_YH: the pre-BatchNorm tensor)
-// bn_y / bn_aux / bn_red (sba_conv_igemm_bnred): the output tensor is d(GLU output) of a BatchNorm + GLU whose input
-// bn_y ([pixels][2 Cout], same pixels as the output) and coefficients bn_aux ([scale | shift | mean | rstd][2 Cout]) are
-// given: the epilogue also adds the BatchNorm backward's two per-channel sums over its tile into bn_red
-// ([SBA_BN_STAT_SLOTS][sum dz | sum dz xhat][2 Cout]: what bn_bwd_reduce_kernel<GLU> computes in a pass of its own)
-struct EpiX { const float* bias; const void* mask; int yh; const void* bn_y = nullptr; const float* bn_aux = nullptr;
-              float* bn_red = nullptr; };
+struct EpiX { const float* bias; const void* mask; int yh; };
 
 // keep the bf16 halves of v whose counterpart in m is > 0
 __device__ __forceinline__ uint32_t relu_mask_bf16x2(uint32_t v, uint32_t m) {
@@ -170,22 +165,6 @@ __device__ __forceinline__ void tile_epilogue(f32x16_t (&acc)[TM][TN], const boo
     if (kStageOut || stats) __syncthreads();
     if (kStageOut) {
         constexpr int CPRO = BN / 8;                 // 16-byte chunks per output row
-        static_assert(NTT % CPRO == 0, "a thread keeps its channel chunk over its rows");
-        // BatchNorm-backward sums of the GLU behind this output (EpiX::bn_red): a thread's chunk of 8 channels is the same
-        // for all its rows, so it keeps the four sums per channel in registers
-        const bool bnr = ex.bn_red != nullptr;
-        const int bn_co = n_base + (int)(threadIdx.x % CPRO) * 8, bn_Co = g.Cout, bn_C = 2 * g.Cout;
-        float q_sc[8], q_sh[8], q_mn[8], q_rs[8], q_scg[8], q_shg[8], q_mng[8], q_rsg[8];
-        float q_s0[8], q_s1[8], q_g0[8], q_g1[8];
-        if (bnr) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int ca = min(bn_co + k, bn_Co - 1), cg = bn_Co + ca;
-                q_sc[k] = ex.bn_aux[ca]; q_sh[k] = ex.bn_aux[bn_C + ca]; q_mn[k] = ex.bn_aux[2 * bn_C + ca]; q_rs[k] = ex.bn_aux[3 * bn_C + ca];
-                q_scg[k] = ex.bn_aux[cg]; q_shg[k] = ex.bn_aux[bn_C + cg]; q_mng[k] = ex.bn_aux[2 * bn_C + cg]; q_rsg[k] = ex.bn_aux[3 * bn_C + cg];
-                q_s0[k] = q_s1[k] = q_g0[k] = q_g1[k] = 0.f;
-            }
-        }
         for (int idx = threadIdx.x; idx < BM * CPRO; idx += NTT) {
             const int row = idx / CPRO, cc = idx - row * CPRO;
             const int pix = rowoff[row];
@@ -209,24 +188,6 @@ __device__ __forceinline__ void tile_epilogue(f32x16_t (&acc)[TM][TN], const boo
                     v.w = relu_mask_bf16x2(v.w, m.w);
                 }
                 *reinterpret_cast<uint4*>(y + o) = v;
-                if (bnr) {          // (the arithmetic of bn_bwd_reduce_kernel<GLU>, on the bf16 values just stored)
-                    const bf16_t* yp = reinterpret_cast<const bf16_t*>(ex.bn_y) + (int64_t)pix * bn_C;
-                    const uint4 ya = *reinterpret_cast<const uint4*>(yp + co), yg = *reinterpret_cast<const uint4*>(yp + bn_Co + co);
-                    const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, aw[4] = {ya.x, ya.y, ya.z, ya.w}, gw[4] = {yg.x, yg.y, yg.z, yg.w};
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const float dd = bf2f((bf16_t)((k & 1) ? (vw[k >> 1] >> 16) : (vw[k >> 1] & 0xffffu)));
-                        const float a = bf2f((bf16_t)((k & 1) ? (aw[k >> 1] >> 16) : (aw[k >> 1] & 0xffffu)));
-                        const float gt = bf2f((bf16_t)((k & 1) ? (gw[k >> 1] >> 16) : (gw[k >> 1] & 0xffffu)));
-                        const float n = a * q_sc[k] + q_sh[k], gp = gt * q_scg[k] + q_shg[k];
-                        const float sg = sigmoid_bwd_(gp);
-                        const float dza = dd * sg, dzg = dd * n * sg * (1.f - sg);
-                        q_s0[k] += dza;
-                        q_s1[k] += dza * (a - q_mn[k]) * q_rs[k];
-                        q_g0[k] += dzg;
-                        q_g1[k] += dzg * (gt - q_mng[k]) * q_rsg[k];
-                    }
-                }
             } else {                                  // ragged Cout tail: scalar
                 // (fully unrolled with static indices: a dynamically indexed private array would be
                 // promoted to LDS and make every wave read the AQL dispatch packet for its flat id)
@@ -241,36 +202,6 @@ __device__ __forceinline__ void tile_epilogue(f32x16_t (&acc)[TM][TN], const boo
                     }
                 }
             }
-        }
-        if (bnr) {
-        // the staging tile has been read: its first 4 BN floats collect the workgroup's sums, then one replica gets them
-        __syncthreads();
-        float* s_red = reinterpret_cast<float*>(lds_all);
-        for (int c = threadIdx.x; c < 4 * BN; c += NTT) s_red[c] = 0.f;
-        __syncthreads();
-        const int c0 = (int)(threadIdx.x % CPRO) * 8;
-        if (threadIdx.x < BM * CPRO) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                atomicAdd(&s_red[c0 + k], q_s0[k]);
-                atomicAdd(&s_red[BN + c0 + k], q_s1[k]);
-                atomicAdd(&s_red[2 * BN + c0 + k], q_g0[k]);
-                atomicAdd(&s_red[3 * BN + c0 + k], q_g1[k]);
-            }
-        }
-        __syncthreads();
-        const int sid = slot_id >= 0 ? slot_id : (int)(blockIdx.x + blockIdx.z);
-        const int C2 = 2 * g.Cout;
-        float* slot = ex.bn_red + (int64_t)(sid & (SBA_BN_STAT_SLOTS - 1)) * 2 * C2;
-        for (int c = threadIdx.x; c < BN; c += NTT) {
-            const int co = n_base + c;
-            if (co < g.Cout) {
-                atomicAdd(&slot[co], s_red[c]);
-                atomicAdd(&slot[C2 + co], s_red[BN + c]);
-                atomicAdd(&slot[g.Cout + co], s_red[2 * BN + c]);
-                atomicAdd(&slot[C2 + g.Cout + co], s_red[3 * BN + c]);
-            }
-        }
         }
     }
     if (stats) {
@@ -3424,24 +3355,6 @@ extern "C" int sba_conv_igemm_bias(int dtype, const void* x, const void* w, void
     SBA_DISPATCH(dtype, return launch_igemm<T>(x, w, y, addend, stats, *g, workspace, workspace_bytes,
                                                (hipStream_t)stream, EpiX{bias, relu_mask, 0}));
     return SBA_E_ARG;
-}
-
-extern "C" int sba_conv_igemm_bnred(const void* x, const void* w, void* y, const void* addend, const void* bn_y,
-                                    const float* bn_aux, float* bn_red, const sba_conv_geom* g, void* workspace,
-                                    int64_t workspace_bytes, void* stream) {
-    if (!x || !w || !y || !bn_y || !bn_aux || !bn_red || !geom_ok(g, SBA_BF16)) return SBA_E_ARG;
-    if (((uintptr_t)workspace & 15) != 0 || sba_det_on()) return SBA_E_ARG;
-    // one K pass per output tile (no split-K: the sums are taken where the tile is complete), whole 8-channel chunks
-    if (g->Cout % 8 != 0 || g->y_cstride || g->y_coff || g->osy != 1 || g->osx != 1 || g->OHs != g->OH || g->OWs != g->OW)
-        return SBA_E_ARG;
-    int plan[3] = {0, 0, 0};
-    int rc = launch_igemm<bf16_t>(x, w, y, addend, nullptr, *g, workspace, workspace_bytes, (hipStream_t)stream,
-                                  EpiX{nullptr, nullptr, 0}, plan);
-    if (rc != SBA_OK) return rc;
-    if (plan[2] > 1) return SBA_E_ARG;
-    EpiX ex{nullptr, nullptr, 0};
-    ex.bn_y = bn_y; ex.bn_aux = bn_aux; ex.bn_red = bn_red;
-    return launch_igemm<bf16_t>(x, w, y, addend, nullptr, *g, workspace, workspace_bytes, (hipStream_t)stream, ex);
 }
 
 extern "C" int sba_conv_igemm_plan(int dtype, const sba_conv_geom* g, int64_t workspace_bytes, int* plan) {

@@ -54,7 +54,6 @@ G = POINTER(ConvGeom)
 SIGNATURES = {
     'sba_conv_igemm': [I, P, P, P, P, P, G, P, L, P],
     'sba_conv_igemm_bias': [I, P, P, P, P, P, P, P, G, P, L, P],
-    'sba_conv_igemm_bnred': [P, P, P, P, P, P, P, POINTER(ConvGeom), P, L, P],
     'sba_conv_igemm_plan': [I, G, L, POINTER(c_int)],
     'sba_conv_igemm_group': [I, I, POINTER(ConvGroupItem), I, P],
     'sba_conv_igemm_group_splitk': [I, I, POINTER(ConvGroupItem), I, I, P, L, P],

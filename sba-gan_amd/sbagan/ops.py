@@ -524,51 +524,13 @@ def _halo_family(g):
         call('sba_conv_igemm_plan', _lib.SBA_BF16, ctypes.byref(g), WORKSPACE_BYTES, plan)
         g.w_layout = old
         h = g._halo = plan[0] == 0
-        g._ksplit_planned = int(plan[2])
     return h
 
 
-# ResBlock backward: the BatchNorm-backward sums of the block's first BatchNorm (+ GLU) taken in the epilogue of the second
-# conv's data gradient, which produces that BatchNorm's incoming gradient (sba_conv_igemm_bnred) -- one pass over dz and y less
-# on the generator's backward chain (four launches, ~160 us alone).  Built for the review item that asked for it three times
-# and MEASURED SLOWER: 10.15-10.21 against 10.06-10.10 ms per step over three 60-step runs each on one box
-# (profiles/r04_ab_fuse_bn_red.txt) -- the epilogue of a data gradient on the serial chain gains two 16-byte loads of y, a
-# sigmoid and a dozen FMAs per element, three barriers and 256 more atomics per tile, which costs more there than the
-# HBM-bound pass it replaces costs beside the weight gradients.  Off; SBA_FUSE_BN_RED=1 turns it on.
-FUSE_BN_RED = os.environ.get('SBA_FUSE_BN_RED', '0') == '1'
-
-
-def conv_dgrad_bnred(dy, pw, in_hw, y_bn, st):
-    """3x3 data gradient dx = conv_transpose(dy) where dx is d(GLU output) of BatchNorm(y_bn) (state st): returns
-    (dx, red) with red = that BatchNorm's backward sums, or (dx, None) where the fused epilogue does not apply (f32, the
-    deterministic mode, a float16 y, small maps that take the one-launch BatchNorm backward, K-split plans)."""
-    N, O, OH, OW = dy.shape
-    I = pw.param.shape[1]
-    ok = (FUSE_BN_RED and dy.dtype == torch.bfloat16 and y_bn.dtype == torch.bfloat16 and st.groups == 1 and
-          st.rows > BN_FUSED_BWD_ROWS and y_bn.shape[1] == 2 * I and I % 8 == 0 and not deterministic())
-    if ok:
-        g = _geom(('3x3', N, OH, OW, O, I, None))
-        tune_geom(g, _lib.SBA_BF16)
-        halo = _halo_family(g)
-        ok = halo or g._ksplit_planned <= 1
-        if ok and not halo and g.ksplit > 1:
-            ok = False
-    if not ok:
-        return conv_dgrad(dy, pw, '3x3', in_hw), None
-    wd = pw.dgrad(dy.dtype, '3x3')
-    wf = pw.dgrad_frag(dy.dtype, '3x3')
-    dx = empty_act(N, I, in_hw[0], in_hw[1], dy)
-    red = zeros_f32((1, BN_STAT_SLOTS, 2 * 2 * I), dy.device)
-    ws = workspace(dy.device)
-    w, g.w_layout = wd.data_ptr(), 0
-    if wf is not None and halo:
-        w, g.w_layout = wf.data_ptr(), 1
-    try:
-        call('sba_conv_igemm_bnred', _p(dy), w, _p(dx), None, _p(y_bn), _p(st.aux), _p(red), ctypes.byref(g), ws.data_ptr(),
-             WORKSPACE_BYTES, _stream())
-    finally:
-        g.w_layout = 0
-    return dx, red
+# (Tried at the end of round 4 and removed: the BatchNorm-backward sums of a ResBlock's first BatchNorm taken in the epilogue of
+# the second conv's data gradient -- sba_conv_igemm_bnred, commit 6ee6d14.  Correct, but 0.08 ms SLOWER per step when used, and
+# the extra state in the epilogue every implicit-GEMM kernel shares cost 0.13 ms even when unused: DESIGN.md §8,
+# profiles/r04_ab_fuse_bn_red.txt.)
 
 
 # ----------------------------------------------------------------------------
@@ -832,7 +794,7 @@ BN_FUSED_BWD_ROWS = int(os.environ.get('SBA_BN_FUSED_ROWS', '2560'))       # row
 
 
 def bn_act_backward(y, dout, st, bn, act, need_param_grad=True, out=None, red=None):
-    """red: the two backward sums when the producer of dout has taken them already (conv_dgrad_bnred)"""
+    """red: the two backward sums when the caller has them already"""
     N, C, H, W = y.shape
     Co = C // 2 if act == ACT_GLU else C
     dy = out if out is not None else torch.empty(y.shape, dtype=_act_dtype(y), device=y.device, memory_format=CL)
@@ -953,8 +915,8 @@ class ResBlockFn(torch.autograd.Function):
         dy2 = bn_act_backward(y2, dout, ctx.st2, blk.l2.bn, ACT_NONE, need_p)
         if need_p:
             conv_wgrad_overlapped(a1, dy2, blk.l2.conv.weight, '3x3')
-        da1, red1 = conv_dgrad_bnred(dy2, blk.l2.pw, a1.shape[2:], y1, ctx.st1)
-        dy1 = bn_act_backward(y1, da1, ctx.st1, blk.l1.bn, ACT_GLU, need_p, red=red1)
+        da1 = conv_dgrad(dy2, blk.l2.pw, '3x3', a1.shape[2:])
+        dy1 = bn_act_backward(y1, da1, ctx.st1, blk.l1.bn, ACT_GLU, need_p)
         if need_p:
             conv_wgrad_overlapped(x, dy1, blk.l1.conv.weight, '3x3')
         dx = None

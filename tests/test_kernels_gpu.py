@@ -545,63 +545,6 @@ def test_conv_bn_act_blocks(dev, dt, which):
     _check_module(mod, Q, dt, 'm.', gscale=3)
 
 
-@pytest.mark.parametrize('case', [(2, 64, 64, 64), (3, 64, 40, 40), (1, 128, 128, 128)])
-def test_resblock_batchnorm_sums_in_the_dgrad_epilogue(dev, case):
-    """sba_conv_igemm_bnred: the data gradient of a ResBlock's second conv also takes the backward sums of the first
-    BatchNorm (+ GLU) in its epilogue (model.py:60-65) -- against the separate sba_bn_act_bwd_reduce pass over the same
-    dz and y (sums of ~10^4 products in another order: 2e-3 of the largest sum), dx bit for bit, and the whole ResBlock
-    (forward + backward, large map) against the oracle."""
-    from sbagan import _lib, nets, ops
-    dt = torch.bfloat16
-    ops.set_compute_dtype(dt)
-    N, C, H, W = case
-    mod = nets.ResBlock(C)
-    P = fill.fill_state_dict({k: tuple(v.shape) for k, v in mod.state_dict().items()})
-    _load(mod, P, dev)
-    x = fill.unit((N, C, H, W), 5)
-    xa = act(x, dt, dev)
-    blk = mod
-    l1 = blk.l1 if hasattr(blk, 'l1') else None
-    assert l1 is not None
-    y1, s1 = ops.conv_forward(xa, blk.l1.pw, '3x3', want_stats=True, pre_bn=True)
-    a1, st1 = ops.bn_act_forward(y1, s1, blk.l1.bn, ops.ACT_GLU)
-    dy2 = act(fill.unit((N, C, H, W), 6), dt, dev)
-    da_ref = ops.conv_dgrad(dy2, blk.l2.pw, '3x3', (H, W))
-    red_ref = torch.zeros((1, ops.BN_STAT_SLOTS, 2 * 2 * C), dtype=torch.float32, device=dev)
-    _lib.call('sba_bn_act_bwd_reduce', _lib.SBA_BF16, y1.data_ptr(), da_ref.data_ptr(), st1.aux.data_ptr(), red_ref.data_ptr(),
-              st1.rows, 1, 2 * C, ops.ACT_GLU, C, 0, ops._stream())
-    was = ops.FUSE_BN_RED
-    ops.FUSE_BN_RED = True          # (off by default: measured slower on the step, profiles/r04_ab_fuse_bn_red.txt)
-    try:
-        _resblock_bn_sums_body(dev, dt, N, C, H, W, mod, P, x, blk, y1, st1, dy2, da_ref, red_ref)
-    finally:
-        ops.FUSE_BN_RED = was
-
-
-def _resblock_bn_sums_body(dev, dt, N, C, H, W, mod, P, x, blk, y1, st1, dy2, da_ref, red_ref):
-    from sbagan import ops
-    da, red = ops.conv_dgrad_bnred(dy2, blk.l2.pw, (H, W), y1, st1)
-    torch.cuda.synchronize()
-    assert red is not None, 'the fused epilogue must apply to this geometry'
-    assert torch.equal(da, da_ref), 'dx'
-    got, want = red.sum(1).flatten().cpu(), red_ref.sum(1).flatten().cpu()
-    assert float((got - want).abs().max()) <= 2e-3 * float(want.abs().max()), float((got - want).abs().max())
-    # the block end to end (the fused path is what ResBlockFn.backward takes here)
-    _load(mod, P, dev)          # (the manual forward above moved the running statistics)
-    xr = rounded(x, dt).requires_grad_(True)
-    Q = _oracle_P(P, 'm.')
-    yref = O.res_block(xr, Q, 'm')
-    dy = fill.unit(tuple(yref.shape), 7)
-    yref.backward(rounded(dy, dt))
-    xg = act(x, dt, dev).requires_grad_(True)
-    y = mod(xg)
-    y.backward(act(dy, dt, dev))
-    torch.cuda.synchronize()
-    close(y, yref, dt, 'out', scale=3)
-    close(xg.grad, xr.grad, dt, 'dx', scale=3)
-    _check_module(mod, Q, dt, 'm.', gscale=3)
-
-
 @pytest.mark.parametrize('which', ['up', 'leak', 'down', 'res'])
 def test_conv_bn_act_blocks_binary16_conv_output(dev, which):
     """SBA_Y_F16=1 / SBA_BF16_YH: the raw conv output between the conv epilogue and the BatchNorm kernels stored as IEEE
