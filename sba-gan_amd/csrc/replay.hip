@@ -357,7 +357,12 @@ extern "C" int sba_replay_prioritize(void* handle, void* stream, int mode, int m
     (void)hipGetLastError();
     // 1. every node alone, in issue order on the caller's stream, an event between neighbours: durations without contention
     std::vector<hipEvent_t> ev(n + 1, nullptr);
-    for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return SBA_E_LAUNCH;
+    for (auto& e : ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            for (auto& d : ev) if (d) (void)hipEventDestroy(d);
+            (void)hipGetLastError();
+            return SBA_E_LAUNCH;
+        }
     int rc = SBA_OK;
     for (int u = 0; u < n && rc == SBA_OK; ++u) {
         if (hipEventRecord(ev[u], caller) != hipSuccess) rc = SBA_E_LAUNCH;
