@@ -2338,6 +2338,10 @@ template <int SX>
 struct WgFragRow {
     // fragment of channels [c32, c32+32) over output pixels [16 k16, 16 k16 + 16) of the chunk, tap column kw
     static __device__ __forceinline__ int swz(int L) { return SX == 2 ? (((L >> 1) & 3) << 1) : (((L >> 1) & 1) << 2); }
+    // Stride 2: a wave's rows all have the parity of kw, and a 128-byte row covers half the banks -- every read would use 32 of
+    // the 64 banks (PMC: SQ_LDS_BANK_CONFLICT = a third of the LDS cycles).  Segment row L therefore lives in LDS row
+    // L ^ bit1(L) (an involution; swz() does not see bit 0): rows L and L + 2 fall into different halves.
+    static __device__ __forceinline__ int slot(int L) { return SX == 2 ? (L ^ ((L >> 1) & 1)) : L; }
     static __device__ __forceinline__ bf16x8_t load(const unsigned char* xs, int k16, int c32, int lane, int kw, int wclog,
                                                     int xw, int ups, int tx0) {
         const int g16 = lane >> 4, i16 = lane & 15;
@@ -2349,8 +2353,8 @@ struct WgFragRow {
         const int L0 = r * xw + col, L1 = L0 + (wclog == 2 ? xw : (ups ? 2 : 4 * SX));
         const int c0 = (cbase >> 3) ^ swz(L0), c1 = (cbase >> 3) ^ swz(L1);
         typedef __attribute__((address_space(3))) s16x4_t* lptr;
-        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xs + L0 * 128 + c0 * 16 + q * 8));
-        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xs + L1 * 128 + c1 * 16 + q * 8));
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xs + slot(L0) * 128 + c0 * 16 + q * 8));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(xs + slot(L1) * 128 + c1 * 16 + q * 8));
         bf16x8_t v;
         v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
         v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
@@ -2425,7 +2429,7 @@ __global__ __launch_bounds__(64 * KW * KR, KR == 1 ? 2 : 1) void wgrad_row_dma_k
         if (b < 4) { role[i] = 0; rr[i] = 8 * b + rsub; }
         else {
             const int sg = (b - 4) / XB;                                 // which kernel row's segment
-            const int L = 8 * (b - 4 - sg * XB) + rsub;
+            const int L = WgFragRow<SX>::slot(8 * (b - 4 - sg * XB) + rsub);  // the segment row this LDS row holds
             if (sg < KR && L < XR) {
                 const int r = L / XW;
                 role[i] = 1;

@@ -43,7 +43,10 @@ def main():
     dev = torch.device('cuda:0')
     ops.set_compute_dtype(torch.bfloat16)
     print('SBA_WGRAD_DMA=%s SBA_WGRAD_GEN_DMA=%s' % (os.environ.get('SBA_WGRAD_DMA', '(default)'), os.environ.get('SBA_WGRAD_GEN_DMA', '(default)')))
+    only = os.environ.get('BENCH_WGRAD_ONLY')           # substring of the shape's name: that shape alone (PMC runs)
     for kind, N, Cin, Cout, H, W, name in SHAPES:
+        if only and only not in name:
+            continue
         k = 4 if kind == '4x4s2' else 3
         w = torch.nn.Parameter(torch.randn(Cout, Cin, k, k, device=dev).contiguous(memory_format=torch.channels_last))
         x = torch.randn(N, Cin, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
