@@ -203,6 +203,84 @@ __global__ __launch_bounds__(256) void enc_stem_bwd_kernel(const float* __restri
     }
 }
 
+// The same gradient on the matrix cores (bf16 features, C = 32).  The 2 x 2 block of image pixels (2 by + a, 2 bx + b) is read
+// by the 2 x 2 neighbourhood of output positions (by - dy, bx - dx), dy, dx in {0, 1}, through the taps kh = a + 2 dy,
+// kw = b + 2 dx (no term where a tap index exceeds 2):
+//   dimg[ci][2 by + a][2 bx + b] = sum_{dy, dx} sum_co dpre[by - dy][bx - dx][co] w[co][kh][kw][ci]
+// -- a 2 x 2 convolution of dpre = dout (out > 0) with 12 "channels" (ci, a, b) and K = 4 x 32: per tile of 16 consecutive bx
+// of one row by, four steps of v_mfma_f32_16x16x32_bf16 (x 2: the f32 weights as hi + lo bf16 parts, so that the products are
+// the VALU kernel's to within f32 rounding).  The weights (A operand: 16 rows, 12 used) live in registers for the whole
+// launch; a lane's B fragment -- 8 channels of one position -- is ONE 16-byte load of dout and one of out straight from
+// global memory (64 lanes = 16 positions x 64 B: 1 KB contiguous), no LDS; the accumulator of lane (position, ci) is exactly
+// the 2 x 2 pixel block of channel ci.  (enc_stem_bwd_kernel: 4 x 32 x 3 FMAs per pixel on the vector pipe, 80 us at B = 20.)
+__global__ __launch_bounds__(256) void enc_stem_bwd_mfma_kernel(const float* __restrict__ w, const bf16_t* __restrict__ out,
+                                                                const bf16_t* __restrict__ dout, float* __restrict__ dimg,
+                                                                const int N, const int S, const int O, const int ntiles) {
+    constexpr int C = 32;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    bf16x8_t a_hi[4], a_lo[4];
+    {
+        const int ci = m >> 2, a = (m >> 1) & 1, b = m & 1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kh = a + 2 * (t >> 1), kw = b + 2 * (t & 1);
+            const bool ok = m < 12 && kh < 3 && kw < 3;
+            bf16x8_t hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int co = 8 * g + j;
+                const float v = ok ? w[co * 27 + (kh * 3 + kw) * 3 + ci] : 0.f;
+                const bf16_t h = f2bf(v);
+                hi[j] = (short)h;
+                lo[j] = (short)f2bf(v - bf2f(h));
+            }
+            a_hi[t] = hi;
+            a_lo[t] = lo;
+        }
+    }
+    const int BH = (S + 1) / 2, tiles_x = (BH + 15) / 16;          // 2 x 2 pixel blocks per image side, 16-block tiles per row
+    for (int tile = blockIdx.x * 4 + wid; tile < ntiles; tile += gridDim.x * 4) {
+        const int txi = tile % tiles_x, by = (tile / tiles_x) % BH, n = tile / (tiles_x * BH);
+        const int bx = txi * 16 + m;
+        f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int oy = by - (t >> 1), ox = bx - (t & 1);
+            uint4 dv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
+            if (oy >= 0 && oy < O && ox >= 0 && ox < O) {
+                const int64_t q = (((int64_t)n * O + oy) * O + ox) * C + 8 * g;
+                dv = *reinterpret_cast<const uint4*>(dout + q);
+                ov = *reinterpret_cast<const uint4*>(out + q);
+            }
+            // dpre = dout where out > 0 (bf16 bits: positive and not zero)
+            const uint32_t d[4] = {dv.x, dv.y, dv.z, dv.w}, o[4] = {ov.x, ov.y, ov.z, ov.w};
+            bf16x8_t bfr;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t lo_ok = ((o[k] & 0x7fffu) != 0u && (o[k] & 0x8000u) == 0u) ? 0x0000ffffu : 0u;
+                const uint32_t hi_ok = ((o[k] & 0x7fff0000u) != 0u && (o[k] & 0x80000000u) == 0u) ? 0xffff0000u : 0u;
+                const uint32_t v = d[k] & (lo_ok | hi_ok);
+                bfr[2 * k] = (short)(v & 0xffffu);
+                bfr[2 * k + 1] = (short)(v >> 16);
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[t], bfr, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[t], bfr, acc, 0, 0, 0);
+        }
+        // D layout: column = lane & 15 (block bx), rows 4 g .. 4 g + 3 = (ci = g; a, b)
+        if (g < 3 && bx < BH) {
+            float* o0 = dimg + (((int64_t)n * 3 + g) * S + 2 * by) * S + 2 * bx;
+            const bool x1 = 2 * bx + 1 < S, y1 = 2 * by + 1 < S;
+            o0[0] = acc[0];
+            if (x1) o0[1] = acc[1];
+            if (y1) {
+                o0[S] = acc[2];
+                if (x1) o0[S + 1] = acc[3];
+            }
+        }
+    }
+}
+
 // ---- max pool 3x3 stride 2 (no padding), NHWC with channel strides ----
 template <typename T>
 __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int xcs,
@@ -507,6 +585,14 @@ extern "C" int sba_enc_stem_bwd(int dtype, const float* w, const void* out, cons
                                 int S, int C, void* stream) {
     if (!w || !out || !dout || !dimg || N <= 0 || S < 3 || C <= 0 || C % 8 || C > 256) return SBA_E_ARG;
     const int O = (S - 3) / 2 + 1;
+    static int mf = -1;         // SBA_ENC_STEM_BWD_MFMA=0: the VALU kernel also for bf16 (A/B aid)
+    if (mf < 0) { const char* e = getenv("SBA_ENC_STEM_BWD_MFMA"); mf = (e && e[0] == '0') ? 0 : 1; }
+    if (mf && dtype == SBA_BF16 && C == 32 && (((uintptr_t)out | (uintptr_t)dout) & 15) == 0) {
+        const int BH = (S + 1) / 2, ntiles = N * BH * ((BH + 15) / 16);
+        SBA_LAUNCH(enc_stem_bwd_mfma_kernel, dim3((ntiles + 3) / 4 < 8192 ? (ntiles + 3) / 4 : 8192), dim3(256), 0,
+                   (hipStream_t)stream, w, (const bf16_t*)out, (const bf16_t*)dout, dimg, N, S, O, ntiles);
+        return SBA_CHECK_LAUNCH();
+    }
     SBA_DISPATCH(dtype, SBA_LAUNCH((enc_stem_bwd_kernel<T>), dim3(grid_for((int64_t)N * S * S, 4096)), dim3(256),
                                            sizeof(float) * 27 * C, (hipStream_t)stream, w, (const T*)out,
                                            (const T*)dout, dimg, N, S, O, C));

@@ -470,6 +470,36 @@ def test_stem_conv_on_the_resized_image(dev, dt):
     close(y1.permute(0, 3, 1, 2), ref, dt, 'fused stem, raw')
 
 
+@pytest.mark.parametrize('S', [75, 40, 299])
+def test_stem_backward_matrix_cores(dev, S):
+    """sba_enc_stem_bwd for bf16 features (enc_stem_bwd_mfma_kernel: the 3x3 / stride-2 stem's data gradient as a 2 x 2
+    conv of dpre with 12 "channels" on the matrix cores) against autograd through F.conv2d + ReLU (model.py:212), odd and
+    even image sizes, ragged 16-block tiles."""
+    from sbagan import _lib, ops
+    N, C = 2, 32
+    dt = torch.bfloat16
+    x = fill.unit((N, 3, S, S), 51)
+    w = fill.unit((C, 3, 3, 3), 52) / 5
+    b = fill.unit((C,), 53) / 10
+    xr = x.clone().requires_grad_(True)
+    y = torch.relu(F.conv2d(xr, w, b, stride=2))
+    O = y.shape[2]
+    dy = rounded(fill.unit((N, C, O, O), 54), dt)
+    # the kernel sees the bf16 features: the mask is out > 0 of the ROUNDED output
+    yb = rounded(y.detach(), dt)
+    pre = F.conv2d(xr, w, b, stride=2)
+    (gref,) = torch.autograd.grad(pre, xr, dy * (yb > 0))
+    st = ops._stream()
+    wa = w.to(dev).contiguous(memory_format=torch.channels_last)
+    outa = yb.permute(0, 2, 3, 1).contiguous().to(dev).to(dt)
+    dya = dy.permute(0, 2, 3, 1).contiguous().to(dev).to(dt)
+    dimg = torch.full((N, 3, S, S), float('nan'), dtype=torch.float32, device=dev)
+    _lib.call('sba_enc_stem_bwd', _lib.SBA_BF16, wa.data_ptr(), outa.data_ptr(), dya.data_ptr(), dimg.data_ptr(), N, S, C, st)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dimg).all(), 'every image pixel is written'
+    assert rel_l2(dimg.cpu(), gref) < 1e-5, rel_l2(dimg.cpu(), gref)
+
+
 # ------------------------------------------------------------------ fused blocks vs the oracle
 def _load(mod, P, dev):
     mod.load_state_dict(P)
