@@ -64,6 +64,51 @@ __global__ void resize_bwd_kernel(const float* __restrict__ dout, float* __restr
     }
 }
 
+// The same with the candidates of every input index tabulated once per workgroup (the image is square: one table serves rows and
+// columns): entry k of index r = (output index, weight) of the k-th output row / column with a non-zero weight, in ascending
+// order -- the loop above spends its time re-deriving them (floorf / ceilf ranges, ~16 weight evaluations per pixel: 55 us at
+// B = 20).  Same weights, same summation order.  Upscaling only (D >= S: at most RESIZE_MAXC candidates per index).
+constexpr int RESIZE_MAXC = 4;
+__global__ __launch_bounds__(256) void resize_bwd_tab_kernel(const float* __restrict__ dout, float* __restrict__ din, int NC,
+                                                             int S, int D) {
+    extern __shared__ unsigned char rs_lds[];
+    int* t_o = reinterpret_cast<int*>(rs_lds);                          // [S][RESIZE_MAXC]
+    float* t_w = reinterpret_cast<float*>(rs_lds + (size_t)S * RESIZE_MAXC * 4);
+    const float sc = (float)(S - 1) / (float)(D - 1);
+    const float inv = 1.f / sc;
+    for (int r = threadIdx.x; r < S; r += blockDim.x) {
+        const int lo = max(0, (int)floorf((r - 1) * inv) - 1), hi = min(D - 1, (int)ceilf((r + 1) * inv) + 1);
+        int k = 0;
+        for (int o = lo; o <= hi && k < RESIZE_MAXC; ++o) {
+            const float wgt = resize_adj_w(o, r, sc, S);
+            if (wgt != 0.f) { t_o[r * RESIZE_MAXC + k] = o; t_w[r * RESIZE_MAXC + k] = wgt; ++k; }
+        }
+        for (; k < RESIZE_MAXC; ++k) { t_o[r * RESIZE_MAXC + k] = 0; t_w[r * RESIZE_MAXC + k] = 0.f; }
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)NC * S * S;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % S), r = (int)((i / S) % S);
+        const int64_t nc = i / ((int64_t)S * S);
+        const float* g = dout + nc * D * D;
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < RESIZE_MAXC; ++ky) {
+            const float wy = t_w[r * RESIZE_MAXC + ky];
+            if (wy == 0.f) continue;
+            const float* grow = g + t_o[r * RESIZE_MAXC + ky] * D;
+            float row = 0.f;
+#pragma unroll
+            for (int kx = 0; kx < RESIZE_MAXC; ++kx) {
+                const float wx = t_w[c * RESIZE_MAXC + kx];
+                if (wx != 0.f) row += grow[t_o[c * RESIZE_MAXC + kx]] * wx;
+            }
+            acc += wy * row;
+        }
+        din[i] = acc;
+    }
+}
+
 // ---- stem: conv3x3 s2 p0 (3 -> C) + bias + ReLU, NCHW f32 in, NHWC T out ----
 // thread = (output pixel, V channels); weights [C][3][3][3] (channels_last OIHW) transposed to [27][C] in LDS
 template <typename T>
@@ -566,6 +611,13 @@ extern "C" int sba_resize_bilinear(const float* in, float* out, int NC, int S, i
     if (!backward) {
         SBA_LAUNCH(resize_fwd_kernel, dim3(grid_for((int64_t)NC * D * D)), dim3(256), 0, st, in, out, NC, S, D);
     } else {     // in = d(out) [NC][D][D], out = d(in) [NC][S][S]
+        static int tab = -1;        // SBA_RESIZE_BWD_TAB=0: the kernel that re-derives the candidates per pixel (A/B aid)
+        if (tab < 0) { const char* e = getenv("SBA_RESIZE_BWD_TAB"); tab = (e && e[0] == '0') ? 0 : 1; }
+        // (an input index collects the outputs o with o (S-1)/(D-1) within (r-1, r+1): at most 2 (D-1)/(S-1) + 1 <= RESIZE_MAXC)
+        if (tab && D >= S && S >= 2 && S <= 2048 && 2 * (int64_t)(D - 1) <= 3 * (int64_t)(S - 1))
+            SBA_LAUNCH(resize_bwd_tab_kernel, dim3(grid_for((int64_t)NC * S * S, 2048)), dim3(256), (size_t)S * RESIZE_MAXC * 8,
+                       st, in, out, NC, S, D);
+        else
         SBA_LAUNCH(resize_bwd_kernel, dim3(grid_for((int64_t)NC * S * S)), dim3(256), 0, st, in, out, NC, S, D);
     }
     return SBA_CHECK_LAUNCH();

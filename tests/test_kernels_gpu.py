@@ -470,6 +470,29 @@ def test_stem_conv_on_the_resized_image(dev, dt):
     close(y1.permute(0, 3, 1, 2), ref, dt, 'fused stem, raw')
 
 
+@pytest.mark.parametrize('sd', [(64, 75), (256, 299), (17, 17), (5, 64)])
+def test_resize_backward_is_the_adjoint(dev, sd):
+    """sba_resize_bilinear(backward): the gather form of the adjoint of F.interpolate(bilinear, align_corners=True)
+    (model.py:210), with the candidates of every input index tabulated per workgroup, against autograd"""
+    from sbagan import _lib, ops
+    S, D = sd
+    NC = 6
+    x = fill.unit((2, 3, S, S), 61).requires_grad_(True)
+    y = F.interpolate(x, size=(D, D), mode='bilinear', align_corners=True)
+    dy = fill.unit((2, 3, D, D), 62)
+    (gref,) = torch.autograd.grad(y, x, dy)
+    dya = dy.to(dev).contiguous()
+    dx = torch.full((2, 3, S, S), float('nan'), dtype=torch.float32, device=dev)
+    _lib.call('sba_resize_bilinear', dya.data_ptr(), dx.data_ptr(), NC, S, D, 1, ops._stream())
+    torch.cuda.synchronize()
+    # (source coordinates up to S - 1 in f32: one ulp of 255 is 1.5e-5 of a pixel, and so is the interpolation weight)
+    assert rel_l2(dx.cpu(), gref) < 3e-5, rel_l2(dx.cpu(), gref)
+    ya = torch.empty((2, 3, D, D), dtype=torch.float32, device=dev)
+    _lib.call('sba_resize_bilinear', x.detach().to(dev).contiguous().data_ptr(), ya.data_ptr(), NC, S, D, 0, ops._stream())
+    torch.cuda.synchronize()
+    assert rel_l2(ya.cpu(), y.detach()) < 3e-5
+
+
 @pytest.mark.parametrize('S', [75, 40, 299])
 def test_stem_backward_matrix_cores(dev, S):
     """sba_enc_stem_bwd for bf16 features (enc_stem_bwd_mfma_kernel: the 3x3 / stride-2 stem's data gradient as a 2 x 2
