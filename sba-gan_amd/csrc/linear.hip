@@ -396,7 +396,8 @@ __global__ void ctx_proj_bwd_kernel(const float* __restrict__ words, const float
 extern "C" int sba_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N,
                               void* stream) {
     if (!x || !w || !y || B <= 0 || K <= 0 || N <= 0) return SBA_E_ARG;
-    if (B <= 32 && K % 4 == 0 && N <= 2048) {            // small layers: matrix cores, one wave per 32 columns
+    if (B <= 32 && K % 4 == 0) {            // batch <= 32: matrix cores, one wave per 32 columns (INIT_STAGE_G.fc, 16384 columns:
+                                            // 49 us as wave-per-column GEMVs)
         SBA_LAUNCH(linear_fwd_mfma_kernel, dim3(cdiv(N, 32)), dim3(64), 0, (hipStream_t)stream, x, w, bias, y, B, K, N);
         return SBA_CHECK_LAUNCH();
     }
@@ -412,9 +413,15 @@ extern "C" int sba_linear_bwd(const float* x, const float* w, const float* dy, f
                               int B, int K, int N, void* stream) {
     if (!x || !w || !dy || B <= 0 || K <= 0 || N <= 0) return SBA_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (B <= 32 && N % 4 == 0 && N <= 2048) {
+    if (B <= 32 && N % 4 == 0 && (N <= 2048 || (N % 32 == 0 && cdiv(N, 32) <= 65535))) {
         if (dw) SBA_LAUNCH(linear_bwd_w_mfma_kernel, dim3(cdiv(K, 32), cdiv(N, 32)), dim3(64), 0, st, x, dy, dw, dbias, B, K, N);
-        if (dx) SBA_LAUNCH(linear_bwd_x_mfma_kernel, dim3(cdiv(K, 32)), dim3(64), 0, st, w, dy, dx, B, K, N, N);
+        if (dx && (N <= 2048 || sba_det_on())) {     // (deterministic mode: one slice, no atomics)
+            SBA_LAUNCH(linear_bwd_x_mfma_kernel, dim3(cdiv(K, 32)), dim3(64), 0, st, w, dy, dx, B, K, N, N);
+        } else if (dx) {       // wide layer (INIT_STAGE_G.fc): the reduction over N sliced over workgroups, f32 atomics into dx
+            sba_zero_f32(dx, nullptr, (int64_t)B * K, st);
+            const int nper = 128;
+            SBA_LAUNCH(linear_bwd_x_mfma_kernel, dim3(cdiv(K, 32), cdiv(N, nper)), dim3(64), 0, st, w, dy, dx, B, K, N, nper);
+        }
         return SBA_CHECK_LAUNCH();
     }
     const size_t sh = sizeof(float) * B * K;

@@ -470,6 +470,34 @@ def test_stem_conv_on_the_resized_image(dev, dt):
     close(y1.permute(0, 3, 1, 2), ref, dt, 'fused stem, raw')
 
 
+@pytest.mark.parametrize('shape', [(20, 200, 16384), (20, 100, 512), (3, 256, 2080), (40, 200, 4096)])
+def test_dense_layers_all_widths(dev, shape):
+    """sba_linear_fwd / sba_linear_bwd (nn.Linear; model.py:278,306-313,330,354): the batch <= 32 layers on the f32 matrix
+    cores at every width -- INIT_STAGE_G.fc has 16384 columns -- and the wave-per-row kernels beyond batch 32, against
+    torch; dW and db accumulate."""
+    from sbagan import _lib, ops
+    B, K, N = shape
+    x, w, b = fill.unit((B, K), 71), fill.unit((N, K), 72) / np.sqrt(K), fill.unit((N,), 73)
+    dy = fill.unit((B, N), 74)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yref = F.linear(xr, wr, br)
+    gx, gw, gb = torch.autograd.grad(yref, [xr, wr, br], dy)
+    st = ops._stream()
+    xa, wa, ba, dya = x.to(dev), w.to(dev), b.to(dev), dy.to(dev)
+    y = torch.empty((B, N), dtype=torch.float32, device=dev)
+    _lib.call('sba_linear_fwd', xa.data_ptr(), wa.data_ptr(), ba.data_ptr(), y.data_ptr(), B, K, N, st)
+    dx = torch.full((B, K), float('nan'), dtype=torch.float32, device=dev)
+    dw = torch.ones((N, K), dtype=torch.float32, device=dev)
+    db = torch.ones((N,), dtype=torch.float32, device=dev)
+    _lib.call('sba_linear_bwd', xa.data_ptr(), wa.data_ptr(), dya.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(),
+              B, K, N, st)
+    torch.cuda.synchronize()
+    assert rel_l2(y.cpu(), yref.detach()) < 1e-5
+    assert rel_l2(dx.cpu(), gx) < 1e-5
+    assert rel_l2(dw.cpu() - 1.0, gw) < 1e-5
+    assert rel_l2(db.cpu() - 1.0, gb) < 1e-5
+
+
 @pytest.mark.parametrize('sd', [(64, 75), (256, 299), (17, 17), (5, 64)])
 def test_resize_backward_is_the_adjoint(dev, sd):
     """sba_resize_bilinear(backward): the gather form of the adjoint of F.interpolate(bilinear, align_corners=True)
