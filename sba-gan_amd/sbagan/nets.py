@@ -304,13 +304,23 @@ class NEXT_STAGE_G(nn.Module):
         self.upsample = upBlock(ngf * 2, ngf)
         self.return_attention = True
 
-    def forward(self, h_code, c_code, w_code, word_embs, mask):
+    def style_of(self, w_code):
+        """ADAIN_NORM.style(w) (model.py:330,335): needs the style code only"""
+        return _linear(w_code, getattr(self, self._adain_name).style)
+
+    def keys_of(self, word_embs):
+        """GlobalAttentionGeneral.conv_context(words) (GlobalAttention.py:97): needs the captions only"""
+        return ops.CtxProjFn.apply(word_embs, self.att.conv_context.weight)
+
+    def forward(self, h_code, c_code, w_code, word_embs, mask, style=None, keys=None):
+        """style / keys: style_of(w_code) / keys_of(word_embs) when the caller has evaluated them already (beside the
+        first stage, on the mapping network's stream: _GBase._styles)"""
         self.att.applyMask(mask)
-        adain = getattr(self, self._adain_name)
-        style = _linear(w_code, adain.style)
+        if style is None:
+            style = self.style_of(w_code)
         mode = 0 if self.att.reference_mask_order else 1
         hc, att = ops.AttnAdainCatFn.apply(h_code, style, word_embs, self.att.conv_context.weight, mask,
-                                           self.return_attention, mode)
+                                           self.return_attention, mode, keys)
         out = hc
         for blk in self.residual:
             out = blk(out)
@@ -391,7 +401,15 @@ class _GBase(nn.Module):
     on_image = None          # callable(i): called right after fake image i has been issued (the trainer forks the
     #                          update of discriminator i from that point instead of from the end of the forward pass)
 
-    def _styles(self, *zs):
+    # Round 4, last third: the same side stream also evaluates what each later stage needs of w and of the captions BEFORE
+    # it can start -- its AdaIN style projection (a 17 us dense layer of pure latency) and its attention's key projection
+    # conv_context(words) (22 us) -- so that they leave the serial chain of the generator's forward pass, and (autograd
+    # replays a node's backward on its forward's stream) their backward passes (ctx_proj_bwd_w 42 us, linear_bwd) leave the
+    # serial chain of its backward pass.  Same kernels, same operands.  SBA_FORK_CTX=0: inside the stages, as before.
+    fork_ctx = os.environ.get('SBA_FORK_CTX', '1') != '0'
+
+    def _styles(self, *zs, word_embs=None):
+        self._pre = None
         if not (self.fork_mapping and zs[0].is_cuda):
             return [self.mapping_net(z) for z in zs], None
         main = torch.cuda.current_stream()
@@ -401,6 +419,9 @@ class _GBase(nn.Module):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             ws = [self.mapping_net(z) for z in zs]
+            if self.fork_ctx and self._fork_guard and word_embs is not None and self.branch_num > 1:
+                stages = [(self.h_net2, ws[0])] + ([(self.h_net3, ws[-1])] if self.branch_num > 2 else [])
+                self._pre = [(st.style_of(w), st.keys_of(word_embs)) for st, w in stages]
         return ws, (main, side)
 
     def _emit(self, fake_imgs, img):
@@ -415,18 +436,24 @@ class _GBase(nn.Module):
         if self.branch_num > 0:
             h = self.h_net1(c_code, z1, None) if self.h_net1.cond_only else self.h_net1(z1, c_code)
             self._emit(fake_imgs, self.img_net1(h))
+        pre = [(None, None), (None, None)]
         if join is not None:
             join[0].wait_stream(join[1])
             if self._fork_guard:
                 ws = [_CrossStream.apply(w, join[0], join[1]) for w in ws]
                 w2, w3 = ws[0], ws[-1]
+                if getattr(self, '_pre', None):
+                    got = [(_CrossStream.apply(s, join[0], join[1]), _CrossStream.apply(k, join[0], join[1]))
+                           for s, k in self._pre]
+                    pre = got + pre[len(got):]
+                    self._pre = None
         if self.branch_num > 1:
-            h, att1 = self.h_net2(h, c_code, w2, word_embs, mask)
+            h, att1 = self.h_net2(h, c_code, w2, word_embs, mask, style=pre[0][0], keys=pre[0][1])
             self._emit(fake_imgs, self.img_net2(h))
             if att1 is not None:
                 att_maps.append(att1)
         if self.branch_num > 2:
-            h, att2 = self.h_net3(h, c_code, w3, word_embs, mask)
+            h, att2 = self.h_net3(h, c_code, w3, word_embs, mask, style=pre[1][0], keys=pre[1][1])
             self._emit(fake_imgs, self.img_net3(h))
             if att2 is not None:
                 att_maps.append(att2)
@@ -442,7 +469,7 @@ class G_NET(_GBase):
         self._build(6, False, 'adain')
 
     def forward(self, z_code, sent_emb, word_embs, mask):
-        ws, join = self._styles(z_code)
+        ws, join = self._styles(z_code, word_embs=word_embs)
         return self._run(z_code, ws, join, sent_emb, word_embs, mask)
 
 
@@ -454,7 +481,7 @@ class G_NET_BERT(_GBase):
         self._build(8, True, 'adain2')
 
     def forward(self, z_code, sent_emb, word_embs, mask):
-        ws, join = self._styles(z_code)
+        ws, join = self._styles(z_code, word_embs=word_embs)
         return self._run(z_code, ws, join, sent_emb, word_embs, mask)
 
 
@@ -466,7 +493,7 @@ class G_NET_MIX(_GBase):
         self._build(8, True, 'adain2')
 
     def forward(self, z_code, sent_emb, word_embs, mask):
-        ws, join = self._styles(z_code[0], z_code[1])
+        ws, join = self._styles(z_code[0], z_code[1], word_embs=word_embs)
         return self._run(z_code, ws, join, sent_emb, word_embs, mask)
 
 

@@ -1069,13 +1069,45 @@ def _mask_u8(mask):
     return mask.to(torch.uint8).contiguous()
 
 
+class CtxProjFn(torch.autograd.Function):
+    """conv_context of GlobalAttentionGeneral (GlobalAttention.py:75,97) as a node of its own: src[b] = W words[b] depends on
+    the captions and the weight only, so the generator evaluates it beside its first stage (nets._GBase._styles) and hands
+    it to AttnAdainCatFn; autograd replays this node's backward on the stream of its forward."""
+
+    @staticmethod
+    def forward(ctx, words, w_ctx):
+        words = words.float().contiguous()
+        N, cdf, L = words.shape
+        C = w_ctx.shape[0]
+        src = torch.empty((N, C, L), dtype=torch.float32, device=words.device)
+        _ctx_proj_fwd(words, w_ctx.detach().reshape(C, cdf), src, N, C, cdf, L)
+        ctx.save_for_backward(words)
+        ctx.w_ctx = w_ctx
+        return src
+
+    @staticmethod
+    def backward(ctx, dsrc):
+        (words,) = ctx.saved_tensors
+        dsrc = dsrc.float().contiguous()
+        N, cdf, L = words.shape
+        C = ctx.w_ctx.shape[0]
+        dwords = torch.empty_like(words) if ctx.needs_input_grad[0] else None
+        wc = ctx.w_ctx.detach().reshape(C, cdf)
+        if ctx.needs_input_grad[1] or dwords is not None:
+            dW = param_grad(ctx.w_ctx) if ctx.needs_input_grad[1] else torch.zeros_like(wc)
+            call('sba_ctx_proj_bwd', _p(words), _p(wc), _p(dsrc), _p(dW), _p(dwords), N, C, cdf, L, _stream())
+        return dwords, None
+
+
 class AttnAdainCatFn(torch.autograd.Function):
     """Entry of NEXT_STAGE_G (model.py:415-418): word attention (GlobalAttention.py:82-121),
     AdaIN (model.py:332-339) and the channel concat, written straight into one NHWC
     tensor [adain(h) | ctx].  Returns (h_c_code, att or empty)."""
 
     @staticmethod
-    def forward(ctx, h, style, words, w_ctx, mask, want_att, mask_mode):
+    def forward(ctx, h, style, words, w_ctx, mask, want_att, mask_mode, src_in=None):
+        """src_in: the key projection when the caller has evaluated it already (CtxProjFn): its gradient is then returned
+        instead of being folded into dW / dwords here"""
         h = as_act(h)
         N, C, H, W = h.shape
         HW = H * W
@@ -1084,9 +1116,13 @@ class AttnAdainCatFn(torch.autograd.Function):
         style = style.float().contiguous()
         m8 = _mask_u8(mask)
         dev = h.device
-        src = torch.empty((N, C, L), dtype=torch.float32, device=dev)
-        wc = w_ctx.detach().reshape(C, cdf)
-        _ctx_proj_fwd(words, wc, src, N, C, cdf, L)
+        ctx.src_given = src_in is not None
+        if src_in is not None:
+            src = src_in.float().contiguous()
+        else:
+            src = torch.empty((N, C, L), dtype=torch.float32, device=dev)
+            wc = w_ctx.detach().reshape(C, cdf)
+            _ctx_proj_fwd(words, wc, src, N, C, cdf, L)
         out = empty_act(N, 2 * C, H, W, h)
         att = torch.empty((N, L, H, W), dtype=torch.float32, device=dev) if want_att else None
         _word_attn_fwd(h, src, m8, out, att, N, HW, C, L, mask_mode, 2 * C, C)
@@ -1119,12 +1155,14 @@ class AttnAdainCatFn(torch.autograd.Function):
         dstyle = torch.empty_like(style)
         call('sba_adain_bwd_apply', _dt(h), _p(h), _p(dout), _p(mr[0]), _p(mr[1]), _p(style), _p(red), _p(dh),
              _p(dstyle), N, HW, C, 2 * C, 0, 1, _stream())
+        if ctx.src_given:
+            return dh, dstyle, None, None, None, None, None, dsrc
         dwords = torch.empty_like(words) if ctx.needs_input_grad[2] else None
         wc = ctx.w_ctx.detach().reshape(C, cdf)
         if ctx.needs_input_grad[3] or dwords is not None:
             dW = param_grad(ctx.w_ctx) if ctx.needs_input_grad[3] else torch.zeros_like(wc)
             call('sba_ctx_proj_bwd', _p(words), _p(wc), _p(dsrc), _p(dW), _p(dwords), N, C, cdf, L, _stream())
-        return dh, dstyle, dwords, None, None, None, None
+        return dh, dstyle, dwords, None, None, None, None, None
 
 
 class WordAttnFn(torch.autograd.Function):
