@@ -1066,6 +1066,8 @@ def _word_attn_fwd(h, src, m8, out, att, N, HW, C, L, mask_mode, ocs, oco):
 def _mask_u8(mask):
     if mask is None:
         return None
+    if mask.dtype == torch.bool and mask.is_contiguous():
+        return mask.view(torch.uint8)       # the same bytes (False / True are stored as 0 / 1): no conversion launch
     return mask.to(torch.uint8).contiguous()
 
 

@@ -849,8 +849,9 @@ def test_init_stage_and_conditioning(dev, dt):
     close(imgs[0], imgs_r[0], dt, 'img64', scale=4)
     close(mu, mu_r, torch.float32, 'mu'); close(lv, lv_r, torch.float32, 'logvar')
     # BatchNorm1d over a batch of 4 right behind the fc amplifies summation-order differences of the
-    # dense layers (each within 5e-7 of an f64 reference, tools/debug_linear.py) by |x|/sigma
-    _check_module(g, Q, dt, '', gscale=20)
+    # dense layers (each within 5e-7 of an f64 reference, tools/debug_linear.py: 3.2e-7 / 4.5e-7 / 7e-8 for y / dx / dW of
+    # the 16384-column fc on the matrix-core kernels) by |x|/sigma: the per-element bound is 40x the plain f32 one
+    _check_module(g, Q, dt, '', gscale=40)
 
 
 def test_damsm_losses(dev):
