@@ -663,6 +663,54 @@ __global__ __launch_bounds__(256) void instnorm_accum_kernel(const T* __restrict
     }
 }
 
+// The same statistics in ONE launch, no atomics, no clearing, no finalize pass: workgroup (n, tc) owns 16-byte channel vector tc
+// of image n over all HW pixels -- each thread sums its pixels (four loads in flight), the 256 partial sums meet in a fixed
+// order through LDS, thread 0..V-1 write mean and rstd.  Three launches (clear, accumulate, finalize: 28-35 us alone at the
+// entry of a generator stage, serial time of the step) become one; deterministic by construction.
+template <typename T>
+__global__ __launch_bounds__(256) void instnorm_stats_fused_kernel(const T* __restrict__ h, float* __restrict__ mean,
+                                                                   float* __restrict__ rstd, int HW, int C, float eps) {
+    constexpr int V = Vec16<T>::N;
+    const int n = blockIdx.x, tc = blockIdx.y, tid = threadIdx.x;
+    const T* base = h + (int64_t)n * HW * C + tc * V;
+    float s0[V], s1[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) s0[k] = s1[k] = 0.f;
+    int p = tid;
+    for (; p + 3 * 256 < HW; p += 4 * 256) {
+        Vec16<T> a0 = ld16(base + (int64_t)p * C), a1 = ld16(base + (int64_t)(p + 256) * C);
+        Vec16<T> a2 = ld16(base + (int64_t)(p + 512) * C), a3 = ld16(base + (int64_t)(p + 768) * C);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float v0 = a0.get(k), v1 = a1.get(k), v2 = a2.get(k), v3 = a3.get(k);
+            s0[k] += (v0 + v1) + (v2 + v3);
+            s1[k] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+        }
+    }
+    for (; p < HW; p += 256) {
+        Vec16<T> a = ld16(base + (int64_t)p * C);
+#pragma unroll
+        for (int k = 0; k < V; ++k) { const float v = a.get(k); s0[k] += v; s1[k] += v * v; }
+    }
+    __shared__ float s_part[4][2 * V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        float a = s0[k], b = s1[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        if ((tid & 63) == 0) { s_part[tid >> 6][k] = a; s_part[tid >> 6][V + k] = b; }
+    }
+    __syncthreads();
+    if (tid < V) {
+        const float sm = (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]);
+        const float sq = (s_part[0][V + tid] + s_part[1][V + tid]) + (s_part[2][V + tid] + s_part[3][V + tid]);
+        const float m = sm / (float)HW;
+        const float var = fmaxf(sq / (float)HW - m * m, 0.f);
+        mean[n * C + tc * V + tid] = m;
+        rstd[n * C + tc * V + tid] = rsqrtf(var + eps);
+    }
+}
+
 __global__ __launch_bounds__(256) void instnorm_finalize_kernel(float* __restrict__ mean, float* __restrict__ rstd, int NC,
                                          float HW, float eps) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1015,8 +1063,15 @@ extern "C" int sba_instnorm_stats(int dtype, const void* h, float* mean, float* 
                                   float eps, void* stream) {
     if (!h || !mean || !rstd || !in_shape_ok(dtype, N, HW, C)) return SBA_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-    sba_zero_f32(mean, rstd, (int64_t)N * C, st);
     const int V = dtype != SBA_F32 ? 8 : 4;
+    static int fused = -1;      // SBA_INSTNORM_FUSED=0: clear + accumulate (atomics) + finalize (A/B aid)
+    if (fused < 0) { const char* e = getenv("SBA_INSTNORM_FUSED"); fused = (e && e[0] == '0') ? 0 : 1; }
+    if (fused && N * (C / V) >= 64 && HW >= 1024) {        // enough workgroups of enough pixels: one launch
+        SBA_DISPATCH(dtype, SBA_LAUNCH((instnorm_stats_fused_kernel<T>), dim3(N, C / V), dim3(256), 0, st, (const T*)h, mean,
+                                               rstd, HW, C, eps));
+        return SBA_CHECK_LAUNCH();
+    }
+    sba_zero_f32(mean, rstd, (int64_t)N * C, st);
     const int rpi = 256 / (C / V);
     int splits = cdiv(HW, rpi * 16);
     if (splits > 256) splits = 256;
