@@ -430,6 +430,7 @@ class _GBase(nn.Module):
             self.on_image(len(fake_imgs) - 1)
 
     def _run(self, z1, ws, join, sent_emb, word_embs, mask):
+        ops.reset_mask_cache()
         w2, w3 = ws[0], ws[-1]
         fake_imgs, att_maps = [], []
         c_code, mu, logvar = self.ca_net(sent_emb)

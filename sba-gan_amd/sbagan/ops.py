@@ -1068,7 +1068,29 @@ def _mask_u8(mask):
         return None
     if mask.dtype == torch.bool and mask.is_contiguous():
         return mask.view(torch.uint8)       # the same bytes (False / True are stored as 0 / 1): no conversion launch
-    return mask.to(torch.uint8).contiguous()
+    # (a sliced mask -- trainer.py:253-256 cuts it to the longest caption -- is not contiguous.)  Both later stages of the
+    # generator pass the SAME mask object: convert it once per generator forward (the cache is cleared at the start of every
+    # forward, nets._GBase._run -- a recording must hold its own conversion launch, the caller refills a static mask between
+    # replays) and per content (tensor identity + version counter)
+    global _MASK_U8_CACHE
+    c = _MASK_U8_CACHE
+    if c is not None and c[0]() is mask and c[1] == mask._version and c[2].device == mask.device:
+        return c[2]
+    import weakref
+    u8 = mask.to(torch.uint8).contiguous()
+    try:
+        _MASK_U8_CACHE = (weakref.ref(mask), mask._version, u8)
+    except TypeError:
+        _MASK_U8_CACHE = None
+    return u8
+
+
+_MASK_U8_CACHE = None
+
+
+def reset_mask_cache():
+    global _MASK_U8_CACHE
+    _MASK_U8_CACHE = None
 
 
 class CtxProjFn(torch.autograd.Function):
