@@ -105,17 +105,18 @@ __global__ __launch_bounds__(64) void linear_fwd_mfma_kernel(const float* __rest
 
 // dx[b][k] = sum_n dy[b][n] w[n][k]: tile = 32 input features, reduction over N
 // blockIdx.y = slice of `nper` output features of the reduction (atomic accumulation when sliced)
-__global__ __launch_bounds__(64) void linear_bwd_x_mfma_kernel(const float* __restrict__ w, const float* __restrict__ dy,
-                                                               float* __restrict__ dx, int B, int K, int N, int nper) {
+__device__ __forceinline__ void linear_bwd_x_mfma_body(const float* __restrict__ w, const float* __restrict__ dy,
+                                                       float* __restrict__ dx, int B, int K, int N, int nper,
+                                                       const int bx, const int by, const int ny) {
     const int lane = threadIdx.x, rl = lane & 31, hf = lane >> 5;
-    const int k = blockIdx.x * 32 + rl;
+    const int k = bx * 32 + rl;
     const bool kv = k < K, bv = rl < B;
     const float* dr = dy + (int64_t)(bv ? rl : 0) * N;
     const float* wc = w + (kv ? k : 0);
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int n_lo = blockIdx.y * nper, n_hi = min(n_lo + nper, N);
+    const int n_lo = by * nper, n_hi = min(n_lo + nper, N);
     for (int n0 = n_lo; n0 < n_hi; n0 += 32) {
         float4 dv[8];
         float wv[16];
@@ -140,19 +141,24 @@ __global__ __launch_bounds__(64) void linear_bwd_x_mfma_kernel(const float* __re
         for (int r = 0; r < 16; ++r) {
             const int b = (r & 3) + 8 * (r >> 2) + 4 * hf;
             if (b < B) {
-                if (gridDim.y > 1) atomicAdd(&dx[(int64_t)b * K + k], acc[r]);
+                if (ny > 1) atomicAdd(&dx[(int64_t)b * K + k], acc[r]);
                 else dx[(int64_t)b * K + k] = acc[r];
             }
         }
     }
 }
 
+__global__ __launch_bounds__(64) void linear_bwd_x_mfma_kernel(const float* __restrict__ w, const float* __restrict__ dy,
+                                                               float* __restrict__ dx, int B, int K, int N, int nper) {
+    linear_bwd_x_mfma_body(w, dy, dx, B, K, N, nper, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+}
+
 // dw[n][k] += sum_b dy[b][n] x[b][k]; dbias[n] += sum_b dy[b][n].  grid = (K tiles, N tiles)
-__global__ __launch_bounds__(64) void linear_bwd_w_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                               float* __restrict__ dw, float* __restrict__ dbias,
-                                                               int B, int K, int N) {
+__device__ __forceinline__ void linear_bwd_w_mfma_body(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ dw, float* __restrict__ dbias,
+                                                       int B, int K, int N, const int bx, const int by) {
     const int lane = threadIdx.x, rl = lane & 31, hf = lane >> 5;
-    const int k = blockIdx.x * 32 + rl, n = blockIdx.y * 32 + rl;
+    const int k = bx * 32 + rl, n = by * 32 + rl;
     const bool kv = k < K, nv = n < N;
     f32x16_t acc;
 #pragma unroll
@@ -169,17 +175,35 @@ __global__ __launch_bounds__(64) void linear_bwd_w_mfma_kernel(const float* __re
     if (kv) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int nn = blockIdx.y * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            const int nn = by * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
             if (nn < N) dw[(int64_t)nn * K + k] += acc[r];
         }
     }
-    if (dbias && blockIdx.x == 0) {
+    if (dbias && bx == 0) {
         float sb = 0.f;
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) sb += av[kk];
         sb += __shfl_xor(sb, 32, 64);
         if (hf == 0 && nv) dbias[n] += sb;
     }
+}
+
+__global__ __launch_bounds__(64) void linear_bwd_w_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ dw, float* __restrict__ dbias,
+                                                               int B, int K, int N) {
+    linear_bwd_w_mfma_body(x, dy, dw, dbias, B, K, N, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// dx AND dW of one small layer in ONE launch: workgroups [0, kt) are the dx tiles (one slice: no atomics), the rest the
+// (K tile, N tile) grid of dW -- they read the same three tensors and write disjoint outputs.  The mapping network's backward
+// pass is a chain of 6 / 8 such layers at the very end of the step (two ~15 us launches each, pure latency).
+__global__ __launch_bounds__(64) void linear_bwd_xw_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ dy, float* __restrict__ dx,
+                                                                float* __restrict__ dw, float* __restrict__ dbias,
+                                                                int B, int K, int N, int kt) {
+    const int b = (int)blockIdx.x;
+    if (b < kt) linear_bwd_x_mfma_body(w, dy, dx, B, K, N, N, b, 0, 1);
+    else linear_bwd_w_mfma_body(x, dy, dw, dbias, B, K, N, (b - kt) % kt, (b - kt) / kt);
 }
 
 // attention key projection (conv_context, GlobalAttention.py:75,97) on the f32 matrix cores.
@@ -414,6 +438,11 @@ extern "C" int sba_linear_bwd(const float* x, const float* w, const float* dy, f
     if (!x || !w || !dy || B <= 0 || K <= 0 || N <= 0) return SBA_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (B <= 32 && N % 4 == 0 && (N <= 2048 || (N % 32 == 0 && cdiv(N, 32) <= 65535))) {
+        if (dw && dx && N <= 2048) {        // one launch for both (linear_bwd_xw_mfma_kernel)
+            const int kt = cdiv(K, 32);
+            SBA_LAUNCH(linear_bwd_xw_mfma_kernel, dim3(kt + kt * cdiv(N, 32)), dim3(64), 0, st, x, w, dy, dx, dw, dbias, B, K, N, kt);
+            return SBA_CHECK_LAUNCH();
+        }
         if (dw) SBA_LAUNCH(linear_bwd_w_mfma_kernel, dim3(cdiv(K, 32), cdiv(N, 32)), dim3(64), 0, st, x, dy, dw, dbias, B, K, N);
         if (dx && (N <= 2048 || sba_det_on())) {     // (deterministic mode: one slice, no atomics)
             SBA_LAUNCH(linear_bwd_x_mfma_kernel, dim3(cdiv(K, 32)), dim3(64), 0, st, w, dy, dx, B, K, N, N);
