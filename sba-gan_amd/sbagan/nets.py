@@ -424,10 +424,25 @@ class _GBase(nn.Module):
                 self._pre = [(st.style_of(w), st.keys_of(word_embs)) for st, w in stages]
         return ws, (main, side)
 
-    def _emit(self, fake_imgs, img):
+    image_stream = None      # callable(i) -> the stream image head i runs on, or None for the current one (the trainer names
+    #                          the stream discriminator i is updated on for every image but the last: a head whose image
+    #                          only that discriminator reads leaves the serial chain of the generator's forward pass, and
+    #                          -- autograd replays a node's backward on its forward's stream -- of its backward pass)
+
+    def _emit(self, fake_imgs, net, h):
+        i = len(fake_imgs)
+        st = self.image_stream(i) if (self.image_stream is not None and h.is_cuda) else None
+        if st is None:
+            img = net(h)
+        else:
+            main = torch.cuda.current_stream()
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                # h: produced on `main`, read on `st`; its gradient: produced on `st`, read on `main`
+                img = net(_CrossStream.apply(h, st, main))
         fake_imgs.append(img)
         if self.on_image is not None:
-            self.on_image(len(fake_imgs) - 1)
+            self.on_image(i)
 
     def _run(self, z1, ws, join, sent_emb, word_embs, mask):
         ops.reset_mask_cache()
@@ -436,7 +451,7 @@ class _GBase(nn.Module):
         c_code, mu, logvar = self.ca_net(sent_emb)
         if self.branch_num > 0:
             h = self.h_net1(c_code, z1, None) if self.h_net1.cond_only else self.h_net1(z1, c_code)
-            self._emit(fake_imgs, self.img_net1(h))
+            self._emit(fake_imgs, self.img_net1, h)
         pre = [(None, None), (None, None)]
         if join is not None:
             join[0].wait_stream(join[1])
@@ -450,12 +465,12 @@ class _GBase(nn.Module):
                     self._pre = None
         if self.branch_num > 1:
             h, att1 = self.h_net2(h, c_code, w2, word_embs, mask, style=pre[0][0], keys=pre[0][1])
-            self._emit(fake_imgs, self.img_net2(h))
+            self._emit(fake_imgs, self.img_net2, h)
             if att1 is not None:
                 att_maps.append(att1)
         if self.branch_num > 2:
             h, att2 = self.h_net3(h, c_code, w3, word_embs, mask, style=pre[1][0], keys=pre[1][1])
-            self._emit(fake_imgs, self.img_net3(h))
+            self._emit(fake_imgs, self.img_net3, h)
             if att2 is not None:
                 att_maps.append(att2)
         return fake_imgs, att_maps, mu, logvar

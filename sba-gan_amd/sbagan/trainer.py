@@ -605,8 +605,11 @@ class GANStep(object):
                     img_ready[i] = torch.cuda.Event()
                     img_ready[i].record()
             self.netG.on_image = on_image
+            if self.fork_heads:
+                self.netG.image_stream = lambda i: streams[i] if (i < nD - 1 and streams[i] is not main) else None
         self.phase_a(sent_emb, words_embs, mask, noise, eps)
         self.netG.on_image = None
+        self.netG.image_stream = None
         mark('g_forward')
         # The three discriminator updates are independent of each other (different networks, the
         # same detached fakes): each runs on its own HIP stream so that the small launches of the
@@ -652,6 +655,10 @@ class GANStep(object):
 
     concurrent_d = True
     early_d = os.environ.get('SBA_EARLY_D', '1') == '1'      # fork the 64 / 128 px discriminator updates inside the G forward
+    fork_heads = os.environ.get('SBA_FORK_HEADS', '0') == '1'      # ... and evaluate the 64 / 128 px image heads on those
+    #                                                              discriminators' streams (nets._GBase.image_stream).  Bit-equal
+    #                                                              and audit-clean, but no measurable gain: 9.42 / 9.53 against
+    #                                                              9.52 / 9.39 ms (profiles/r04_ab_fork_heads.txt).  Off.
     bucket_adam = os.environ.get('SBA_BUCKET_ADAM', '0') == '1'      # D_NET128 / D_NET256: Adam of the tail + heads beside the
     #                                                                  trunk's backward pass (phase_d_bwd).  Correct (the GPU
     #                                                                  suite passes with it on) but measured SLOWER: 11.50
