@@ -518,7 +518,7 @@ def main():
     if dp_graph is not None:
         graph = dp_graph
         if dp_mode == '4':      # (a step with its collectives: after the ranks have agreed on the launch mode)
-            graph.prioritize(verbose=1)
+            graph.prioritize(verbose=int(os.environ.get("SBA_REPLAY_PRIO_VERBOSE", "1")))
         for _ in range(2):
             graph.replay()
         torch.cuda.synchronize()

@@ -148,6 +148,7 @@ class ExchangeRecorder(object):
         self.exchange = exchange
         self.calls = []                 # tag -> ('start', tensor) | ('wait', start tag) | ('host', callable)
         self.live = {}                  # start tag -> handle of the exchange started by the current replay
+        self.recorded_update = False    # the recording holds the deferred generator update as launches (GANStep.finish)
 
     def _mark(self, entry):
         tag = len(self.calls)
@@ -304,9 +305,31 @@ class GANStep(object):
         a host-call node: whether an update is pending is host state, so every replay applies it from the host, here."""
         rec = self.exchange.recorder
         if rec is not None:
-            rec.host(self._finish_replayed)
+            if self.record_g_update:
+                # Only the WAIT for the exchange in flight is a host call (which handle to wait for is host state); the
+                # Adam + EMA launch and the repack of the bf16 weight copies are recorded like any other launch -- as
+                # eager launches issued from the callback they cost 0.38 ms at the head of the generator's forward pass
+                # (profiles/r04_dp_recorded_update.txt).  A replay therefore REQUIRES a pending update: ReplayedStep
+                # runs an eager step instead when there is none (after finish() / restore()).
+                rec.host(self._wait_pending_replayed)
+                self.optG.step(1.0 / self.world)
+                if self.flatG.packs is not None:
+                    self.flatG.packs.refresh(ops.compute_dtype())
+                rec.recorded_update = True
+            else:
+                rec.host(self._finish_replayed)
             return
         self._finish_now()
+
+    record_g_update = os.environ.get('SBA_DP_RECORD_UPDATE', '1') == '1'
+
+    def _wait_pending_replayed(self):
+        """the host-call node in front of the RECORDED generator update: order the node's stream behind the exchange the
+        previous step left in flight"""
+        if self._g_pending is None:
+            raise RuntimeError('the recorded generator update was replayed with no update pending')
+        h, self._g_pending = self._g_pending, None
+        self._allreduce_wait(h[0])
 
     def _finish_now(self):
         if self._g_pending is not None:
@@ -1070,6 +1093,7 @@ class ReplayedStep(object):
         self.gan, self.noise, self.prologue = gan, noise, prologue
         dev = gan.device
         args = (imgs, sent_emb, words_embs, mask, cap_lens, class_ids, noise)
+        self._args, self._recorded_prologue = args, recorded_prologue
         if warm is None:
             warm = self.warm_up(gan, *args, recorded_prologue=recorded_prologue)
         self.eps, self.cap = warm['eps'], warm['cap']
@@ -1154,6 +1178,8 @@ class ReplayedStep(object):
         streams = int(f[1]) if len(f) > 1 else 6
         n_high = int(f[2]) if len(f) > 2 else 2
         slack = float(f[3]) if len(f) > 3 else 0.08
+        if self._no_update_pending():
+            self._eager_step()          # (now one is)
         ops.weights_changed()
         self._draw()
         call('sba_replay_prioritize', self.handle, torch.cuda.current_stream().cuda_stream, mode, streams, n_high,
@@ -1164,7 +1190,26 @@ class ReplayedStep(object):
         self._refresh_info()
         return self.out
 
+    def _no_update_pending(self):
+        """data-parallel, the deferred generator update recorded as launches: the recording applies an update whenever
+        it runs, so it must not run when none is pending (after finish(), restore(), resync())"""
+        return self._rec is not None and self._rec.recorded_update and self.gan._g_pending is None
+
+    def _eager_step(self):
+        """the same step, launched eagerly (bit-identical in the deterministic mode); leaves an update pending"""
+        ops.weights_changed()
+        self._draw()
+        if self._recorded_prologue is not None:
+            self._recorded_prologue()
+        out = self.gan.step(*self._args, eps=self.eps)
+        for k, v in out.items():
+            if k in self.out:
+                self.out[k].copy_(v)
+        return self.out
+
     def replay(self):
+        if self._no_update_pending():
+            return self._eager_step()
         ops.weights_changed()
         self._draw()
         call('sba_replay_launch', self.handle, torch.cuda.current_stream().cuda_stream)
