@@ -150,6 +150,31 @@ def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake
     return ops.BCEMultiFn.apply((1., 0., 0.), (1., .5, .5), cond_real, cond_fake, cond_wrong)
 
 
+def discriminator_real_term(netD, real_features, conditions):
+    """The terms of errD that read the REAL images only (losses.py:141-149: real, cond_real and the wrong-pair term, with
+    their weights 1/2, 1/2, 1/3), as one node over netD(real_imgs): they depend on neither the generator nor the fake
+    images, so a trainer can run their backward pass ahead of the fake half (GANStep.real_bwd_early).  Beyond the
+    reference: the conditional head's BatchNorm then sees its batches in the order real, wrong, fake instead of real,
+    fake, wrong (running statistics only; nothing reads them in training)."""
+    n = real_features.size(0)
+    if netD.UNCOND_DNET is not None:
+        heads = ((0, n, 0, 1., .5, 1), (0, n - 1, 1, 0., 1. / 3, 2), (0, n, None, 1., .5, 0))
+    else:
+        heads = ((0, n, 0, 1., 1., 0), (0, n - 1, 1, 0., .5, 1))
+    return ops.d_heads(netD, real_features, conditions, heads)
+
+
+def discriminator_fake_term(netD, fake_imgs, conditions):
+    """the terms of errD that read the fake images (losses.py:145-158: fake, cond_fake), as their own trunk pass"""
+    fake_features = netD(fake_imgs.detach())
+    n = fake_features.size(0)
+    if netD.UNCOND_DNET is not None:
+        heads = ((0, n, 0, 0., 1. / 3, 1), (0, n, None, 0., 1. / 3, 0))
+    else:
+        heads = ((0, n, 0, 0., .5, 0),)
+    return ops.d_heads(netD, fake_features, conditions, heads)
+
+
 def damsm_image_terms(image_encoder, fake_img, words_embs, sent_emb, match_labels, cap_lens, class_ids):
     """The DAMSM ranking terms of generator_loss (losses.py:187-204) for one batch of fake images, together with
     their gradient with respect to the images: returns (w_loss, s_loss, d(w_loss + s_loss)/d fake_img).

@@ -19,7 +19,7 @@ import torch.distributed as dist
 
 from miscc.config import cfg
 from miscc.losses import (KL_loss, backward_with_image_grad, backward_with_image_grads, damsm_image_terms,
-                          discriminator_loss, generator_d_term,
+                          discriminator_fake_term, discriminator_loss, discriminator_real_term, generator_d_term,
                           generator_loss)
 
 from . import ops
@@ -244,6 +244,8 @@ class GANStep(object):
             first = next(getattr(d, name).parameters()) if name else None
             self._bucket_off.append(None if first is None else f.offset_of[id(first)])
         self._real_feats = [None] * len(netsD)
+        self._real_terms = [None] * len(netsD)
+        self._begun = False
         self._g_terms = [None] * len(netsD)
         self._adam_early = [None] * len(netsD)
         self._d_zeroed = [False] * len(netsD)
@@ -278,9 +280,15 @@ class GANStep(object):
     real_first = os.environ.get('SBA_REAL_FIRST', '0') == '1'
 
     def _two_pass(self):
-        return (self.distributed and self.overlap_g) or self.force_overlap_layout or self.real_first
+        return (self.distributed and self.overlap_g) or self.force_overlap_layout or self.real_first or self.real_bwd_early
 
-    def phase_pre(self, imgs, streams=None):
+    # Experiment (last hours of round 4): with the two-pass layout, ALSO the real half's loss terms and their backward pass
+    # at the start of the step (they need neither the generator nor the fake images), so that only the fake half's
+    # forward + backward pass is left between the generator's passes.  SBA_REAL_BWD_EARLY=1; see losses.discriminator_real_term
+    # for the one deviation (order of the conditional head's BatchNorm running-statistic updates).
+    real_bwd_early = os.environ.get('SBA_REAL_BWD_EARLY', '0') == '1'
+
+    def phase_pre(self, imgs, streams=None, sent_emb=None):
         """netD_i(real_i) for every discriminator, ahead of the generator's (pending) update; a no-op outside the
         overlapped data-parallel mode.  streams[i]: the stream discriminator i's update will run on -- autograd
         replays a node's backward on the stream of its forward, and the two passes of one network add into the same
@@ -295,6 +303,19 @@ class GANStep(object):
             if st is not main:
                 st.wait_stream(main)
             with torch.cuda.stream(st):
+                if self.real_bwd_early and sent_emb is not None and imgs[i].is_cuda:
+                    if self._d_frozen[i]:
+                        for p in d.parameters():
+                            p.requires_grad_(True)
+                        self._d_frozen[i] = False
+                    d.clear_cuts(record=False)
+                    if not self._d_zeroed[i]:
+                        self.flatD[i].zero_grad()
+                        self._d_zeroed[i] = True
+                    term = discriminator_real_term(d, d(imgs[i]), sent_emb)
+                    term.backward()
+                    self._real_terms[i] = term.detach()
+                    continue
                 d.clear_cuts()
                 self._real_feats[i] = d(imgs[i])
 
@@ -372,8 +393,11 @@ class GANStep(object):
     # loss, backward, Adam + EMA.  step() composes them with the eager stream forks.
     def phase_a(self, sent_emb, words_embs, mask, noise, eps=None):
         ops.SIDE_WGRAD = self.overlap_wgrad
-        ops.det_reset()                       # deterministic mode: the step's partial sums start at the ring's base
-        ops.ARENA.begin(self.device)          # one memset for all per-layer accumulators of the step
+        if self._begun:                       # (step() did both ahead of the early real-half backward pass)
+            self._begun = False
+        else:
+            ops.det_reset()                   # deterministic mode: the step's partial sums start at the ring's base
+            ops.ARENA.begin(self.device)      # one memset for all per-layer accumulators of the step
         self.netG.ca_net.eps = eps
         fake_imgs, _, mu, logvar = self.netG(noise, sent_emb, words_embs, mask)
         self._ctx = (fake_imgs, mu, logvar)
@@ -408,13 +432,19 @@ class GANStep(object):
         split = ((self.distributed and self.bucket_d) or self.force_overlap_layout or
                  (self.bucket_adam and self._forked_d)) and \
             self._bucket_off[i] is not None and not ops.SIDE_WGRAD
+        rt = self._real_terms[i]
+        self._real_terms[i] = None
         if rf is None:
             netD.clear_cuts(record=split)
-        errD = discriminator_loss(netD, imgs[i], fake_imgs[i], sent_emb, self.real_labels, self.fake_labels,
-                                  real_features=rf)
+        if rt is not None:          # the real half, backward pass included, ran at the start of the step (phase_pre)
+            errD = discriminator_fake_term(netD, fake_imgs[i], sent_emb)
+            self._out['errD%d' % i] = rt + errD.detach()
+        else:
+            errD = discriminator_loss(netD, imgs[i], fake_imgs[i], sent_emb, self.real_labels, self.fake_labels,
+                                      real_features=rf)
+            self._out['errD%d' % i] = errD.detach()
         cuts = list(netD._cuts)
         netD.clear_cuts(record=False)
-        self._out['errD%d' % i] = errD.detach()
         if split and cuts:
             gcuts = torch.autograd.grad(errD, cuts)         # heads + tail: their parameter gradients are complete now
             self._d_buckets[i] = (cuts, gcuts)
@@ -617,7 +647,11 @@ class GANStep(object):
                     with torch.cuda.stream(streams[i]):
                         self.flatD[i].zero_grad()
                     self._d_zeroed[i] = True
-        self.phase_pre(imgs, streams)         # (data-parallel: beside the generator's pending gradient exchange)
+        if self.real_bwd_early and self._two_pass():
+            ops.det_reset()
+            ops.ARENA.begin(self.device)
+            self._begun = True
+        self.phase_pre(imgs, streams, sent_emb)         # (data-parallel: beside the generator's pending gradient exchange)
         self.finish()
         # discriminator i reads fake image i only: its update forks from the point where that image has been issued
         # (64 px: after the first stage, 128 px: after the second), not from the end of the generator's forward pass
