@@ -242,6 +242,33 @@ def test_dependency_relaxations_do_not_change_a_bit(dev, det, encoder, dt):
     assert not d, ('relaxed dependencies vs the reference order', d[:8])
     d = _diff(run(True, bucket=True), ref, 'bucket_adam_' + tag)
     assert not d, ('bucketed discriminator update vs one Adam launch', d[:8])
+    # the 64 / 128 px image heads on their discriminators' streams (opt-in, SBA_FORK_HEADS: nets._GBase.image_stream)
+    st.fork_heads = True
+    try:
+        d = _diff(run(True), ref, 'fork_heads_' + tag)
+    finally:
+        st.fork_heads = False
+    assert not d, ('image heads on the discriminator streams vs the reference order', d[:8])
+
+    # The two-pass layouts (opt-in on one GPU, the data-parallel step's shape): real-image forwards first (real_first), and
+    # with the real half's loss terms + backward pass at the start of the step too (real_bwd_early).  They regroup sums
+    # (per-pass launches, the order the halves' gradients are added in), so they are held to rounding, not to bits: the
+    # losses, and -- in f32 -- the discriminators' gradients.
+    def two_pass(early):
+        st.real_first, st.real_bwd_early = True, early
+        try:
+            return run(True)
+        finally:
+            st.real_first = st.real_bwd_early = False
+    a, b2 = two_pass(False), two_pass(True)
+    again = two_pass(True)
+    assert not _diff(b2, again), 'the early real-half backward pass is not reproducible'
+    for k in a:
+        if k.startswith('loss/errD'):
+            assert abs(float(a[k]) - float(b2[k])) <= 2e-6 * abs(float(a[k])), (k, float(a[k]), float(b2[k]))
+            assert abs(float(a[k]) - float(ref[k])) <= (2e-5 if dt == torch.float32 else 2e-2) * abs(float(ref[k])), k
+        if k.startswith('grad/D') and dt == torch.float32:
+            assert rel_l2(b2[k], a[k]) < 1e-5, (k, rel_l2(b2[k], a[k]))
 
 
 def test_small_batch_discriminator_gradients_are_reproducible(dev, det):
