@@ -492,6 +492,10 @@ def main():
     dp_graph = None
     if args.graph and multi and dp_mode in ('1', '2', '3', '4'):
         from sbagan.trainer import ReplayedStep, ReplayedStepDP
+        if os.environ.get('SBA_DP_OVERLAP_G', '1') == '0':
+            # the alternative measured in profiles/r04_dp_overlap_g.txt: the generator's 30 MB exchange waited for where it is
+            # issued (exposed), the discriminator loss as ONE grouped real|fake pass instead of two passes
+            step.overlap_g = False
         flags = (step.overlap_g, step.bucket_d)
         a = (b['imgs'], b['sent_emb'], b['words_embs'], b['mask'], b['cap_lens'], b['class_ids'], noise)
         nstreams = int(os.environ.get('SBA_REPLAY_STREAMS', '4'))

@@ -326,7 +326,7 @@ class GANStep(object):
         a host-call node: whether an update is pending is host state, so every replay applies it from the host, here."""
         rec = self.exchange.recorder
         if rec is not None:
-            if self.record_g_update:
+            if self.record_g_update and self.distributed and self.overlap_g:
                 # Only the WAIT for the exchange in flight is a host call (which handle to wait for is host state); the
                 # Adam + EMA launch and the repack of the bf16 weight copies are recorded like any other launch -- as
                 # eager launches issued from the callback they cost 0.38 ms at the head of the generator's forward pass

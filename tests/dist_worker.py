@@ -281,6 +281,35 @@ def main():
     bad_out = [(k, got_out[k], want_out[k]) for k in want_out if got_out[k] != want_out[k]]
     expect(not bad and not bad_out, 'ReplayedStep (one recording, host-call exchanges) differs from the eager data-parallel '
            'step in %d tensors: %r; losses %r' % (len(bad), bad[:12], bad_out[:6]))
+    # ---- the single recording with the generator's exchange WAITED FOR where it is issued (bench.py: SBA_DP_OVERLAP_G=0; the
+    # discriminator loss as one grouped real|fake pass): no update is ever pending, so the recording must not hold the
+    # deferred update's launches (it would apply Adam twice), and two replays equal two eager steps of that layout
+    dp.restore(snap_dp)
+    rs.resync()
+    dp.overlap_g, dp.bucket_d = False, True
+    for _ in range(2):
+        eager_out = dp.step(*gargs)
+    torch.cuda.synchronize()
+    want = [t.clone() for t in state()]
+    want_out = {k: float(v) for k, v in eager_out.items()}
+    rs2 = ReplayedStep(dp, *gargs)
+    expect(not rs2._rec.recorded_update and dp._g_pending is None,
+           'exposed generator exchange: the recording holds a deferred update')
+    rs2.draw = False
+    rs2.eps.copy_(eps)
+    noise_in.copy_(noise_keep)
+    dp.restore(snap_dp)
+    rs2.resync()
+    for _ in range(2):
+        rs2.replay()
+    torch.cuda.synchronize()
+    got = state()
+    bad = [(names[i], rel_l2(a.float(), b.float())) for i, (a, b) in enumerate(zip(got, want)) if not torch.equal(a, b)]
+    got_out = {k: float(v) for k, v in rs2.out.items()}
+    bad_out = [(k, got_out[k], want_out[k]) for k in want_out if got_out[k] != want_out[k]]
+    expect(not bad and not bad_out, 'ReplayedStep (one recording, exposed generator exchange) differs from the eager '
+           'data-parallel step in %d tensors: %r; losses %r' % (len(bad), bad[:12], bad_out[:6]))
+    del rs2
     # ---- ReplayedStepDP with the generator's exchange deferred behind the next step's text encoder + real-image
     # forwards (recording R0), image encoder + DAMSM terms beside the discriminators' exchange.  Same bits as two eager
     # data-parallel steps with the same decomposition (two-pass discriminator loss, one bucket), and the ORDER north_star
